@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py -- kssd hot path on MI355X: genomes sketched/s (+ pairwise distances/s) at L3K10.
+
+One step = one pass of the hot path over one batch that is already resident in HBM:
+    sketch (scan + per-genome dedup)  ->  [N>1: RCCL all-gather of the packed sketches]
+    ->  inverted index of all reference sketches  ->  all-pairs rows of this rank's query block
+        (shared counts + Jaccard / MashD / containment / AafD, 36 B per pair)
+Workload = BASELINE.json configs[1]: 1 000 synthetic 5 Mb bacterial genomes per GPU (50 clades x 20 members,
+0.5-5 % substitutions, 1e-4 N), L3K10 shuffle, all-pairs.  Weak scaling: every rank sketches its own 1 000
+genomes; rank r's query block is its own genomes against the gathered N x 1 000 references.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import public_kssd_amd as K  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------
+# synthetic batch, generated and packed on the device (setup, untimed)
+# ------------------------------------------------------------------------------------------------------
+def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0):
+    """returns packed int32[words+slack], mask int32[...], chunk_off uint64[n+1], kept [(codes u8, nmask bool)]"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    chunks = (length + K.CHUNK_BASES - 1) // K.CHUNK_BASES
+    padded = chunks * K.CHUNK_BASES
+    packed = torch.zeros(n_genomes * chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
+    mask = torch.zeros(n_genomes * chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
+    wsh = (30 - 2 * torch.arange(16, device=dev, dtype=torch.int64))
+    msh = torch.arange(32, device=dev, dtype=torch.int64)
+    per = (n_genomes + n_clades - 1) // n_clades
+    kept = []
+    gi = 0
+    for c in range(n_clades):
+        anc = torch.randint(0, 4, (length,), generator=g, device=dev, dtype=torch.uint8)
+        for m in range(per):
+            if gi >= n_genomes:
+                break
+            rate = 0.005 + 0.045 * float(torch.rand((), generator=g, device=dev))
+            mut = torch.rand(length, generator=g, device=dev) < rate
+            add = torch.randint(1, 4, (length,), generator=g, device=dev, dtype=torch.uint8)
+            codes = torch.where(mut, (anc + add) & 3, anc)
+            nmask = torch.rand(length, generator=g, device=dev) < 1e-4
+            valid = ~nmask
+            codes_v = torch.where(valid, codes, torch.zeros_like(codes))
+            cp = torch.zeros(padded, dtype=torch.int64, device=dev)
+            cp[:length] = codes_v
+            vp = torch.zeros(padded, dtype=torch.int64, device=dev)
+            vp[:length] = valid
+            w = (cp.view(-1, 16) << wsh).sum(1)
+            mw = (vp.view(-1, 32) << msh).sum(1)
+            packed[gi * chunks * K.CHUNK_WORDS:(gi + 1) * chunks * K.CHUNK_WORDS] = w.to(torch.int32)
+            mask[gi * chunks * K.CHUNK_MASKW:(gi + 1) * chunks * K.CHUNK_MASKW] = mw.to(torch.int32)
+            if gi < keep_codes:
+                kept.append((codes.cpu().numpy(), nmask.cpu().numpy()))
+            gi += 1
+    chunk_off = np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(chunks)
+    return packed, mask, chunk_off, kept
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1, bounded sample)
+# ------------------------------------------------------------------------------------------------------
+def cpu_baseline(shuf, kept, cores, gpu_sets):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kssd_oracle as ko
+    from synth import fasta_text
+    texts = [fasta_text(c, b"g%d" % i, n_mask=m) for i, (c, m) in enumerate(kept)]
+    nb = sum(len(c) for c, _ in kept)
+    out = {}
+    # the port (our C restatement of the reference algorithm), OpenMP over genomes like run_stageI
+    t0 = time.time()
+    off, ids = ko.sketch_texts(shuf.table, shuf.k, shuf.subk, shuf.drlevel, texts, threads=cores)
+    t_port = time.time() - t0
+    # parity of the bench inputs while we are here: the GPU sketches of the sample must equal the oracle's
+    for g in range(len(texts)):
+        want = np.sort(ids[int(off[g]):int(off[g + 1])])
+        assert np.array_equal(gpu_sets[g], want), "bench sample genome %d: GPU sketch != oracle" % g
+    port = {"value": len(texts) / t_port, "unit": "genomes/s", "cores": cores, "kind": "port",
+            "sample": "%d of the bench genomes (%.0f Mbase) as 70-col FASTA text in memory, oracle/kssd_oracle.c "
+                      "sketch_texts, OpenMP over genomes" % (len(texts), nb / 1e6),
+            "mbase_per_s": nb / 1e6 / t_port}
+    out["port"] = port
+    # the real reference binary when the snapshot carries it
+    if ko.have_ref() and shutil.which("zcat"):
+        d = tempfile.mkdtemp(prefix="kssd_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            os.mkdir(os.path.join(d, "fa"))
+            for i, t in enumerate(texts):
+                with open(os.path.join(d, "fa", "g%04d.fasta" % i), "wb") as f:
+                    f.write(t)
+            shuf.write(os.path.join(d, "L3K10.shuf"))
+            t0 = time.time()
+            ko.run_ref(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "sk", "fa"], cwd=d, timeout=900)
+            t_ref = time.time() - t0
+            sets = ko.sketch_sets_by_name(os.path.join(d, "sk"))
+            for i in range(len(texts)):
+                assert np.array_equal(sets["g%04d.fasta" % i], gpu_sets[i]), "reference binary sketch != GPU sketch"
+            out["reference"] = {"value": len(texts) / t_ref, "unit": "genomes/s", "cores": cores, "kind": "reference",
+                                "sample": "%d of the bench genomes (%.0f Mbase) as FASTA files in tmpfs, "
+                                          "`oracle/_ref/kssd dist -p %d -L L3K10.shuf` wall time incl. process start "
+                                          "and the 64 MiB .shuf load" % (len(texts), nb / 1e6, cores),
+                                "mbase_per_s": nb / 1e6 / t_ref}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # distances: posting traversal + output_ctrl arithmetic of the port on the sample's all-pairs
+    t0 = time.time()
+    sh = ko.shared_counts(off, ids, off, ids, threads=cores)
+    t_cnt = time.time() - t0
+    out["dist_port"] = {"value": sh.size / t_cnt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                        "sample": "%dx%d all-pairs of the sample sketches, index build + posting traversal only "
+                                  "(the reference adds a fixed ~7-25 s for its 2 GiB mco.index and ~2 us/pair of "
+                                  "text formatting)" % (len(texts), len(texts))}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU")
+    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--clades", type=int, default=50)
+    ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path to measure)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    G, L = a.genomes, a.length
+    shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
+    ctx = K.GpuCtx(shuf, local)
+    t0 = time.time()
+    n_keep = a.cpu_sample if (rank == 0 and world == 1) else 0
+    packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * rank, dev, keep_codes=min(n_keep, G))
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("[bench] batch of %d x %.1f Mb packed on device in %.1f s" % (G, L / 1e6, time.time() - t0))
+
+    # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
+    exp_ids = int(G * L / 4096)
+    cap = int(exp_ids * 1.25) + 4096                      # ids per rank (padded all-gather unit)
+    off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
+    R = G * world
+    if world > 1:
+        off_all = torch.zeros(world * (G + 1), dtype=torch.int64, device=dev)
+        ids_all = torch.zeros(world * cap, dtype=torch.int32, device=dev)
+        roff = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        rids = torch.zeros(world * cap, dtype=torch.int32, device=dev)
+        jj = torch.arange(world * cap, device=dev, dtype=torch.int64)
+    shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
+    planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.sketch_device(packed, mask, chunk_off, off_l, ids_l, cap, K.SKETCH_FASTA, 1, stream)
+        if world == 1:
+            ctx.index_build_device(off_l, ids_l, G, cap, stream)
+            ctx.dist_device(off_l, ids_l, G, 0, G, shared, *planes, stream=stream)
+        else:
+            # the one exchange step of the path: all-gather of every rank's packed sketches (RCCL over xGMI),
+            # fixed-size padded units so that no size has to visit the host
+            dist.all_gather_into_tensor(off_all, off_l)
+            dist.all_gather_into_tensor(ids_all, ids_l)
+            o = off_all.view(world, G + 1)
+            sizes = (o[:, 1:] - o[:, :-1]).reshape(-1)
+            roff[1:] = torch.cumsum(sizes, 0)
+            tot = o[:, G]                                   # ids per rank
+            ends = torch.cumsum(tot, 0)
+            starts = ends - tot
+            rk = torch.searchsorted(ends, jj, right=True).clamp_(max=world - 1)
+            src = (jj - starts[rk] + rk * cap).clamp_(max=world * cap - 1)
+            torch.index_select(ids_all, 0, src, out=rids)   # compact CSR of all references, on the device
+            ctx.index_build_device(roff, rids, R, world * cap, stream)
+            # this rank's query block = its own genomes = rows [rank*G, (rank+1)*G) of the global matrix
+            ctx.dist_device(roff, rids, R, rank * G, (rank + 1) * G, shared, *planes, stream=stream)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # first call sizes the workspaces; retry if a staging region was too small
+    for attempt in range(6):
+        step()
+        rc, total, bad = ctx.sketch_status(stream)
+        if rc == 0:
+            break
+        if rc != K.capi.ERR_OVERFLOW:
+            raise SystemExit("sketch failed: rc=%d" % rc)
+    else:
+        raise SystemExit("sketch kept overflowing")
+    for _ in range(a.warmup):
+        step()
+    sync()
+    ctx.kernel_time(0, reset=True)
+    ctx.kernel_time(1, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    rc, total, bad = ctx.sketch_status(stream)
+    if rc != 0:
+        raise SystemExit("sketch status rc=%d after the timed loop" % rc)
+    scan_ms, scan_n = ctx.kernel_time(0)
+    dist_ms, dist_n = ctx.kernel_time(1)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        # size-independent sanity on the full matrix of this rank
+        sh = shared.view(G, R)
+        szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
+        diag = sh[torch.arange(G, device=dev), rank * G + torch.arange(G, device=dev)]
+        assert torch.equal(diag, szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
+        if world == 1:
+            assert torch.equal(sh, sh.t()), "all-pairs shared-count matrix must be symmetric"
+        n_bases = G * L
+        scan_bytes = 0.375 * n_bases + 4.0 * total        # 2-bit base + 1-bit mask, 4 B per id
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        pairs = G * R
+        dist_bytes = (4 if a.no_planes else 36) * pairs + 4.0 * (total + R / G * total)
+        res = {
+            "metric": "genomes sketched/s (whole hot path per step: sketch + index + all-pairs distances, L3K10)",
+            "value": world * G * a.steps / dt,
+            "unit": "genomes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
+                                   "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
+                       "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
+                       "pairs_per_step": world * pairs, "parallelism": "genomes and query rows sharded x%d, "
+                       "all-gather of sketches" % world if world > 1 else "single GPU"},
+            "pairs_per_s": world * pairs * a.steps / dt,
+            "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
+            "ids_per_batch": int(total),
+            "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [scan_n, dist_n],
+                        "dist_rows_GBs": dist_bytes / (dist_ms * 1e-3) / 1e9 if dist_ms > 0 else None},
+            "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": scan_bytes},
+        }
+        if a.cpu_sample and world == 1 and kept:
+            ol = off_l.cpu().numpy()
+            il = ids_l.cpu().numpy().view(np.uint32)
+            gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
+            cores = os.cpu_count() or 1
+            cb = cpu_baseline(shuf, kept, cores, gpu_sets)
+            res["cpu_baseline"] = cb.get("reference", cb["port"])
+            res["cpu_baseline_port"] = cb["port"]
+            res["cpu_baseline_dist"] = cb["dist_port"]
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                res["roofline"]["traffic"] = json.load(open(pmc)).get("sketch_scan_bytes_per_launch")
+            except Exception:
+                pass
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/*
+ * kssd_gpu.h -- C ABI of libkssd_gpu.so: the MI355X (gfx950) implementation of the kssd
+ * sketch + distance hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference (yhg926/public_kssd v1.2.21) has no FFI: its seams are C functions inside one
+ * binary.  Each entry point below names the reference function it replaces.
+ * The binding a kssd maintainer would add is shown in INTEGRATION.md.
+ *
+ * Threading: one calling thread per kssd_gpu_ctx.  All work is enqueued on the hipStream_t passed
+ * as `stream` (void*, NULL = the null stream).  Device-level calls (`*_device`) take DEVICE
+ * pointers and do not synchronise; host-level calls take HOST pointers and return finished data.
+ */
+#ifndef KSSD_GPU_H
+#define KSSD_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------------------------- */
+#define KSSD_OK 0
+#define KSSD_ERR_HIP (-1)         /* a HIP runtime call failed (kssd_gpu_strerror gives the text)      */
+#define KSSD_ERR_PARAM (-2)       /* k/subk/drlevel outside what the reference accepts                 */
+                                  /*   (command_shuffle.c:163-168, command_dist.c:217-236)             */
+#define KSSD_ERR_CAPACITY (-3)    /* a genome holds more distinct k-mers than the reference's hash     */
+                                  /*   admits: "the context space is too crowd" iseq2comem.c:262-263   */
+#define KSSD_ERR_OVERFLOW (-4)    /* an output / staging buffer was too small (call again larger)      */
+#define KSSD_ERR_UNSUPPORTED (-5) /* valid for the reference, not implemented on the device yet        */
+#define KSSD_ERR_NOMEM (-6)
+#define KSSD_ERR_NO_DEVICE (-7)   /* no usable gfx950 device: there is NO CPU fallback                 */
+
+/* ---- geometry of a packed batch -------------------------------------------------------------- */
+#define KSSD_CHUNK_BASES 4096u   /* positions per chunk; every genome starts on a chunk boundary      */
+#define KSSD_CHUNK_WORDS 256u    /* u32 words of packed bases per chunk (16 bases / word)              */
+#define KSSD_CHUNK_MASKW 128u    /* u32 words of validity mask per chunk (32 positions / word)         */
+#define KSSD_PACK_SLACK_WORDS 8u /* readable words required past the last chunk of `packed` AND `mask`   */
+/*
+ * packed : position p lives in word p/16, bits [31-2(p%16)-1, 31-2(p%16)]  (first base = top bits),
+ *          code A=0 C=1 G=2 T=3  (global_basic.c:64-71)
+ * mask   : position p lives in word p/32, bit p%32; 1 = an A/C/G/T base, 0 = anything that resets the
+ *          reference's run counter (iseq2comem.c:221-242): N, IUPAC, header, record boundary, padding
+ */
+
+/* sketch flags */
+#define KSSD_SKETCH_FASTA 0u        /* fasta2co semantics: id 0 is never stored (iseq2comem.c:258)     */
+#define KSSD_SKETCH_KEEP_ZERO 1u    /* fastq2co semantics: id 0 is kept (iseq2comem.c:335-337)         */
+#define KSSD_SKETCH_UNIQ 2u         /* uniq_fasta2co (-u): drop ids seen more than once (:694-696)     */
+#define KSSD_SKETCH_NO_CAPACITY 4u  /* do not raise KSSD_ERR_CAPACITY (fastq2co never does, :338)      */
+
+typedef struct kssd_gpu_ctx kssd_gpu_ctx;
+
+/* mirrors dim_shuffle_stat_t (command_shuffle.h:17-23) */
+typedef struct kssd_shuf_hdr {
+    int32_t id, k, subk, drlevel;
+} kssd_shuf_hdr;
+
+/* derived constants, mirrors seq2co_global_var_initial (iseq2comem.c:54-77) + get_hashsz */
+typedef struct kssd_gpu_info {
+    int32_t k, subk, drlevel, kmerlen /*2k*/, dim_rd_len /*2*drlevel*/;
+    int32_t comp_num, comp_bits;
+    uint32_t dim_end, hashsize, hashlimit;
+    int32_t device, cu_count;
+} kssd_gpu_info;
+
+const char *kssd_gpu_strerror(int code);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char *kssd_gpu_last_hip_error(void);
+
+/*
+ * Replaces read_dim_shuffle_file + seq2co_global_var_initial (command_shuffle.c:192-207,
+ * iseq2comem.c:54-77).  `table` = the .shuf permutation, HOST int32[16^subk].  Only the dim_end
+ * sub-contexts with table[x] < dim_end are kept (device tables are a few hundred KB).
+ */
+int kssd_gpu_create(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, const int32_t *table, int device);
+/* same, from the compact form: accepted[r] = the sub-context x with table[x] == r, r < dim_end */
+int kssd_gpu_create_compact(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, const uint32_t *accepted,
+                            uint32_t n_accepted, int device);
+void kssd_gpu_destroy(kssd_gpu_ctx *ctx);
+int kssd_gpu_get_info(const kssd_gpu_ctx *ctx, kssd_gpu_info *info);
+
+/*
+ * Sketch a packed batch: replaces fasta2co / fastq2co + wrt_co2cmpn_use_inn_subctx / write_fqco2file
+ * for every genome of the batch (iseq2comem.c:188-356,499-551; driver loop command_dist.c:277-312).
+ *   d_packed, d_mask : DEVICE, n_chunks chunks (+ KSSD_PACK_SLACK_WORDS readable words after each)
+ *   h_chunk_off      : HOST  u64[n_genomes+1], genome g owns chunks [h_chunk_off[g], h_chunk_off[g+1])
+ *   min_occ          : keep an id only if it occurs >= min_occ times (fastq -n, iseq2comem.c:336-345)
+ *   d_out_off        : DEVICE u64[n_genomes+1] exclusive prefix of sketch sizes
+ *   d_out_ids        : DEVICE u32[out_cap]; genome g's ids ascending and distinct (the reference's
+ *                      sketch is this set in hash-slot order; see kssd_host_slot_order)
+ * Nothing is synchronised; call kssd_gpu_sketch_status afterwards.
+ */
+int kssd_gpu_sketch_device(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
+                           const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags,
+                           uint32_t min_occ, uint64_t *d_out_off, uint32_t *d_out_ids,
+                           uint64_t out_cap, void *stream);
+/*
+ * Synchronises `stream` and reports on the last kssd_gpu_sketch_device call:
+ *   *total_ids  = ids the batch produced (valid even on KSSD_ERR_OVERFLOW: size to retry with)
+ *   *bad_genome = first genome that raised KSSD_ERR_CAPACITY, else -1
+ * returns KSSD_OK, KSSD_ERR_OVERFLOW (out_cap or the staging regions too small; the latter are
+ * grown automatically, just call again), KSSD_ERR_CAPACITY, KSSD_ERR_UNSUPPORTED or KSSD_ERR_HIP.
+ */
+int kssd_gpu_sketch_status(kssd_gpu_ctx *ctx, uint64_t *total_ids, int64_t *bad_genome, void *stream);
+
+/* host-level convenience: HOST packed/mask in, malloc'd HOST CSR out (free with kssd_gpu_free) */
+int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
+                          const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
+                          uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                          int64_t *bad_genome);
+void kssd_gpu_free(void *p);
+
+/*
+ * Build the inverted index of the reference sketches on the device: replaces combco2mco
+ * (co2mco.c:25-77).  CSR input, DEVICE pointers (as kssd_gpu_sketch_device writes them; any id order is
+ * accepted).  max_ref_ids is only an upper bound of d_roff[n_ref] (it sizes the hash), so no host
+ * synchronisation is needed between sketching and indexing.  The index lives in ctx until the next call.
+ */
+int kssd_gpu_index_build_device(kssd_gpu_ctx *ctx, const uint64_t *d_roff, const uint32_t *d_rids,
+                                uint32_t n_ref, uint64_t max_ref_ids, void *stream);
+
+/*
+ * Shared-k-mer counts and distances for query rows [q_begin, q_end) against the indexed references:
+ * replaces the hot loop of mco_cbdco_nobin_dist (command_dist.c:763-790) and the arithmetic of
+ * output_ctrl (command_dist.c:1251-1266, no --correction).  All pointers DEVICE; the five outputs are
+ * row-major [(q_end-q_begin) x n_ref], any of the four f64 planes may be NULL.
+ *   J = s/(X+Y-s)  MashD = min(1, ln(1/(2J)+0.5)/kmerlen)  C = s/min(X,Y)  AafD = min(1, ln(1/C)/kmerlen)
+ * with X=|ref|, Y=|qry|, s=shared.
+ */
+int kssd_gpu_dist_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32_t *d_qids,
+                         uint32_t n_qry, uint32_t q_begin, uint32_t q_end, uint32_t *d_shared,
+                         double *d_jaccard, double *d_mashd, double *d_contain, double *d_aafd,
+                         void *stream);
+
+/* host-level convenience: HOST CSR in, HOST matrices out (caller-allocated, Q x R; planes may be NULL) */
+int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref,
+                  const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,
+                  double *jaccard, double *mashd, double *contain, double *aafd);
+
+/*
+ * Timing hook for bench.py: every launch of the dominant kernel of a path is bracketed by HIP events on
+ * the caller's stream (a ring of the last 128 launches).  which: 0 = sketch scan, 1 = distance rows.
+ * Waits for the recorded events, returns their average in milliseconds and how many launches that covers;
+ * reset != 0 empties the ring.
+ */
+int kssd_gpu_kernel_time(kssd_gpu_ctx *ctx, int which, int reset, float *avg_ms, uint32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,10 @@
+"""public_kssd_amd -- MI355X (gfx950) implementation of the kssd sketch + distance hot path.
+
+The product is native: HIP kernels behind a C ABI (include/kssd_gpu.h, csrc/), a C host layer and the
+`kssd` command line (host/).  This package only binds those libraries for the tests and bench.py.
+"""
+from .capi import (Batch, GpuCtx, KssdError, Shuf, gpu_lib, host_lib, CHUNK_BASES, CHUNK_MASKW, CHUNK_WORDS,
+                   SLACK_WORDS, SKETCH_FASTA, SKETCH_KEEP_ZERO, SKETCH_NO_CAPACITY, SKETCH_UNIQ)
+
+__all__ = ["Batch", "GpuCtx", "KssdError", "Shuf", "gpu_lib", "host_lib", "CHUNK_BASES", "CHUNK_MASKW",
+           "CHUNK_WORDS", "SLACK_WORDS", "SKETCH_FASTA", "SKETCH_KEEP_ZERO", "SKETCH_NO_CAPACITY", "SKETCH_UNIQ"]

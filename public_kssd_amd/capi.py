@@ -1,0 +1,339 @@
+"""ctypes bindings of the two in-tree native libraries.
+
+  libkssd_gpu.so   HIP kernels behind the C ABI declared in include/kssd_gpu.h
+  libkssd_host.so  host C (host/kssd_host.h): .shuf files, tokeniser / packer, on-disk formats
+
+There is no Python or CPU implementation of the hot path in this package: if libkssd_gpu.so is not
+built, or no gfx950 device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GPU_LIB = os.path.join(HERE, "libkssd_gpu.so")
+HOST_LIB = os.path.join(HERE, "libkssd_host.so")
+
+CHUNK_BASES = 4096
+CHUNK_WORDS = 256
+CHUNK_MASKW = 128
+SLACK_WORDS = 8
+
+SKETCH_FASTA = 0
+SKETCH_KEEP_ZERO = 1
+SKETCH_UNIQ = 2
+SKETCH_NO_CAPACITY = 4
+
+OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
+
+GPU_SYMBOLS = [
+    "kssd_gpu_strerror", "kssd_gpu_last_hip_error", "kssd_gpu_create", "kssd_gpu_create_compact",
+    "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
+    "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
+    "kssd_gpu_dist", "kssd_gpu_kernel_time",
+]
+
+
+class KssdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("kssd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ShufHdr(C.Structure):
+    _fields_ = [("id", C.c_int32), ("k", C.c_int32), ("subk", C.c_int32), ("drlevel", C.c_int32)]
+
+
+class GpuInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("subk", C.c_int32), ("drlevel", C.c_int32), ("kmerlen", C.c_int32),
+                ("dim_rd_len", C.c_int32), ("comp_num", C.c_int32), ("comp_bits", C.c_int32),
+                ("dim_end", C.c_uint32), ("hashsize", C.c_uint32), ("hashlimit", C.c_uint32),
+                ("device", C.c_int32), ("cu_count", C.c_int32)]
+
+
+class _Shuf(C.Structure):
+    _fields_ = [("id", C.c_int32), ("k", C.c_int32), ("subk", C.c_int32), ("drlevel", C.c_int32),
+                ("table", C.POINTER(C.c_int32))]
+
+
+_gpu = None
+_host = None
+
+
+def gpu_lib():
+    """libkssd_gpu.so; raises if it has not been built (no fallback exists)."""
+    global _gpu
+    if _gpu is None:
+        if not os.path.exists(GPU_LIB):
+            raise ImportError("public_kssd_amd: %s is missing -- build it with `make -C public_kssd_amd` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % GPU_LIB)
+        L = C.CDLL(GPU_LIB)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.kssd_gpu_strerror.restype = C.c_char_p
+        L.kssd_gpu_strerror.argtypes = [i32]
+        L.kssd_gpu_last_hip_error.restype = C.c_char_p
+        L.kssd_gpu_create.argtypes = [C.POINTER(vp), C.POINTER(ShufHdr), vp, i32]
+        L.kssd_gpu_create_compact.argtypes = [C.POINTER(vp), C.POINTER(ShufHdr), vp, u32, i32]
+        L.kssd_gpu_destroy.argtypes = [vp]
+        L.kssd_gpu_destroy.restype = None
+        L.kssd_gpu_get_info.argtypes = [vp, C.POINTER(GpuInfo)]
+        L.kssd_gpu_sketch_device.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, u64, vp]
+        L.kssd_gpu_sketch_status.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_int64), vp]
+        L.kssd_gpu_sketch_batch.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp),
+                                            C.POINTER(C.c_int64)]
+        L.kssd_gpu_free.argtypes = [vp]
+        L.kssd_gpu_free.restype = None
+        L.kssd_gpu_index_build_device.argtypes = [vp, vp, vp, u32, u64, vp]
+        L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
+        L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
+        L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
+        _gpu = L
+    return _gpu
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise ImportError("public_kssd_amd: %s is missing -- build it with `make -C public_kssd_amd`" % HOST_LIB)
+        L = C.CDLL(HOST_LIB)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.kssd_host_strerror.restype = C.c_char_p
+        L.kssd_host_strerror.argtypes = [i32]
+        L.kssd_shuf_generate.argtypes = [C.POINTER(_Shuf), i32, i32, i32, u64]
+        L.kssd_shuf_write.argtypes = [C.POINTER(_Shuf), C.c_char_p]
+        L.kssd_shuf_read.argtypes = [C.POINTER(_Shuf), C.c_char_p]
+        L.kssd_shuf_release.argtypes = [C.POINTER(_Shuf)]
+        L.kssd_shuf_release.restype = None
+        L.kssd_batch_create.restype = vp
+        L.kssd_batch_destroy.argtypes = [vp]
+        L.kssd_batch_destroy.restype = None
+        L.kssd_batch_clear.argtypes = [vp]
+        L.kssd_batch_clear.restype = None
+        L.kssd_batch_add_fasta.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.kssd_batch_add_fastq.argtypes = [vp, C.c_char_p, C.c_size_t, i32, C.POINTER(u64)]
+        L.kssd_batch_add_file.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(u64)]
+        for f in ("packed", "mask", "chunk_off"):
+            getattr(L, "kssd_batch_" + f).restype = vp
+            getattr(L, "kssd_batch_" + f).argtypes = [vp]
+        L.kssd_batch_n_chunks.restype = u64
+        L.kssd_batch_n_chunks.argtypes = [vp]
+        L.kssd_batch_n_genomes.restype = u32
+        L.kssd_batch_n_genomes.argtypes = [vp]
+        L.kssd_batch_n_positions.restype = u64
+        L.kssd_batch_n_positions.argtypes = [vp, u32]
+        _host = L
+    return _host
+
+
+def _hck(rc):
+    if rc != 0:
+        raise KssdError(rc, host_lib().kssd_host_strerror(rc).decode())
+
+
+def _gck(rc):
+    if rc != 0:
+        raise KssdError(rc, gpu_lib().kssd_gpu_strerror(rc).decode())
+
+
+# ------------------------------------------------------------------------------------------------------
+# .shuf
+# ------------------------------------------------------------------------------------------------------
+class Shuf:
+    """A dimension-reduction shuffle (the reference's dim_shuffle_t): header + int32 permutation."""
+
+    def __init__(self, hdr, table):
+        self.id, self.k, self.subk, self.drlevel = hdr
+        self.table = np.ascontiguousarray(table, dtype=np.int32)
+
+    @classmethod
+    def generate(cls, k, subk, drlevel, seed):
+        s = _Shuf()
+        _hck(host_lib().kssd_shuf_generate(C.byref(s), k, subk, drlevel, seed))
+        try:
+            t = np.ctypeslib.as_array(s.table, shape=(16 ** subk,)).copy()
+            return cls((s.id, s.k, s.subk, s.drlevel), t)
+        finally:
+            host_lib().kssd_shuf_release(C.byref(s))
+
+    @classmethod
+    def read(cls, path):
+        s = _Shuf()
+        _hck(host_lib().kssd_shuf_read(C.byref(s), os.fsencode(path)))
+        try:
+            t = np.ctypeslib.as_array(s.table, shape=(16 ** s.subk,)).copy()
+            return cls((s.id, s.k, s.subk, s.drlevel), t)
+        finally:
+            host_lib().kssd_shuf_release(C.byref(s))
+
+    def write(self, path):
+        s = _Shuf(self.id, self.k, self.subk, self.drlevel, self.table.ctypes.data_as(C.POINTER(C.c_int32)))
+        _hck(host_lib().kssd_shuf_write(C.byref(s), os.fsencode(path)))
+
+    def hdr(self):
+        return ShufHdr(self.id, self.k, self.subk, self.drlevel)
+
+
+# ------------------------------------------------------------------------------------------------------
+# packed batches
+# ------------------------------------------------------------------------------------------------------
+class Batch:
+    """Genomes tokenised into the packed device layout (2-bit bases + validity mask, 4096-base chunks)."""
+
+    def __init__(self):
+        self.h = host_lib().kssd_batch_create()
+        if not self.h:
+            raise MemoryError
+
+    def close(self):
+        if self.h:
+            host_lib().kssd_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def clear(self):
+        host_lib().kssd_batch_clear(self.h)
+
+    def add_fasta(self, text):
+        text = bytes(text)
+        _hck(host_lib().kssd_batch_add_fasta(self.h, text, len(text)))
+
+    def add_fastq(self, text, Q=0):
+        text = bytes(text)
+        n = C.c_uint64(0)
+        _hck(host_lib().kssd_batch_add_fastq(self.h, text, len(text), Q, C.byref(n)))
+        return n.value
+
+    def add_file(self, path, is_fastq=False, Q=0):
+        n = C.c_uint64(0)
+        _hck(host_lib().kssd_batch_add_file(self.h, os.fsencode(path), int(is_fastq), Q, C.byref(n)))
+        return n.value
+
+    @property
+    def n_chunks(self):
+        return host_lib().kssd_batch_n_chunks(self.h)
+
+    @property
+    def n_genomes(self):
+        return host_lib().kssd_batch_n_genomes(self.h)
+
+    def n_positions(self, g):
+        return host_lib().kssd_batch_n_positions(self.h, g)
+
+    def _view(self, ptr, n, dtype):
+        if n == 0 or not ptr:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=n)
+
+    def packed(self):
+        """view incl. the slack words (valid until the batch is modified)"""
+        return self._view(host_lib().kssd_batch_packed(self.h), self.n_chunks * CHUNK_WORDS + SLACK_WORDS, np.uint32)
+
+    def mask(self):
+        return self._view(host_lib().kssd_batch_mask(self.h), self.n_chunks * CHUNK_MASKW + SLACK_WORDS, np.uint32)
+
+    def chunk_off(self):
+        return self._view(host_lib().kssd_batch_chunk_off(self.h), self.n_genomes + 1, np.uint64).copy()
+
+
+# ------------------------------------------------------------------------------------------------------
+# the device context
+# ------------------------------------------------------------------------------------------------------
+def _ptr(x):
+    """device or host address of a numpy array / torch tensor / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()  # torch tensor
+
+
+class GpuCtx:
+    """kssd_gpu_ctx: device tables for one .shuf + workspaces (one calling thread per context)."""
+
+    def __init__(self, shuf, device=0):
+        self.h = C.c_void_p()
+        hdr = shuf.hdr()
+        _gck(gpu_lib().kssd_gpu_create(C.byref(self.h), C.byref(hdr), shuf.table.ctypes.data, device))
+        self.info = GpuInfo()
+        _gck(gpu_lib().kssd_gpu_get_info(self.h, C.byref(self.info)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            gpu_lib().kssd_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # host-level ---------------------------------------------------------------------------------------
+    def sketch_batch(self, batch, flags=SKETCH_FASTA, min_occ=1):
+        """(off uint64[n+1], ids uint32) -- ascending distinct ids per genome"""
+        return self.sketch_packed(batch.packed(), batch.mask(), batch.chunk_off(), flags, min_occ)
+
+    def sketch_packed(self, packed, mask, chunk_off, flags=SKETCH_FASTA, min_occ=1):
+        chunk_off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        n = len(chunk_off) - 1
+        po, pi, bad = C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+        rc = gpu_lib().kssd_gpu_sketch_batch(self.h, _ptr(packed), _ptr(mask), chunk_off.ctypes.data, n, flags,
+                                             min_occ, C.byref(po), C.byref(pi), C.byref(bad))
+        if rc != 0:
+            e = KssdError(rc, gpu_lib().kssd_gpu_strerror(rc).decode())
+            e.bad_genome = bad.value
+            raise e
+        try:
+            off = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(po.value), dtype=np.uint64).copy()
+            tot = int(off[-1])
+            ids = (np.frombuffer((C.c_char * (4 * tot)).from_address(pi.value), dtype=np.uint32).copy()
+                   if tot else np.zeros(0, np.uint32))
+        finally:
+            gpu_lib().kssd_gpu_free(po)
+            gpu_lib().kssd_gpu_free(pi)
+        return off, ids
+
+    def dist(self, roff, rids, qoff, qids, planes=True):
+        """shared uint32[Q,R] (+ J, MashD, C, AafD float64[Q,R] when planes)"""
+        roff = np.ascontiguousarray(roff, dtype=np.uint64)
+        qoff = np.ascontiguousarray(qoff, dtype=np.uint64)
+        rids = np.ascontiguousarray(rids, dtype=np.uint32)
+        qids = np.ascontiguousarray(qids, dtype=np.uint32)
+        R, Q = len(roff) - 1, len(qoff) - 1
+        shared = np.zeros((Q, R), dtype=np.uint32)
+        pl = [np.zeros((Q, R), dtype=np.float64) for _ in range(4)] if planes else [None] * 4
+        _gck(gpu_lib().kssd_gpu_dist(self.h, roff.ctypes.data, rids.ctypes.data, R, qoff.ctypes.data,
+                                     qids.ctypes.data, Q, shared.ctypes.data, *[_ptr(p) for p in pl]))
+        return (shared, *pl) if planes else shared
+
+    # device-level (torch tensors or raw addresses; nothing is synchronised) ------------------------------
+    def sketch_device(self, d_packed, d_mask, chunk_off, d_out_off, d_out_ids, out_cap, flags=SKETCH_FASTA,
+                      min_occ=1, stream=None):
+        chunk_off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        _gck(gpu_lib().kssd_gpu_sketch_device(self.h, _ptr(d_packed), _ptr(d_mask), chunk_off.ctypes.data,
+                                              len(chunk_off) - 1, flags, min_occ, _ptr(d_out_off), _ptr(d_out_ids),
+                                              out_cap, stream))
+
+    def sketch_status(self, stream=None):
+        """(rc, total_ids, bad_genome) after synchronising the stream"""
+        tot, bad = C.c_uint64(0), C.c_int64(-1)
+        rc = gpu_lib().kssd_gpu_sketch_status(self.h, C.byref(tot), C.byref(bad), stream)
+        return rc, tot.value, bad.value
+
+    def index_build_device(self, d_roff, d_rids, n_ref, max_ref_ids, stream=None):
+        _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
+
+    def dist_device(self, d_qoff, d_qids, n_qry, q_begin, q_end, d_shared, d_j=None, d_m=None, d_c=None, d_a=None,
+                    stream=None):
+        _gck(gpu_lib().kssd_gpu_dist_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_shared),
+                                            _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
+
+    def kernel_time(self, which, reset=False):
+        """(average ms, launches) of the dominant kernel: 0 = sketch scan, 1 = distance rows"""
+        ms, n = C.c_float(0), C.c_uint32(0)
+        _gck(gpu_lib().kssd_gpu_kernel_time(self.h, which, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

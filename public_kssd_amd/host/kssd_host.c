@@ -1,0 +1,442 @@
+/*
+ * kssd_host.c -- .shuf generation / io and FASTA / FASTQ tokenisation into packed batches.
+ * See kssd_host.h.  Reference behaviour is cited per function; the code is new.
+ */
+#define _GNU_SOURCE
+#include "kssd_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <zlib.h>
+
+#define CHUNK_BASES 4096u
+#define CHUNK_WORDS 256u
+#define CHUNK_MASKW 128u
+#define SLACK_WORDS 8u
+
+const char *kssd_host_strerror(int code)
+{
+    switch (code) {
+    case KSSD_HOST_OK: return "ok";
+    case KSSD_HOST_ERR_IO: return "i/o error";
+    case KSSD_HOST_ERR_PARAM: return "bad parameter (half-context / half-subcontext / level)";
+    case KSSD_HOST_ERR_HEADER: return "can not find seqences head start from '>'";
+    case KSSD_HOST_ERR_EMPTY: return "eof or fread error";
+    case KSSD_HOST_ERR_NOMEM: return "out of memory";
+    case KSSD_HOST_ERR_FORMAT: return "malformed file";
+    default: return "unknown kssd_host error";
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * .shuf
+ * ------------------------------------------------------------------------------------------------- */
+static inline uint64_t splitmix64(uint64_t *x)
+{
+    uint64_t z = (*x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+typedef struct { uint64_t s[4]; } xoshiro;
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+static inline uint64_t xo_next(xoshiro *g)
+{
+    uint64_t *s = g->s;
+    const uint64_t r = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return r;
+}
+
+/* unbiased draw from [0, n) */
+static inline uint32_t xo_below(xoshiro *g, uint32_t n)
+{
+    uint64_t m = (uint64_t)(uint32_t)(xo_next(g) >> 32) * n;
+    uint32_t l = (uint32_t)m;
+    if (l < n) {
+        uint32_t t = (0u - n) % n;
+        while (l < t) {
+            m = (uint64_t)(uint32_t)(xo_next(g) >> 32) * n;
+            l = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+
+int kssd_shuf_generate(kssd_shuf *s, int k, int subk, int drlevel, uint64_t seed)
+{
+    if (!s) return KSSD_HOST_ERR_PARAM;
+    memset(s, 0, sizeof *s);
+    /* same refusals as write_dim_shuffle_file (command_shuffle.c:163-168) */
+    if (k < subk || subk >= 8 || subk < 1 || drlevel < 0 || drlevel > subk) return KSSD_HOST_ERR_PARAM;
+    if (seed == 0) seed = (uint64_t)time(NULL); /* command_shuffle.c:180 */
+    xoshiro g;
+    uint64_t sm = seed;
+    for (int i = 0; i < 4; i++) g.s[i] = splitmix64(&sm);
+    const uint32_t n = 1u << (4 * subk);
+    int32_t *t = malloc((size_t)n * sizeof(int32_t));
+    if (!t) return KSSD_HOST_ERR_NOMEM;
+    for (uint32_t i = 0; i < n; i++) t[i] = (int32_t)i;
+    for (uint32_t i = n - 1; i > 0; i--) { /* Fisher-Yates, command_shuffle.c:131-144 */
+        uint32_t j = xo_below(&g, i + 1);
+        int32_t tmp = t[i];
+        t[i] = t[j];
+        t[j] = tmp;
+    }
+    s->id = (int32_t)(xo_next(&g) >> 33); /* a positive int, like rand() (command_shuffle.c:181) */
+    s->k = k;
+    s->subk = subk;
+    s->drlevel = drlevel;
+    s->table = t;
+    return KSSD_HOST_OK;
+}
+
+int kssd_shuf_write(const kssd_shuf *s, const char *path)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return KSSD_HOST_ERR_IO;
+    int32_t hdr[4] = {s->id, s->k, s->subk, s->drlevel}; /* command_shuffle.c:184-185 */
+    size_t n = (size_t)1 << (4 * s->subk);
+    int ok = fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(s->table, sizeof(int32_t), n, f) == n;
+    if (fclose(f) != 0) ok = 0;
+    return ok ? KSSD_HOST_OK : KSSD_HOST_ERR_IO;
+}
+
+int kssd_shuf_read(kssd_shuf *s, const char *path)
+{
+    memset(s, 0, sizeof *s);
+    size_t L = strlen(path);
+    if (L < 5 || strcmp(path + L - 5, ".shuf") != 0) return KSSD_HOST_ERR_FORMAT; /* command_shuffle.c:194-196 */
+    FILE *f = fopen(path, "rb");
+    if (!f) return KSSD_HOST_ERR_IO;
+    int32_t hdr[4];
+    if (fread(hdr, sizeof hdr, 1, f) != 1 || hdr[2] < 1 || hdr[2] >= 8) {
+        fclose(f);
+        return KSSD_HOST_ERR_FORMAT;
+    }
+    size_t n = (size_t)1 << (4 * hdr[2]);
+    int32_t *t = malloc(n * sizeof(int32_t));
+    if (!t) {
+        fclose(f);
+        return KSSD_HOST_ERR_NOMEM;
+    }
+    if (fread(t, sizeof(int32_t), n, f) != n) {
+        free(t);
+        fclose(f);
+        return KSSD_HOST_ERR_FORMAT;
+    }
+    fclose(f);
+    s->id = hdr[0]; s->k = hdr[1]; s->subk = hdr[2]; s->drlevel = hdr[3];
+    s->table = t;
+    return KSSD_HOST_OK;
+}
+
+void kssd_shuf_release(kssd_shuf *s)
+{
+    if (s) {
+        free(s->table);
+        s->table = NULL;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * packed batches
+ * ------------------------------------------------------------------------------------------------- */
+struct kssd_batch {
+    uint32_t *packed, *mask;
+    uint64_t n_chunks, cap_chunks;
+    uint64_t *chunk_off; /* n_genomes + 1 */
+    uint64_t *n_pos;     /* per genome */
+    uint32_t n_genomes, cap_genomes;
+};
+
+kssd_batch *kssd_batch_create(void)
+{
+    kssd_batch *b = calloc(1, sizeof *b);
+    if (!b) return NULL;
+    b->cap_genomes = 16;
+    b->chunk_off = calloc(b->cap_genomes + 1, sizeof(uint64_t));
+    b->n_pos = calloc(b->cap_genomes, sizeof(uint64_t));
+    if (!b->chunk_off || !b->n_pos) {
+        kssd_batch_destroy(b);
+        return NULL;
+    }
+    return b;
+}
+
+void kssd_batch_destroy(kssd_batch *b)
+{
+    if (!b) return;
+    free(b->packed);
+    free(b->mask);
+    free(b->chunk_off);
+    free(b->n_pos);
+    free(b);
+}
+
+void kssd_batch_clear(kssd_batch *b)
+{
+    if (b->packed) memset(b->packed, 0, ((size_t)b->cap_chunks * CHUNK_WORDS + SLACK_WORDS) * 4);
+    if (b->mask) memset(b->mask, 0, ((size_t)b->cap_chunks * CHUNK_MASKW + SLACK_WORDS) * 4);
+    b->n_chunks = 0;
+    b->n_genomes = 0;
+    b->chunk_off[0] = 0;
+}
+
+static int batch_reserve_chunks(kssd_batch *b, uint64_t need)
+{
+    if (need <= b->cap_chunks) return KSSD_HOST_OK;
+    uint64_t nc = b->cap_chunks ? b->cap_chunks : 64;
+    while (nc < need) nc += nc / 2 + 64;
+    size_t pw_old = b->packed ? (size_t)b->cap_chunks * CHUNK_WORDS + SLACK_WORDS : 0;
+    size_t mw_old = b->mask ? (size_t)b->cap_chunks * CHUNK_MASKW + SLACK_WORDS : 0;
+    size_t pw = (size_t)nc * CHUNK_WORDS + SLACK_WORDS, mw = (size_t)nc * CHUNK_MASKW + SLACK_WORDS;
+    uint32_t *p = realloc(b->packed, pw * 4);
+    if (!p) return KSSD_HOST_ERR_NOMEM;
+    b->packed = p;
+    memset(p + pw_old, 0, (pw - pw_old) * 4);
+    uint32_t *m = realloc(b->mask, mw * 4);
+    if (!m) return KSSD_HOST_ERR_NOMEM;
+    b->mask = m;
+    memset(m + mw_old, 0, (mw - mw_old) * 4);
+    b->cap_chunks = nc;
+    return KSSD_HOST_OK;
+}
+
+static int batch_begin(kssd_batch *b)
+{
+    if (b->n_genomes == b->cap_genomes) {
+        uint32_t nc = b->cap_genomes * 2;
+        uint64_t *o = realloc(b->chunk_off, ((size_t)nc + 1) * sizeof(uint64_t));
+        if (!o) return KSSD_HOST_ERR_NOMEM;
+        b->chunk_off = o;
+        uint64_t *np = realloc(b->n_pos, (size_t)nc * sizeof(uint64_t));
+        if (!np) return KSSD_HOST_ERR_NOMEM;
+        b->n_pos = np;
+        b->cap_genomes = nc;
+    }
+    return KSSD_HOST_OK;
+}
+
+/* writer state of the genome being appended */
+typedef struct {
+    kssd_batch *b;
+    uint64_t base_pos; /* first position of this genome in the batch */
+    uint64_t p;        /* positions written so far */
+    int pending_break; /* a run-breaking byte was seen since the last base */
+} gwriter;
+
+static inline int gw_room(gwriter *w)
+{
+    /* make sure position base_pos + p is inside the buffers */
+    uint64_t chunk = (w->base_pos + w->p) / CHUNK_BASES;
+    if (chunk >= w->b->cap_chunks) return batch_reserve_chunks(w->b, chunk + 1);
+    return KSSD_HOST_OK;
+}
+
+static inline int gw_base(gwriter *w, unsigned code)
+{
+    int rc;
+    if (w->pending_break) {
+        /* one invalid position stands for any stretch of bytes that reset the run counter */
+        if (w->p) {
+            if ((rc = gw_room(w)) != 0) return rc;
+            w->p++; /* bits stay 0 */
+        }
+        w->pending_break = 0;
+    }
+    if ((rc = gw_room(w)) != 0) return rc;
+    const uint64_t g = w->base_pos + w->p;
+    w->b->packed[g >> 4] |= (uint32_t)code << (30 - 2 * (unsigned)(g & 15));
+    w->b->mask[g >> 5] |= 1u << (unsigned)(g & 31);
+    w->p++;
+    return KSSD_HOST_OK;
+}
+
+static void gw_start(gwriter *w, kssd_batch *b)
+{
+    w->b = b;
+    w->base_pos = b->n_chunks * CHUNK_BASES;
+    w->p = 0;
+    w->pending_break = 0;
+}
+
+static void gw_finish(gwriter *w)
+{
+    kssd_batch *b = w->b;
+    uint64_t chunks = (w->p + CHUNK_BASES - 1) / CHUNK_BASES;
+    b->n_pos[b->n_genomes] = w->p;
+    b->n_chunks += chunks;
+    b->n_genomes++;
+    b->chunk_off[b->n_genomes] = b->n_chunks;
+}
+
+/* roll back a genome whose input turned out to be malformed */
+static void gw_abort(gwriter *w)
+{
+    kssd_batch *b = w->b;
+    uint64_t c0 = b->n_chunks, c1 = (w->base_pos + w->p + CHUNK_BASES - 1) / CHUNK_BASES;
+    if (c1 > b->cap_chunks) c1 = b->cap_chunks;
+    if (c1 > c0) {
+        memset(b->packed + c0 * CHUNK_WORDS, 0, (size_t)(c1 - c0) * CHUNK_WORDS * 4);
+        memset(b->mask + c0 * CHUNK_MASKW, 0, (size_t)(c1 - c0) * CHUNK_MASKW * 4);
+    }
+}
+
+/* byte classes of the FASTA scanner (iseq2comem.c:213-242, Basemap global_basic.c:64-71) */
+enum { C_A = 0, C_C = 1, C_G = 2, C_T = 3, C_SKIP = 4, C_HEADER = 5, C_BREAK = 6 };
+static unsigned char fa_class[256];
+static int fa_class_ready = 0;
+
+static void fa_class_init(void)
+{
+    for (int i = 0; i < 256; i++) fa_class[i] = C_BREAK;
+    fa_class['A'] = fa_class['a'] = C_A;
+    fa_class['C'] = fa_class['c'] = C_C;
+    fa_class['G'] = fa_class['g'] = C_G;
+    fa_class['T'] = fa_class['t'] = C_T;
+    fa_class['\n'] = fa_class['\r'] = C_SKIP;
+    fa_class['>'] = C_HEADER;
+    fa_class_ready = 1;
+}
+
+int kssd_batch_add_fasta(kssd_batch *b, const unsigned char *text, size_t n)
+{
+    if (!fa_class_ready) fa_class_init();
+    if (n == 0) return KSSD_HOST_ERR_EMPTY;
+    int rc = batch_begin(b);
+    if (rc) return rc;
+    gwriter w;
+    gw_start(&w, b);
+    for (size_t i = 0; i < n; i++) {
+        unsigned cls = fa_class[text[i]];
+        if (cls < 4) {
+            if ((rc = gw_base(&w, cls)) != 0) { gw_abort(&w); return rc; }
+        } else if (cls == C_SKIP) {
+            /* line ends are transparent: k-mers run across them */
+        } else if (cls == C_HEADER) {
+            const unsigned char *nl = memchr(text + i, '\n', n - i);
+            if (!nl) { gw_abort(&w); return KSSD_HOST_ERR_HEADER; }
+            i = (size_t)(nl - text);
+            w.pending_break = 1;
+        } else {
+            w.pending_break = 1;
+        }
+    }
+    gw_finish(&w);
+    return KSSD_HOST_OK;
+}
+
+/* fgets() on a memory stream, end-of-file indicator included */
+typedef struct {
+    const unsigned char *p;
+    size_t n, pos;
+    int eof;
+} mstream;
+
+static char *ms_gets(char *buf, int size, mstream *s)
+{
+    int i = 0;
+    while (i < size - 1) {
+        if (s->pos >= s->n) { s->eof = 1; break; }
+        char ch = (char)s->p[s->pos++];
+        buf[i++] = ch;
+        if (ch == '\n') break;
+    }
+    if (i == 0) return NULL;
+    buf[i] = 0;
+    return buf;
+}
+
+#define FQ_LINE 20000 /* LEN, iseq2comem.c:274 */
+
+int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int Q, uint64_t *n_lines)
+{
+    if (!fa_class_ready) fa_class_init();
+    int rc = batch_begin(b);
+    if (rc) return rc;
+    char *seq = calloc(1, FQ_LINE + 10), *qual = calloc(1, FQ_LINE + 10);
+    if (!seq || !qual) { free(seq); free(qual); return KSSD_HOST_ERR_NOMEM; }
+    gwriter w;
+    gw_start(&w, b);
+    mstream ms = {text, n, 0, 0};
+    uint64_t lines = 0;
+    /* record = name, bases, '+', qualities; the second and fourth line are what the scanner keeps */
+    ms_gets(seq, FQ_LINE, &ms); ms_gets(seq, FQ_LINE, &ms);
+    ms_gets(qual, FQ_LINE, &ms); ms_gets(qual, FQ_LINE, &ms);
+    int sl = (int)strlen(seq);
+    for (int pos = 0; pos < sl; pos++) {
+        if (seq[pos] == '\n') {
+            ms_gets(seq, FQ_LINE, &ms); ms_gets(seq, FQ_LINE, &ms);
+            ms_gets(qual, FQ_LINE, &ms); ms_gets(qual, FQ_LINE, &ms);
+            sl = (int)strlen(seq);
+            lines += 4;
+            if (ms.eof) break; /* a final record without trailing newline is not scanned (iseq2comem.c:302-307) */
+            w.pending_break = 1;
+            pos = -1;
+            continue;
+        }
+        unsigned cls = fa_class[(unsigned char)seq[pos]];
+        if (cls < 4 && qual[pos] >= Q) {
+            if ((rc = gw_base(&w, cls)) != 0) { gw_abort(&w); free(seq); free(qual); return rc; }
+        } else {
+            w.pending_break = 1;
+        }
+    }
+    free(seq);
+    free(qual);
+    gw_finish(&w);
+    if (n_lines) *n_lines = lines;
+    return KSSD_HOST_OK;
+}
+
+int kssd_slurp(const char *path, unsigned char **buf, size_t *len)
+{
+    gzFile g = gzopen(path, "rb");
+    if (!g) return KSSD_HOST_ERR_IO;
+    gzbuffer(g, 1 << 20);
+    size_t cap = 1 << 22, n = 0;
+    unsigned char *p = malloc(cap);
+    if (!p) { gzclose(g); return KSSD_HOST_ERR_NOMEM; }
+    for (;;) {
+        if (cap - n < (1u << 20)) {
+            cap += cap / 2;
+            unsigned char *q = realloc(p, cap);
+            if (!q) { free(p); gzclose(g); return KSSD_HOST_ERR_NOMEM; }
+            p = q;
+        }
+        size_t room = cap - n;
+        int r = gzread(g, p + n, (unsigned)(room > (1u << 30) ? (1u << 30) : room));
+        if (r < 0) { free(p); gzclose(g); return KSSD_HOST_ERR_IO; }
+        if (r == 0) break;
+        n += (size_t)r;
+    }
+    gzclose(g);
+    *buf = p;
+    *len = n;
+    return KSSD_HOST_OK;
+}
+
+int kssd_batch_add_file(kssd_batch *b, const char *path, int is_fastq, int Q, uint64_t *n_lines)
+{
+    unsigned char *txt = NULL;
+    size_t n = 0;
+    int rc = kssd_slurp(path, &txt, &n);
+    if (rc) return rc;
+    rc = is_fastq ? kssd_batch_add_fastq(b, txt, n, Q, n_lines) : kssd_batch_add_fasta(b, txt, n);
+    free(txt);
+    return rc;
+}
+
+const uint32_t *kssd_batch_packed(const kssd_batch *b) { return b->packed; }
+const uint32_t *kssd_batch_mask(const kssd_batch *b) { return b->mask; }
+const uint64_t *kssd_batch_chunk_off(const kssd_batch *b) { return b->chunk_off; }
+uint64_t kssd_batch_n_chunks(const kssd_batch *b) { return b->n_chunks; }
+uint32_t kssd_batch_n_genomes(const kssd_batch *b) { return b->n_genomes; }
+uint64_t kssd_batch_n_positions(const kssd_batch *b, uint32_t g) { return g < b->n_genomes ? b->n_pos[g] : 0; }

@@ -1,0 +1,72 @@
+"""CPU check of the host/device-shared bit manipulation in public_kssd_amd/csrc/kssd_core.h.
+
+tests/emu/emu_sketch.cpp (a test helper, not product code) runs the stage-1 quad-core filter and the stage-2
+exact evaluation lane by lane on the packed layout the host tokeniser writes; the emitted (genome, id) pairs
+must equal the oracle's sketches, and stage 1 must never lose a k-mer that stage 2 on every position finds.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kssd_oracle as ko
+import public_kssd_amd as K
+from synth import fasta_text
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(HERE, "emu", "libemu_sketch.so")
+    src = os.path.join(HERE, "emu", "emu_sketch.cpp")
+    core = os.path.join(HERE, "..", "public_kssd_amd", "csrc", "kssd_core.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so])
+    L = C.CDLL(so)
+    L.emu_sketch.restype = C.c_long
+    L.emu_sketch.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
+                                                                  C.c_uint64, C.c_void_p]
+    return L
+
+
+def run_emu(L, shuf, batch, brute=0):
+    p, m, co = batch.packed(), batch.mask(), batch.chunk_off()
+    gid = np.repeat(np.arange(batch.n_genomes, dtype=np.uint32), np.diff(co).astype(np.int64))
+    out = np.zeros(batch.n_chunks * 4096 + 16, dtype=np.uint64)
+    nc = C.c_uint64(0)
+    n = L.emu_sketch(shuf.k, shuf.subk, shuf.drlevel, shuf.table.ctypes.data, p.ctypes.data, m.ctypes.data,
+                     batch.n_chunks, gid.ctypes.data, brute, out.ctypes.data, len(out), C.byref(nc))
+    assert n >= 0, n
+    return out[:n], nc.value
+
+
+def texts(rng):
+    def rnd(n, pn=0.0):
+        return fasta_text(rng.integers(0, 4, n, dtype=np.uint8), n_mask=(rng.random(n) < pn) if pn else None)
+    multi = b"".join(rnd(60000, 0.0005) for _ in range(3))
+    return [multi, rnd(8000), b">e\nACGT\n", rnd(4096 * 3 - 7), rnd(4096 * 2)]
+
+
+@pytest.mark.parametrize("k,subk,dr", [(10, 6, 3), (8, 5, 2), (10, 7, 5), (9, 6, 3), (11, 6, 3), (8, 4, 1), (12, 7, 4)])
+def test_stage1_stage2_match_oracle(emu, k, subk, dr):
+    rng = np.random.default_rng(100 * k + subk)
+    shuf = K.Shuf.generate(k, subk, dr, seed=42 + k)
+    b = K.Batch()
+    tx = texts(rng)
+    for t in tx:
+        b.add_fasta(t)
+    got, ncand = run_emu(emu, shuf, b)
+    sk = ko.Sketcher(shuf.table, k, subk, dr)
+    for g, t in enumerate(tx):
+        ids, comps = sk.fasta(t, with_comps=True)
+        want = np.sort((ids.astype(np.uint64) << np.uint64(sk.p.comp_bits)) | comps.astype(np.uint64))
+        mine = np.unique(got[(got >> np.uint64(32)) == g] & np.uint64(0xFFFFFFFF))
+        mine = mine[mine != 0]
+        assert np.array_equal(mine, want), (g, len(mine), len(want))
+    brute, _ = run_emu(emu, shuf, b, brute=1)
+    assert np.array_equal(np.sort(got), np.sort(brute))
+    if subk == 6:
+        assert 0.02 < ncand / (b.n_chunks * 4096) < 0.04  # 2*4096*4 patterns over 2^18 cores

@@ -1,0 +1,150 @@
+"""-m gpu: the HIP sketch path, through the C ABI, against the CPU oracle (bit-exact id sets)."""
+import numpy as np
+import pytest
+
+import kssd_oracle as ko
+import public_kssd_amd as K
+from synth import clade_genomes, fasta_text, fastq_text
+
+pytestmark = pytest.mark.gpu
+
+
+def csr_sets(off, ids):
+    return [ids[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+
+
+def oracle_sets(shuf, texts, uniq=False):
+    sk = ko.Sketcher(shuf.table, shuf.k, shuf.subk, shuf.drlevel)
+    out = []
+    for t in texts:
+        ids, comps = sk.fasta(t, uniq=uniq, with_comps=True)
+        out.append(np.sort((ids.astype(np.uint64) << np.uint64(sk.p.comp_bits)) | comps.astype(np.uint64)).astype(np.uint32))
+    return out
+
+
+def check(ctx, shuf, texts, flags=K.SKETCH_FASTA, uniq=False):
+    b = K.Batch()
+    for t in texts:
+        b.add_fasta(t)
+    off, ids = ctx.sketch_batch(b, flags)
+    got = csr_sets(off, ids)
+    want = oracle_sets(shuf, texts, uniq)
+    assert len(got) == len(want)
+    for g, (a, w) in enumerate(zip(got, want)):
+        assert np.array_equal(a, w), "genome %d: %d vs %d ids" % (g, len(a), len(w))
+    return off, ids
+
+
+def test_clade_genomes_l3k10(gpu_ctx, shuf_l3k10):
+    gs = clade_genomes(3, 4, 300_000, seed=11)
+    texts = [fasta_text(c, nm, n_mask=m) for nm, c, m in gs]
+    off, ids = check(gpu_ctx, shuf_l3k10, texts)
+    sizes = np.diff(off)
+    assert sizes.min() > 40 and sizes.max() < 120  # ~ 300000 / 4096
+
+
+def test_edge_cases_l3k10(gpu_ctx, shuf_l3k10):
+    rng = np.random.default_rng(5)
+
+    def rnd(n):
+        return rng.integers(0, 4, n, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    lower = bytes(acgt[rnd(50000)]).lower()
+    texts = [
+        b">only header and a short record\nACGTACGTAC\n",                      # shorter than 2k
+        b">a\n" + bytes(acgt[rnd(19)]) + b"\n",                                  # 2k-1 bases: nothing
+        b">a\n" + bytes(acgt[rnd(20)]) + b"\n",                                  # exactly one window
+        b">lower\n" + lower + b"\n",                                              # soft-masked
+        b">crlf\r\n" + b"\r\n".join(bytes(acgt[rnd(60)]) for _ in range(500)) + b"\r\n",
+        b">iupac\n" + bytes(acgt[rnd(30000)]) + b"RYKMSWN-*" + bytes(acgt[rnd(30000)]) + b"\n",
+        b"".join(b">rec%d some text\n" % i + bytes(acgt[rnd(7000)]) + b"\n" for i in range(9)),  # multi record
+        b">mid\n" + bytes(acgt[rnd(20000)]) + b">inline header breaks the run\n" + bytes(acgt[rnd(20000)]) + b"\n",
+        b"ACGT" * 5000 + b"\n",                                                   # no header, low complexity
+        b">polyA\n" + b"A" * 30000 + b"\n",
+        b">exact chunk\n" + bytes(acgt[rnd(4096)]) + b"\n",
+        b">two chunks minus one\n" + bytes(acgt[rnd(8191)]) + b"\n",
+        b">n-rich\n" + bytes(np.where(rng.random(80000) < 0.02, ord("N"), acgt[rnd(80000)]).astype(np.uint8)) + b"\n",
+    ]
+    check(gpu_ctx, shuf_l3k10, texts)
+
+
+def test_uniq_mode(gpu_ctx, shuf_l3k10):
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    unit = bytes(acgt[rng.integers(0, 4, 150000, dtype=np.uint8)])
+    texts = [b">dup\n" + unit + b"\nN\n" + unit[:70000] + b"\n", b">single\n" + unit + b"\n"]
+    check(gpu_ctx, shuf_l3k10, texts, flags=K.SKETCH_UNIQ, uniq=True)
+
+
+def test_fastq_min_occ(gpu_ctx, shuf_l3k10):
+    rng = np.random.default_rng(3)
+    genome = rng.integers(0, 4, 120000, dtype=np.uint8)
+    reads = []
+    for _ in range(4000):
+        s = int(rng.integers(0, len(genome) - 150))
+        r = genome[s:s + 150].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(r)
+    fq = fastq_text(reads)
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    for M in (1, 2, 3):
+        want = np.sort(sk.fastq(fq, Q=0, M=M))
+        b = K.Batch()
+        lines = b.add_fastq(fq, Q=0)
+        assert lines == 4 * len(reads)
+        off, ids = gpu_ctx.sketch_batch(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY, min_occ=M)
+        assert np.array_equal(ids, want), (M, len(ids), len(want))
+    # quality floor: raw ASCII compare (iseq2comem.c:312); 'I' >= '5' passes, '#' fails
+    fq2 = fastq_text(reads[:500], qual=b"#")
+    b = K.Batch()
+    b.add_fastq(fq2, Q=ord("5"))
+    off, ids = gpu_ctx.sketch_batch(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY)
+    assert len(ids) == 0 and len(sk.fastq(fq2, Q=ord("5"), M=1)) == 0
+
+
+@pytest.mark.parametrize("k,subk,dr", [(8, 5, 2), (10, 7, 5), (9, 6, 3), (11, 6, 3), (12, 7, 4)])
+def test_other_shuffles(k, subk, dr):
+    shuf = K.Shuf.generate(k, subk, dr, seed=77 + k)
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        gs = clade_genomes(2, 2, 400_000, seed=k)
+        texts = [fasta_text(c, nm, n_mask=m) for nm, c, m in gs]
+        check(ctx, shuf, texts)
+    finally:
+        ctx.close()
+
+
+def test_capacity_error_is_the_references(gpu_ctx, shuf_l3k10):
+    """a genome with more distinct k-mers than 0.6*hashsize must fail like the reference (iseq2comem.c:262)"""
+    # L3K10 needs > 1.26 M distinct ids (> 5 Gb of sequence): not testable at unit size; use a small-k shuffle
+    shuf = K.Shuf.generate(6, 4, 1, seed=5)   # hashsize = primer[5] = 8191, limit 4914, pass rate 1/16
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        rng = np.random.default_rng(1)
+        big = fasta_text(rng.integers(0, 4, 400_000, dtype=np.uint8))
+        small = fasta_text(rng.integers(0, 4, 20_000, dtype=np.uint8))
+        sk = ko.Sketcher(shuf.table, 6, 4, 1)
+        with pytest.raises(ko.OracleError) as oe:
+            sk.fasta(big)
+        assert oe.value.code == -2
+        b = K.Batch()
+        b.add_fasta(small)
+        b.add_fasta(big)
+        with pytest.raises(K.KssdError) as e:
+            ctx.sketch_batch(b)
+        assert e.value.code == -3 and e.value.bad_genome == 1
+        b2 = K.Batch()
+        b2.add_fasta(small)
+        off, ids = ctx.sketch_batch(b2)
+        assert np.array_equal(ids, np.sort(sk.fasta(small)))
+    finally:
+        ctx.close()
+
+
+def test_empty_batch_and_empty_genome(gpu_ctx, shuf_l3k10):
+    b = K.Batch()
+    b.add_fasta(b">nothing but a header\n")
+    b.add_fasta(b">x\nACGT\n")
+    off, ids = gpu_ctx.sketch_batch(b)
+    assert list(off) == [0, 0, 0] and len(ids) == 0
