@@ -99,7 +99,7 @@ def cpu_baseline(shuf, kept, cores, gpu_sets):
     for g in range(len(texts)):
         want = np.sort(ids[int(off[g]):int(off[g + 1])])
         assert np.array_equal(gpu_sets[g], want), "bench sample genome %d: GPU sketch != oracle" % g
-    port = {"value": len(texts) / t_port, "unit": "genomes/s", "cores": cores, "kind": "port",
+    port = {"value": len(texts) / t_port, "unit": "genomes/s", "cores": min(cores, len(texts)), "kind": "port",
             "sample": "%d of the bench genomes (%.0f Mbase) as 70-col FASTA text in memory, oracle/kssd_oracle.c "
                       "sketch_texts, OpenMP over genomes" % (len(texts), nb / 1e6),
             "mbase_per_s": nb / 1e6 / t_port}
@@ -114,15 +114,17 @@ def cpu_baseline(shuf, kept, cores, gpu_sets):
                     f.write(t)
             shuf.write(os.path.join(d, "L3K10.shuf"))
             t0 = time.time()
-            ko.run_ref(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "sk", "fa"], cwd=d, timeout=900)
+            # the reference only goes parallel when there are more files than threads (command_dist.c:275)
+            p_ref = max(1, min(cores, len(texts) - 1))
+            ko.run_ref(["dist", "-p", p_ref, "-L", "L3K10.shuf", "-o", "sk", "fa"], cwd=d, timeout=900)
             t_ref = time.time() - t0
             sets = ko.sketch_sets_by_name(os.path.join(d, "sk"))
             for i in range(len(texts)):
                 assert np.array_equal(sets["g%04d.fasta" % i], gpu_sets[i]), "reference binary sketch != GPU sketch"
-            out["reference"] = {"value": len(texts) / t_ref, "unit": "genomes/s", "cores": cores, "kind": "reference",
+            out["reference"] = {"value": len(texts) / t_ref, "unit": "genomes/s", "cores": p_ref, "kind": "reference",
                                 "sample": "%d of the bench genomes (%.0f Mbase) as FASTA files in tmpfs, "
                                           "`oracle/_ref/kssd dist -p %d -L L3K10.shuf` wall time incl. process start "
-                                          "and the 64 MiB .shuf load" % (len(texts), nb / 1e6, cores),
+                                          "and the 64 MiB .shuf load" % (len(texts), nb / 1e6, p_ref),
                                 "mbase_per_s": nb / 1e6 / t_ref}
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -302,6 +304,7 @@ def main():
             except Exception:
                 pass
         print(json.dumps(res), flush=True)
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

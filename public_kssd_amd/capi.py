@@ -270,7 +270,9 @@ class GpuCtx:
             self.h = None
 
     def __del__(self):
-        self.close()
+        import sys
+        if not sys.is_finalizing():  # never call into HIP while the interpreter (and the runtime) shut down
+            self.close()
 
     # host-level ---------------------------------------------------------------------------------------
     def sketch_batch(self, batch, flags=SKETCH_FASTA, min_occ=1):

@@ -102,25 +102,41 @@ KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t g_log2) { return (dim * 0x9E
 // Stage 1 for one lane: W[0..4] = the 5 packed words covering the lane's 64 window-start positions
 // plus the 2*subk-1 bases after them.  Bit i of the result <=> the sub-context that starts at the
 // lane's position i MAY be one of the accepted sub-contexts or the reverse complement of one.
-// One table read answers 4 consecutive positions: they share the 2*subk-3 bases in the middle.
+// One table read answers 4 consecutive positions: they share the 2*subk-3 bases in the middle ("quad
+// core").  Every position is tested under two quad alignments (quads starting at 4q and at 4q+2): the
+// two cores together pin 2*subk-1 of its 2*subk bases, which cuts the candidates ~10x (3.1 % -> 0.3 %
+// at subk = 6) for the price of a second LDS read per 4 positions.
 template <int SUBK, typename T1PTR>
 KSSD_HD void kssd_stage1(const uint32_t (&W)[5], T1PTR T1, uint32_t &cand_lo, uint32_t &cand_hi)
 {
     constexpr int CB = 2 * (2 * SUBK - 3);  // bits of a quad core
+    constexpr uint32_t CMASK = (1u << CB) - 1u;
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int o = 8 * q + 6;  // bit offset of the core of quad q, counted from the top of W[0]
         const int wi = o >> 5, bo = o & 31;
         uint64_t win = ((uint64_t)W[wi] << 32) | W[wi + 1];
-        uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & ((1u << CB) - 1u);
+        uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & CMASK;
         uint32_t idx = kssd_t1_index<CB>(core);
         uint32_t nib = ((uint32_t)T1[idx >> 1] >> ((idx & 1u) * 4u)) & 0xFu;
         if (q < 8) lo |= nib << (4 * q);
         else hi |= nib << (4 * (q - 8));
     }
-    cand_lo = lo;
-    cand_hi = hi;
+    uint64_t second = 0;
+#pragma unroll
+    for (int q = -1; q < 16; q++) {
+        const int o = 8 * q + 10;  // quads shifted by two positions: windows 4q+2 .. 4q+5
+        const int wi = o >> 5, bo = o & 31;
+        uint64_t win = ((uint64_t)W[wi] << 32) | (wi < 4 ? W[wi < 4 ? wi + 1 : 4] : 0u);
+        uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & CMASK;
+        uint32_t idx = kssd_t1_index<CB>(core);
+        uint64_t nib = ((uint32_t)T1[idx >> 1] >> ((idx & 1u) * 4u)) & 0xFu;
+        if (q < 0) second |= nib >> 2;  // windows -2,-1 belong to the previous lane
+        else second |= nib << (4 * q + 2);  // q = 15: windows 64,65 fall off the top
+    }
+    cand_lo = lo & (uint32_t)second;
+    cand_hi = hi & (uint32_t)(second >> 32);
 }
 
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank

@@ -6,11 +6,21 @@ ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 def fasta_text(codes, name=b"seq", width=70, n_mask=None):
     """codes: uint8 array of 0..3; n_mask: optional bool array, True -> 'N'"""
-    s = ACGT[codes].copy()
+    s = ACGT[codes]
     if n_mask is not None:
+        s = s.copy()
         s[n_mask] = ord("N")
-    body = b"\n".join(bytes(s[i:i + width]) for i in range(0, len(s), width))
-    return b">" + name + b"\n" + body + b"\n"
+    n = len(s)
+    rows = (n + width - 1) // width
+    buf = np.full((rows, width + 1), ord("\n"), dtype=np.uint8)
+    flat = np.zeros(rows * width, dtype=np.uint8)
+    flat[:n] = s
+    buf[:, :width] = flat.reshape(rows, width)
+    body = buf.reshape(-1)
+    if rows:
+        tail = n - (rows - 1) * width  # bases on the last line
+        body = np.concatenate([body[:(rows - 1) * (width + 1) + tail], np.array([ord("\n")], dtype=np.uint8)])
+    return b">" + name + b"\n" + body.tobytes()
 
 
 def clade_genomes(n_clades, per_clade, length, seed, sub_lo=0.005, sub_hi=0.05, p_n=1e-4):

@@ -69,4 +69,5 @@ def test_stage1_stage2_match_oracle(emu, k, subk, dr):
     brute, _ = run_emu(emu, shuf, b, brute=1)
     assert np.array_equal(np.sort(got), np.sort(brute))
     if subk == 6:
-        assert 0.02 < ncand / (b.n_chunks * 4096) < 0.04  # 2*4096*4 patterns over 2^18 cores
+        # two quad alignments: (8192*4 / 2^18) * (1/16 + 8192/2^18) ~ 0.3 % of the positions reach stage 2
+        assert 0.002 < ncand / (b.n_chunks * 4096) < 0.004
