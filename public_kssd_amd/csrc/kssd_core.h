@@ -106,37 +106,56 @@ KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t g_log2) { return (dim * 0x9E
 // core").  Every position is tested under two quad alignments (quads starting at 4q and at 4q+2): the
 // two cores together pin 2*subk-1 of its 2*subk bases, which cuts the candidates ~10x (3.1 % -> 0.3 %
 // at subk = 6) for the price of a second LDS read per 4 positions.
+// One quad lookup.  The core is pulled out of the 64-bit window with 2 spare bits below it, so that
+//   byte address = field >> 3, nibble select = field & 4   (identity index, CB <= 18)
+// costs one shift/alignbit, one bfe, one and, one bfe after the LDS read.
+template <int CB, typename T1PTR>
+KSSD_HD uint32_t kssd_quad_nibble(uint32_t whi, uint32_t wlo, int bo, T1PTR T1)
+{
+    const uint64_t win = ((uint64_t)whi << 32) | wlo;
+    if (CB <= KSSD_T1_BITS) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int sh = 62 - bo - CB;  // compile-time after unrolling
+        const uint32_t field = sh >= 32 ? (whi >> (sh - 32)) : __builtin_amdgcn_alignbit(whi, wlo, sh);
+        const uint32_t byte = T1[__builtin_amdgcn_ubfe(field, 3, CB - 1)];
+        return __builtin_amdgcn_ubfe(byte, field & 4u, 4);
+#else
+        const uint32_t field = (uint32_t)(win >> (62 - bo - CB));  // core in bits [2, 2+CB)
+        const uint32_t byte = T1[(field >> 3) & ((1u << (CB - 1)) - 1u)];
+        return (byte >> (field & 4u)) & 0xFu;
+#endif
+    } else {
+        const uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & ((1u << CB) - 1u);
+        const uint32_t idx = kssd_t1_index<CB>(core);
+        return ((uint32_t)T1[idx >> 1] >> ((idx & 1u) * 4u)) & 0xFu;
+    }
+}
+
 template <int SUBK, typename T1PTR>
 KSSD_HD void kssd_stage1(const uint32_t (&W)[5], T1PTR T1, uint32_t &cand_lo, uint32_t &cand_hi)
 {
     constexpr int CB = 2 * (2 * SUBK - 3);  // bits of a quad core
-    constexpr uint32_t CMASK = (1u << CB) - 1u;
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int o = 8 * q + 6;  // bit offset of the core of quad q, counted from the top of W[0]
-        const int wi = o >> 5, bo = o & 31;
-        uint64_t win = ((uint64_t)W[wi] << 32) | W[wi + 1];
-        uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & CMASK;
-        uint32_t idx = kssd_t1_index<CB>(core);
-        uint32_t nib = ((uint32_t)T1[idx >> 1] >> ((idx & 1u) * 4u)) & 0xFu;
+        const uint32_t nib = kssd_quad_nibble<CB>(W[o >> 5], W[(o >> 5) + 1], o & 31, T1);
         if (q < 8) lo |= nib << (4 * q);
         else hi |= nib << (4 * (q - 8));
     }
-    uint64_t second = 0;
+    uint32_t lo2 = 0, hi2 = 0;
 #pragma unroll
     for (int q = -1; q < 16; q++) {
         const int o = 8 * q + 10;  // quads shifted by two positions: windows 4q+2 .. 4q+5
-        const int wi = o >> 5, bo = o & 31;
-        uint64_t win = ((uint64_t)W[wi] << 32) | (wi < 4 ? W[wi < 4 ? wi + 1 : 4] : 0u);
-        uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & CMASK;
-        uint32_t idx = kssd_t1_index<CB>(core);
-        uint64_t nib = ((uint32_t)T1[idx >> 1] >> ((idx & 1u) * 4u)) & 0xFu;
-        if (q < 0) second |= nib >> 2;  // windows -2,-1 belong to the previous lane
-        else second |= nib << (4 * q + 2);  // q = 15: windows 64,65 fall off the top
+        const int wi = o >> 5;
+        const uint32_t nib = kssd_quad_nibble<CB>(W[wi], wi < 4 ? W[wi < 4 ? wi + 1 : 4] : 0u, o & 31, T1);
+        if (q < 0) lo2 |= nib >> 2;  // windows -2,-1 belong to the previous lane
+        else if (q < 7) lo2 |= nib << (4 * q + 2);
+        else if (q == 7) { lo2 |= nib << 30; hi2 |= nib >> 2; }  // windows 30..33 straddle the two words
+        else hi2 |= nib << (4 * q - 30);  // q = 15: windows 64,65 fall off the top
     }
-    cand_lo = lo & (uint32_t)second;
-    cand_hi = hi & (uint32_t)(second >> 32);
+    cand_lo = lo & lo2;
+    cand_hi = hi & hi2;
 }
 
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank

@@ -53,11 +53,12 @@ extern "C" const char *kssd_gpu_strerror(int code)
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define QCAP 256          // per-wave candidate queue (u16 chunk-local positions)
+#define QCAP 256          // per-wave candidate queue (u32: chunk offset << 12 | position), lives across chunks
 #define EBUF 64           // per-wave emission buffer (u32 reduced tuples)
 #define DEDUP_THREADS 256
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
+#define SCAN_LDS_BYTES (KSSD_T1_BYTES + SCAN_WAVES * QCAP * 4 + SCAN_WAVES * EBUF * 4)
 
 struct SketchStatus {
     unsigned long long total_ids;
@@ -263,14 +264,16 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
 // ---------------------------------------------------------------------------------------------------
 // kernel 1: the scan.  One wave per 4096-position chunk iteration, one lane per 64 positions.
 //   HBM -> registers: 16 B of packed bases + 8 B of mask per lane, coalesced, next chunk prefetched
-//   stage 1: 16 LDS nibble reads per lane decide 64 positions (quad-core table, 128 KiB of LDS)
-//   ballot/scan compaction of the ~3 % candidate positions into a per-wave LDS queue
-//   stage 2: dense exact evaluation, survivors staged in LDS and appended to the genome's region
+//   stage 1: 33 LDS nibble reads per lane decide 64 positions (quad-core table, 128 KiB of LDS)
+//   ballot compaction of the ~0.3 % candidate positions into a per-wave LDS queue that lives ACROSS
+//   chunks: stage 2 only runs on full rounds of 64 candidates (it costs the same for 1 lane as for 64)
+//   stage 2: exact evaluation, survivors staged in LDS and appended to the genome's region
 // ---------------------------------------------------------------------------------------------------
 struct ScanArgs {
     const uint32_t *packed;
     const uint32_t *mask;
     const uint32_t *chunk_gid;
+    const unsigned long long *chunk_off;  // per genome, in chunks
     unsigned long long n_chunks;
     const uint8_t *T1;
     const KssdG *G;
@@ -291,15 +294,73 @@ __device__ __forceinline__ void flush_emissions(const ScanArgs &a, uint32_t gid,
     if (lane < n && (unsigned long long)base + lane < cap) a.regions[r0 + base + lane] = ebuf[lane];
 }
 
-template <int SUBK>
+// per-wave state of the scan that the helpers below share
+struct WaveState {
+    uint32_t *queue;   // LDS, QCAP entries: (chunk - c0) << 12 | position in chunk
+    uint32_t *ebuf;    // LDS, EBUF reduced tuples waiting for the next region append
+    uint32_t qn;       // queued candidates (wave-uniform)
+    uint32_t ecount;   // staged emissions (wave-uniform)
+    uint32_t gid;      // genome all queued candidates and staged emissions belong to
+    long long glo, ghi;  // positions of that genome: [glo, ghi)
+    unsigned long long c0;
+};
+
+// stage 2 for one round of up to 64 queued candidates (entries [first, first+n) of the queue)
+__device__ __forceinline__ void stage2_round(const KssdParams &P, const ScanArgs &a, WaveState &w, uint32_t first, uint32_t n,
+                                             uint32_t lane)
+{
+    bool ok = false;
+    uint32_t dr = 0;
+    if (lane < n) {
+        const uint32_t e = w.queue[first + lane];
+        const long long s = (long long)((w.c0 + (e >> 12)) * KSSD_CHUNK) + (long long)(e & 4095u);
+        ok = kssd_stage2(P, s, w.glo, w.ghi, a.packed, a.mask, a.G, dr);
+    }
+    const uint64_t bal = __ballot(ok);
+    const uint32_t m = __builtin_popcountll(bal);
+    if (m) {
+        if (w.ecount + m > EBUF) {
+            wave_lds_sync();
+            flush_emissions(a, w.gid, w.ecount, w.ebuf, lane);
+            wave_lds_sync();
+            w.ecount = 0;
+        }
+        if (ok) w.ebuf[w.ecount + rank_in(bal)] = dr;
+        w.ecount += m;
+    }
+}
+
+// run stage 2 on full rounds of 64 (all = false) or on everything that is queued (all = true)
+__device__ __forceinline__ void drain_queue(const KssdParams &P, const ScanArgs &a, WaveState &w, bool all, uint32_t lane)
+{
+    wave_lds_sync();
+    while (w.qn >= 64) {
+        w.qn -= 64;
+        stage2_round(P, a, w, w.qn, 64, lane);
+    }
+    if (all && w.qn) {
+        stage2_round(P, a, w, 0, w.qn, lane);
+        w.qn = 0;
+    }
+    wave_lds_sync();
+}
+
+// ABL != 0: development-only ablations for profiling (1 = loads only, 2 = + stage 1, 3 = + queue push);
+// never used by the product path
+template <int SUBK, int ABL = 0>
 __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(KssdParams P, ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t abl_acc = 0;
+    // static LDS: the table sits at LDS address 0, so its byte reads need no base add
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SCAN_LDS_BYTES];
     uint8_t *T1 = smem;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
-    uint16_t *queue = reinterpret_cast<uint16_t *>(smem + KSSD_T1_BYTES) + wave * QCAP;
-    uint32_t *ebuf = reinterpret_cast<uint32_t *>(smem + KSSD_T1_BYTES + SCAN_WAVES * QCAP * 2) + wave * EBUF;
+    WaveState w;
+    w.queue = reinterpret_cast<uint32_t *>(smem + KSSD_T1_BYTES) + wave * QCAP;
+    w.ebuf = reinterpret_cast<uint32_t *>(smem + KSSD_T1_BYTES + SCAN_WAVES * QCAP * 4) + wave * EBUF;
+    w.qn = 0;
+    w.ecount = 0;
 
     for (uint32_t i = threadIdx.x * 16; i < KSSD_T1_BYTES; i += SCAN_THREADS * 16)
         *reinterpret_cast<uint4 *>(T1 + i) = *reinterpret_cast<const uint4 *>(a.T1 + i);
@@ -313,9 +374,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(KssdParams P,
     unsigned long long c0 = wid * per, c1 = c0 + per;
     if (c1 > a.n_chunks) c1 = a.n_chunks;
     if (c0 >= c1) return;
-
-    const unsigned long long total_pos = a.n_chunks * KSSD_CHUNK;
-    uint32_t ecount = 0, egid = a.chunk_gid[c0];
+    w.c0 = c0;
+    w.gid = 0xFFFFFFFFu;
+    w.glo = w.ghi = 0;
 
     uint32_t W[5], M[2];
     {
@@ -325,87 +386,57 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(KssdParams P,
         const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + c0 * 128 + lane * 2);
         M[0] = m.x; M[1] = m.y;
     }
+    uint32_t gid_next = a.chunk_gid[c0];
     for (unsigned long long c = c0; c < c1; ++c) {
         // prefetch the next chunk while this one is processed
         uint32_t Wn[5] = {0, 0, 0, 0, 0}, Mn[2] = {0, 0};
+        const uint32_t gid = gid_next;
         if (c + 1 < c1) {
             const uint4 v = *reinterpret_cast<const uint4 *>(a.packed + (c + 1) * 256 + lane * 4);
             Wn[0] = v.x; Wn[1] = v.y; Wn[2] = v.z; Wn[3] = v.w;
             Wn[4] = a.packed[(c + 1) * 256 + lane * 4 + 4];
             const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + (c + 1) * 128 + lane * 2);
             Mn[0] = m.x; Mn[1] = m.y;
+            gid_next = a.chunk_gid[c + 1];
         }
-        const uint32_t gid = a.chunk_gid[c];
-        if (gid != egid) {
-            if (ecount) { wave_lds_sync(); flush_emissions(a, egid, ecount, ebuf, lane); wave_lds_sync(); }
-            ecount = 0;
-            egid = gid;
-        }
-        // positions the k-mers of this chunk may touch: the chunk itself plus same-genome neighbours
-        const long long cbeg = (long long)(c * KSSD_CHUNK);
-        long long lo_ok = cbeg, hi_ok = cbeg + KSSD_CHUNK;
-        if (c > 0 && a.chunk_gid[c - 1] == gid) lo_ok -= KSSD_CHUNK;
-        if (c + 1 < a.n_chunks && a.chunk_gid[c + 1] == gid) hi_ok += KSSD_CHUNK;
-        if (hi_ok > (long long)total_pos) hi_ok = (long long)total_pos;
-
-        uint32_t cl, ch;
-        kssd_stage1<SUBK>(W, T1, cl, ch);
-        cl &= M[0];  // the window start itself must be a base: kills padding / N stretches early
-        ch &= M[1];
-
-        const uint32_t cnt = __builtin_popcount(cl) + __builtin_popcount(ch);
-        const uint32_t incl = wave_incl_scan(cnt, lane);
-        const uint32_t total = __shfl(incl, 63, 64);
-        if (total == 0) {
-            // nothing to do
-        } else if (total <= QCAP) {
-            uint32_t w = incl - cnt;
-            uint32_t x = cl;
-            while (x) { uint32_t b = __builtin_ctz(x); x &= x - 1; queue[w++] = (uint16_t)(lane * 64 + b); }
-            x = ch;
-            while (x) { uint32_t b = __builtin_ctz(x); x &= x - 1; queue[w++] = (uint16_t)(lane * 64 + 32 + b); }
-            wave_lds_sync();
-            for (uint32_t i0 = 0; i0 < total; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                bool ok = false;
-                uint32_t dr = 0;
-                if (i < total) ok = kssd_stage2(P, cbeg + queue[i], lo_ok, hi_ok, a.packed, a.mask, a.G, dr);
-                const uint64_t bal = __ballot(ok);
-                const uint32_t n = __builtin_popcountll(bal);
-                if (n) {
-                    if (ecount + n > EBUF) {
-                        wave_lds_sync();
-                        flush_emissions(a, egid, ecount, ebuf, lane);
-                        wave_lds_sync();
-                        ecount = 0;
-                    }
-                    if (ok) ebuf[ecount + rank_in(bal)] = dr;
-                    ecount += n;
-                }
-            }
-            wave_lds_sync();
+        if (ABL == 1) {
+            abl_acc ^= W[0] ^ W[1] ^ W[2] ^ W[3] ^ W[4] ^ M[0] ^ M[1] ^ gid;
         } else {
-            // more candidates than the queue holds (low-complexity sequence): lanes evaluate their own
-            while (__any((cl | ch) != 0)) {
-                bool ok = false;
-                uint32_t dr = 0;
-                if (cl | ch) {
-                    uint32_t b;
-                    if (cl) { b = __builtin_ctz(cl); cl &= cl - 1; }
-                    else { b = 32 + __builtin_ctz(ch); ch &= ch - 1; }
-                    ok = kssd_stage2(P, cbeg + lane * 64 + b, lo_ok, hi_ok, a.packed, a.mask, a.G, dr);
-                }
-                const uint64_t bal = __ballot(ok);
-                const uint32_t n = __builtin_popcountll(bal);
-                if (n) {
-                    if (ecount + n > EBUF) {
-                        wave_lds_sync();
-                        flush_emissions(a, egid, ecount, ebuf, lane);
-                        wave_lds_sync();
-                        ecount = 0;
+            if (gid != w.gid) {
+                // genome boundary: everything queued or staged belongs to the previous genome
+                if (w.qn) drain_queue(P, a, w, true, lane);
+                if (w.ecount) { wave_lds_sync(); flush_emissions(a, w.gid, w.ecount, w.ebuf, lane); wave_lds_sync(); }
+                w.ecount = 0;
+                w.gid = gid;
+                w.glo = (long long)(a.chunk_off[gid] * KSSD_CHUNK);
+                w.ghi = (long long)(a.chunk_off[gid + 1] * KSSD_CHUNK);
+            }
+            uint32_t cl, ch;
+            kssd_stage1<SUBK>(W, T1, cl, ch);
+            cl &= M[0];  // the window start itself must be a base: kills padding / N stretches early
+            ch &= M[1];
+            if (ABL == 2) {
+                abl_acc ^= cl ^ ch;
+            } else {
+                // ballot compaction: every pass moves one candidate of every lane that still has one
+                const uint32_t ebase = ((uint32_t)(c - c0) << 12) | (lane << 6);
+                for (;;) {
+                    const bool has = (cl | ch) != 0;
+                    const uint64_t bal = __ballot(has);
+                    if (!bal) break;
+                    if (w.qn + 64 > QCAP) drain_queue(P, a, w, false, lane);
+                    if (has) {
+                        uint32_t b;
+                        if (cl) { b = __builtin_ctz(cl); cl &= cl - 1; }
+                        else { b = 32 + __builtin_ctz(ch); ch &= ch - 1; }
+                        w.queue[w.qn + rank_in(bal)] = ebase | b;
                     }
-                    if (ok) ebuf[ecount + rank_in(bal)] = dr;
-                    ecount += n;
+                    w.qn += __builtin_popcountll(bal);
+                }
+                if (ABL == 3) {
+                    if (w.qn >= 64) { wave_lds_sync(); abl_acc ^= w.queue[lane]; w.qn = 0; wave_lds_sync(); }
+                } else if (w.qn >= 64) {
+                    drain_queue(P, a, w, false, lane);
                 }
             }
         }
@@ -414,7 +445,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(KssdParams P,
         M[0] = Mn[0];
         M[1] = Mn[1];
     }
-    if (ecount) { wave_lds_sync(); flush_emissions(a, egid, ecount, ebuf, lane); }
+    if (ABL == 0 || ABL == 3) {
+        if (w.qn && ABL == 0) drain_queue(P, a, w, true, lane);
+        if (w.ecount) { wave_lds_sync(); flush_emissions(a, w.gid, w.ecount, w.ebuf, lane); }
+    }
+    if (ABL != 0 && abl_acc == 0x9e3779b9u) a.regions[0] = abl_acc;  // keeps the ablated work alive
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -563,13 +598,10 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
 // ---------------------------------------------------------------------------------------------------
 // sketch entry points
 // ---------------------------------------------------------------------------------------------------
-template <int SUBK>
+template <int SUBK, int ABL = 0>
 static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s)
 {
-    const size_t lds = KSSD_T1_BYTES + SCAN_WAVES * QCAP * 2 + SCAN_WAVES * EBUF * 4;
-    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_scan_kernel<SUBK>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sketch_scan_kernel<SUBK>, dim3(grid), dim3(SCAN_THREADS), lds, s, c->P, a);
+    hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, c->P, a);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -627,6 +659,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
                            (const uint64_t *)c->d_chunk_off, n_genomes, n_chunks, c->d_chunk_gid);
         ScanArgs a;
         a.packed = d_packed; a.mask = d_mask; a.chunk_gid = c->d_chunk_gid; a.n_chunks = n_chunks;
+        a.chunk_off = (const unsigned long long *)c->d_chunk_off;
         a.T1 = c->d_T1; a.G = c->d_G; a.reg_off = (const unsigned long long *)c->d_reg_off;
         a.cursor = c->d_cursor; a.regions = c->d_regions;
         uint64_t want = (n_chunks + SCAN_WAVES - 1) / SCAN_WAVES;
@@ -638,7 +671,14 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         case 3: rc = launch_scan<3>(c, a, grid, s); break;
         case 4: rc = launch_scan<4>(c, a, grid, s); break;
         case 5: rc = launch_scan<5>(c, a, grid, s); break;
-        case 6: rc = launch_scan<6>(c, a, grid, s); break;
+        case 6: {
+            static const int abl = getenv("KSSD_DEV_ABLATE") ? atoi(getenv("KSSD_DEV_ABLATE")) : 0;  // profiling only
+            if (abl == 1) rc = launch_scan<6, 1>(c, a, grid, s);
+            else if (abl == 2) rc = launch_scan<6, 2>(c, a, grid, s);
+            else if (abl == 3) rc = launch_scan<6, 3>(c, a, grid, s);
+            else rc = launch_scan<6>(c, a, grid, s);
+            break;
+        }
         case 7: rc = launch_scan<7>(c, a, grid, s); break;
         default: rc = KSSD_ERR_UNSUPPORTED;
         }
