@@ -77,6 +77,9 @@ int kssd_gpu_create(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, const int32_t 
 /* same, from the compact form: accepted[r] = the sub-context x with table[x] == r, r < dim_end */
 int kssd_gpu_create_compact(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, const uint32_t *accepted,
                             uint32_t n_accepted, int device);
+/* a context that can only index and compute distances (no .shuf needed): kmerlen = 2k of the sketches,
+ * as stored in cofiles.stat / mcofiles.stat (command_dist.c:727) */
+int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int device);
 void kssd_gpu_destroy(kssd_gpu_ctx *ctx);
 int kssd_gpu_get_info(const kssd_gpu_ctx *ctx, kssd_gpu_info *info);
 

@@ -29,6 +29,7 @@ OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, 
 
 GPU_SYMBOLS = [
     "kssd_gpu_strerror", "kssd_gpu_last_hip_error", "kssd_gpu_create", "kssd_gpu_create_compact",
+    "kssd_gpu_create_for_dist",
     "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
     "kssd_gpu_dist", "kssd_gpu_kernel_time",
@@ -50,6 +51,22 @@ class GpuInfo(C.Structure):
                 ("dim_rd_len", C.c_int32), ("comp_num", C.c_int32), ("comp_bits", C.c_int32),
                 ("dim_end", C.c_uint32), ("hashsize", C.c_uint32), ("hashlimit", C.c_uint32),
                 ("device", C.c_int32), ("cu_count", C.c_int32)]
+
+
+class _SketchSet(C.Structure):
+    _fields_ = [("shuf_id", C.c_uint32), ("koc", C.c_int), ("kmerlen", C.c_int), ("dim_rd_len", C.c_int),
+                ("comp_num", C.c_int), ("n", C.c_uint32), ("off", C.c_void_p), ("ids", C.c_void_p),
+                ("names", C.c_void_p)]
+
+
+class _PrintOpt(C.Structure):
+    _fields_ = [("metric", C.c_int), ("pfield", C.c_int), ("correction", C.c_int), ("dthreshold", C.c_double),
+                ("n_max", C.c_int), ("threads", C.c_int)]
+
+
+class _Derived(C.Structure):
+    _fields_ = [("k", C.c_int), ("subk", C.c_int), ("drlevel", C.c_int), ("kmerlen", C.c_int), ("dim_rd_len", C.c_int),
+                ("comp_num", C.c_int), ("comp_bits", C.c_int), ("hashsize", C.c_uint32), ("hashlimit", C.c_uint32)]
 
 
 class _Shuf(C.Structure):
@@ -75,6 +92,7 @@ def gpu_lib():
         L.kssd_gpu_last_hip_error.restype = C.c_char_p
         L.kssd_gpu_create.argtypes = [C.POINTER(vp), C.POINTER(ShufHdr), vp, i32]
         L.kssd_gpu_create_compact.argtypes = [C.POINTER(vp), C.POINTER(ShufHdr), vp, u32, i32]
+        L.kssd_gpu_create_for_dist.argtypes = [C.POINTER(vp), i32, i32]
         L.kssd_gpu_destroy.argtypes = [vp]
         L.kssd_gpu_destroy.restype = None
         L.kssd_gpu_get_info.argtypes = [vp, C.POINTER(GpuInfo)]
@@ -123,6 +141,19 @@ def host_lib():
         L.kssd_batch_n_genomes.argtypes = [vp]
         L.kssd_batch_n_positions.restype = u64
         L.kssd_batch_n_positions.argtypes = [vp, u32]
+        L.kssd_batch_append.argtypes = [vp, vp]
+        L.kssd_derive.argtypes = [C.POINTER(_Derived), i32, i32, i32]
+        L.kssd_sketchset_release.argtypes = [C.POINTER(_SketchSet)]
+        L.kssd_sketchset_release.restype = None
+        L.kssd_slot_order.argtypes = [vp, u64, u32]
+        L.kssd_slot_order.restype = None
+        L.kssd_sketchset_write.argtypes = [C.POINTER(_SketchSet), C.c_char_p, u32, i32]
+        L.kssd_sketchset_read.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
+        L.kssd_index_write.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
+        L.kssd_index_read.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
+        L.kssd_probe_dir.argtypes = [C.c_char_p]
+        L.kssd_distance_print.argtypes = [C.c_char_p, vp, C.POINTER(_SketchSet), C.POINTER(_SketchSet),
+                                          C.POINTER(_PrintOpt)]
         _host = L
     return _host
 
@@ -173,6 +204,88 @@ class Shuf:
 
     def hdr(self):
         return ShufHdr(self.id, self.k, self.subk, self.drlevel)
+
+
+# ------------------------------------------------------------------------------------------------------
+# on-disk sketch / index formats and the distance report (host C, kssd_formats.c)
+# ------------------------------------------------------------------------------------------------------
+def derive(k, subk, drlevel):
+    d = _Derived()
+    _hck(host_lib().kssd_derive(C.byref(d), k, subk, drlevel))
+    return d
+
+
+class SketchSet:
+    """Sketches of n genomes: CSR of full reduced tuples + the header fields of cofiles.stat."""
+
+    def __init__(self, shuf_id, kmerlen, dim_rd_len, comp_num, names, off, ids):
+        self.shuf_id, self.kmerlen, self.dim_rd_len, self.comp_num = shuf_id, kmerlen, dim_rd_len, comp_num
+        self.names = list(names)
+        self.off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.ids = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+        assert len(self.off) == len(self.names) + 1
+
+    def _c(self):
+        self._nm = b"".join(os.fsencode(n).ljust(256, b"\0")[:256] for n in self.names) or b"\0"
+        self._nmbuf = C.create_string_buffer(self._nm, len(self._nm))
+        self._ids = self.ids if len(self.ids) else np.zeros(1, np.uint32)
+        return _SketchSet(self.shuf_id, 0, self.kmerlen, self.dim_rd_len, self.comp_num, len(self.names),
+                          self.off.ctypes.data, self._ids.ctypes.data, C.addressof(self._nmbuf))
+
+    @classmethod
+    def _from_c(cls, s):
+        n = s.n
+        off = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(s.off), dtype=np.uint64).copy()
+        tot = int(off[-1])
+        ids = (np.frombuffer((C.c_char * (4 * tot)).from_address(s.ids), dtype=np.uint32).copy() if tot
+               else np.zeros(0, np.uint32))
+        raw = (C.c_char * (256 * n)).from_address(s.names).raw if n else b""
+        names = [raw[256 * i:256 * (i + 1)].split(b"\0")[0].decode() for i in range(n)]
+        return cls(s.shuf_id, s.kmerlen, s.dim_rd_len, s.comp_num, names, off, ids)
+
+    def write(self, d, hashsize, slot_order=True):
+        """cofiles.stat + combco.<c> + combco.index.<c>"""
+        _hck(host_lib().kssd_sketchset_write(C.byref(self._c()), os.fsencode(d), hashsize, int(slot_order)))
+
+    def write_index(self, d):
+        """mcofiles.stat + mco.index.<c> (dense, 2 GiB per component) + mco.<c>"""
+        _hck(host_lib().kssd_index_write(C.byref(self._c()), os.fsencode(d)))
+
+    @classmethod
+    def read(cls, d):
+        s = _SketchSet()
+        _hck(host_lib().kssd_sketchset_read(C.byref(s), os.fsencode(d)))
+        try:
+            return cls._from_c(s)
+        finally:
+            host_lib().kssd_sketchset_release(C.byref(s))
+
+    @classmethod
+    def read_index(cls, d):
+        s = _SketchSet()
+        _hck(host_lib().kssd_index_read(C.byref(s), os.fsencode(d)))
+        try:
+            return cls._from_c(s)
+        finally:
+            host_lib().kssd_sketchset_release(C.byref(s))
+
+    def sets_by_name(self):
+        return {os.path.basename(n): np.sort(self.ids[int(self.off[i]):int(self.off[i + 1])])
+                for i, n in enumerate(self.names)}
+
+
+def slot_order(ids, hashsize):
+    a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+    host_lib().kssd_slot_order(a.ctypes.data, len(a), hashsize)
+    return a
+
+
+def distance_print(path, shared, ref, qry, metric=0, pfield=2, correction=0, dthreshold=1.0, n_max=0, threads=1):
+    shared = np.ascontiguousarray(shared, dtype=np.uint32)
+    assert shared.shape == (len(qry.names), len(ref.names))
+    o = _PrintOpt(metric, pfield, correction, dthreshold, n_max, threads)
+    _hck(host_lib().kssd_distance_print(os.fsencode(path), shared.ctypes.data, C.byref(ref._c()), C.byref(qry._c()),
+                                        C.byref(o)))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -257,10 +370,14 @@ def _ptr(x):
 class GpuCtx:
     """kssd_gpu_ctx: device tables for one .shuf + workspaces (one calling thread per context)."""
 
-    def __init__(self, shuf, device=0):
+    def __init__(self, shuf=None, device=0, kmerlen=None):
+        """shuf: a Shuf (sketch + distance context); or kmerlen=2k for a distance-only context"""
         self.h = C.c_void_p()
-        hdr = shuf.hdr()
-        _gck(gpu_lib().kssd_gpu_create(C.byref(self.h), C.byref(hdr), shuf.table.ctypes.data, device))
+        if shuf is None:
+            _gck(gpu_lib().kssd_gpu_create_for_dist(C.byref(self.h), kmerlen, device))
+        else:
+            hdr = shuf.hdr()
+            _gck(gpu_lib().kssd_gpu_create(C.byref(self.h), C.byref(hdr), shuf.table.ctypes.data, device))
         self.info = GpuInfo()
         _gck(gpu_lib().kssd_gpu_get_info(self.h, C.byref(self.info)))
 

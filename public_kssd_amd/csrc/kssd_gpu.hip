@@ -71,6 +71,7 @@ struct SketchStatus {
 struct kssd_gpu_ctx {
     int device;
     int cu_count;
+    bool dist_only;  // created by kssd_gpu_create_for_dist: no sketch tables
     KssdParams P;
     uint8_t *d_T1;
     KssdG *d_G;
@@ -170,6 +171,31 @@ extern "C" int kssd_gpu_create_compact(kssd_gpu_ctx **out, const kssd_shuf_hdr *
     if (!hdr || !acc) return KSSD_ERR_PARAM;
     std::vector<uint32_t> accepted(acc, acc + n);
     return ctx_new(out, hdr, accepted, device);
+}
+
+extern "C" int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int device)
+{
+    if (!out || kmerlen < 2 || kmerlen > 30 || (kmerlen & 1)) return KSSD_ERR_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KSSD_ERR_NO_DEVICE;
+    HIPCK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCK(hipGetDeviceProperties(&prop, device));
+    kssd_gpu_ctx *c = new (std::nothrow) kssd_gpu_ctx();
+    if (!c) return KSSD_ERR_NOMEM;
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    memset(&c->P, 0, sizeof c->P);
+    c->P.k = kmerlen / 2;
+    c->dist_only = true;
+    if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) { delete c; return KSSD_ERR_NOMEM; }
+    for (int w = 0; w < 2; w++)
+        for (int i = 0; i < EV_RING; i++) {
+            hipEventCreate(&c->ev_a[w][i]);
+            hipEventCreate(&c->ev_b[w][i]);
+        }
+    *out = c;
+    return KSSD_OK;
 }
 
 extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
@@ -610,7 +636,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
                                       const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
                                       uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap, void *stream)
 {
-    if (!c || !h_chunk_off || !d_out_off || (!d_out_ids && out_cap)) return KSSD_ERR_PARAM;
+    if (!c || c->dist_only || !h_chunk_off || !d_out_off || (!d_out_ids && out_cap)) return KSSD_ERR_PARAM;
     hipStream_t s = (hipStream_t)stream;
     HIPCK(hipSetDevice(c->device));
     c->last_launch_rc = KSSD_OK;

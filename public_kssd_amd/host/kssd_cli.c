@@ -1,0 +1,487 @@
+/*
+ * kssd_cli.c -- `kssd shuffle` and `kssd dist` on MI355X.
+ *
+ * Same sub-commands, flags, directory protocol and files as the reference front end
+ * (global_wrapper.c:82-145, command_shuffle.c:33-130, command_dist_wrapper.c:41-319, dist_dispatch
+ * command_dist.c:53-192); the two hot loops run on the GPU through include/kssd_gpu.h.
+ * Host C; there is no CPU implementation of the hot path behind it: without a gfx950 device the
+ * sketch and search modes stop with an error.
+ */
+#define _GNU_SOURCE
+#include <dirent.h>
+#include <errno.h>
+#include <getopt.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../../include/kssd_gpu.h"
+#include "kssd_host.h"
+
+#define VERSION "kssd-mi355x 0.1 (formats and results of KSSD version 1.2.21)"
+
+static void die(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "kssd: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    exit(code ? code : 1);
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * kssd shuffle  (command_shuffle.c)
+ * ------------------------------------------------------------------------------------------------- */
+static int cmd_shuffle(int argc, char **argv)
+{
+    int k = 8, subk = 5, lvl = 2; /* defaults of dim_shuffle_stat, command_shuffle.c:48-53 */
+    unsigned long long seed = 0;
+    char prefix[KSSD_PATHLEN] = "./default";
+    static struct option lo[] = {{"halfKmerLen", 1, 0, 'k'}, {"halfSubstrLen", 1, 0, 's'}, {"level", 1, 0, 'l'},
+                                 {"outfile", 1, 0, 'o'},     {"usedefault", 0, 0, 999},    {"seed", 1, 0, 998},
+                                 {0, 0, 0, 0}};
+    if (argc < 2) die(EINVAL, "usage: kssd shuffle -k <halfKmerLen> -s <halfSubstrLen> -l <level> -o <prefix> [--seed N]");
+    int c;
+    while ((c = getopt_long(argc, argv, "k:s:l:o:", lo, NULL)) != -1) {
+        switch (c) {
+        case 'k': k = atoi(optarg); break;
+        case 's': subk = atoi(optarg); break;
+        case 'l': lvl = atoi(optarg); break;
+        case 'o':
+            if (strlen(optarg) + strlen(".shuf") >= KSSD_PATHLEN) die(ENAMETOOLONG, "output path name %s should less than %d characters", optarg, KSSD_PATHLEN);
+            strcpy(prefix, optarg);
+            break;
+        case 999: printf("use default values for all options\n"); break;
+        case 998: seed = strtoull(optarg, NULL, 10); break; /* extension: reproducible .shuf */
+        default: die(EINVAL, "shuffle: unknown option");
+        }
+    }
+    if (k < subk) die(EINVAL, "write_dim_shuffle_file(): half-context len: %d should larger than half-subcontext len (or dimension reduce level + 2) %d", k, subk);
+    if (subk >= 8) die(EINVAL, "write_dim_shuffle_file(): subk shoud smaller than 8");
+    if ((1 << 4 * (subk - lvl > 0 ? subk - lvl : 0)) < 4096)
+        fprintf(stderr, "kssd: dimension after reduction %d is smaller than the suggested minimal dimension sample size %d, "
+                        "which might cause loss of robutness, -s %d is suggested\n", 1 << 4 * (subk - lvl > 0 ? subk - lvl : 0), 4096, lvl + 3);
+    kssd_shuf s;
+    int rc = kssd_shuf_generate(&s, k, subk, lvl, seed);
+    if (rc) die(EINVAL, "shuffle: %s", kssd_host_strerror(rc));
+    char out[KSSD_PATHLEN + 8];
+    snprintf(out, sizeof out, "%s.shuf", prefix);
+    if ((rc = kssd_shuf_write(&s, out)) != 0) die(EIO, "write_dim_shuffle_file(): open file %s failed", out);
+    printf("kssd shuffle: shuf_id=%d, k = %d, halfCtxLen = %d, level= %d\n", s.id, s.k, s.subk, s.drlevel);
+    kssd_shuf_release(&s);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * input discovery (organize_infile_frm_arg / organize_infile_list, global_basic.c:143-283)
+ * ------------------------------------------------------------------------------------------------- */
+static const char *acpt[] = {"fna", "fas", "fasta", "fq", "fastq", "fa", "co", NULL};
+static const char *fq_fmt[] = {"fq", "fastq", NULL};
+
+static int has_fmt(const char *name, const char **fmts)
+{ /* isOK_fmt_infile, global_basic.h:129-150: suffix test after stripping .gz / .bz2 */
+    char tmp[4096];
+    snprintf(tmp, sizeof tmp, "%s", name);
+    size_t L = strlen(tmp);
+    if (L > 3 && strcmp(tmp + L - 3, ".gz") == 0) tmp[L - 3] = 0;
+    else if (L > 4 && strcmp(tmp + L - 4, ".bz2") == 0) tmp[L - 4] = 0;
+    L = strlen(tmp);
+    for (int i = 0; fmts[i]; i++) {
+        size_t fl = strlen(fmts[i]);
+        if (L > fl + 1 && tmp[L - fl - 1] == '.' && strcmp(tmp + L - fl, fmts[i]) == 0) return 1;
+    }
+    return 0;
+}
+
+typedef struct {
+    char (*path)[KSSD_PATHLEN];
+    int n, cap;
+} filelist;
+
+static void fl_add(filelist *f, const char *p)
+{
+    if (strlen(p) >= KSSD_PATHLEN) die(ENAMETOOLONG, "path: %s exceed maximal path lenth %d", p, KSSD_PATHLEN);
+    if (f->n == f->cap) {
+        f->cap = f->cap ? f->cap * 2 : 1024;
+        f->path = realloc(f->path, (size_t)f->cap * KSSD_PATHLEN);
+    }
+    memset(f->path[f->n], 0, KSSD_PATHLEN);
+    strcpy(f->path[f->n++], p);
+}
+
+static int cmp_path(const void *a, const void *b) { return strcmp((const char *)a, (const char *)b); }
+
+static void collect_inputs(filelist *f, int nargs, char **args, const char *listfile)
+{
+    char full[4096];
+    if (listfile && listfile[0]) {
+        FILE *l = fopen(listfile, "r");
+        if (!l) die(errno, "can't open file %s", listfile);
+        char line[4096];
+        while (fgets(line, sizeof line, l)) {
+            char *p = line;
+            while (*p == ' ' || *p == '\t') p++;
+            p[strcspn(p, "\r\n")] = 0;
+            if (!*p) continue;
+            struct stat st;
+            if (stat(p, &st) != 0 || !S_ISREG(st.st_mode)) die(ENOENT, "%dth line: %s", f->n, p);
+            if (!has_fmt(p, acpt)) die(EINVAL, "isOK_fmt_infile(): wrong format %dth line: %s", f->n, p);
+            fl_add(f, p);
+        }
+        fclose(l);
+        return;
+    }
+    for (int i = 0; i < nargs; i++) {
+        struct stat st;
+        if (stat(args[i], &st) != 0) die(errno, "%dth argument: can't open %s", i + 1, args[i]);
+        if (S_ISDIR(st.st_mode)) {
+            DIR *d = opendir(args[i]);
+            if (!d) die(errno, "%dth argument: can't open %s", i + 1, args[i]);
+            int first = f->n;
+            struct dirent *e;
+            while ((e = readdir(d)) != NULL) {
+                snprintf(full, sizeof full, "%s/%s", args[i], e->d_name);
+                if (has_fmt(full, acpt)) fl_add(f, full);
+            }
+            closedir(d);
+            /* the reference shuffles the order with a time seed (command_dist.c:168); any order is valid,
+             * we keep it reproducible */
+            qsort(f->path + first, (size_t)(f->n - first), KSSD_PATHLEN, cmp_path);
+        } else if (has_fmt(args[i], acpt)) {
+            fl_add(f, args[i]);
+        } else {
+            die(EINVAL, "wrong format %dth argument: %s\nSupported format are: .fna .fas .fasta .fq .fastq .fa .co", i + 1, args[i]);
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * dist options (command_dist_wrapper.c:41-100)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int k, p, dr_level, kmerocrs, kmerqlty, num_neigb, metric, outfields, correction, u, keep_skf, abundance, byread;
+    double mut_dist_max;
+    char dr_file[KSSD_PATHLEN], refpath[KSSD_PATHLEN], fpath[KSSD_PATHLEN], outdir[KSSD_PATHLEN], skf[KSSD_PATHLEN],
+        pipecmd[KSSD_PATHLEN];
+    int nargs;
+    char **args;
+    int device;
+    unsigned long long seed;
+} dist_opt;
+
+static kssd_gpu_ctx *g_ctx;
+
+static void gck(int rc, const char *what)
+{
+    if (rc != KSSD_OK) die(rc == KSSD_ERR_CAPACITY ? ENOSPC : EIO, "%s: %s", what, kssd_gpu_strerror(rc));
+}
+
+/* the .shuf of this run: -L <file>, or a fresh default.shuf in the output directory (get_dim_shuffle, command_dist.c:193-216) */
+static void load_shuf(const dist_opt *o, kssd_shuf *s)
+{
+    char path[KSSD_PATHLEN + 16];
+    if (o->dr_file[0]) {
+        snprintf(path, sizeof path, "%s", o->dr_file);
+    } else {
+        int subk = o->dr_level + 3; /* add_len_drlevel2subk() == 3, command_shuffle.c:154-160 */
+        if (o->k < subk) die(EINVAL, "write_dim_shuffle_file(): half-context len: %d should larger than half-subcontext len (or dimension reduce level + 2) %d", o->k, subk);
+        if (subk >= 8) die(EINVAL, "write_dim_shuffle_file(): subk shoud smaller than 8");
+        kssd_shuf g;
+        int rc = kssd_shuf_generate(&g, o->k, subk, o->dr_level, o->seed);
+        if (rc) die(EINVAL, "shuffle: %s", kssd_host_strerror(rc));
+        mkdir(o->outdir, 0777);
+        snprintf(path, sizeof path, "%s/default.shuf", o->outdir);
+        if (kssd_shuf_write(&g, path)) die(EIO, "write_dim_shuffle_file(): open file %s failed", path);
+        printf("kssd shuffle: shuf_id=%d, k = %d, halfCtxLen = %d, level= %d\n", g.id, g.k, g.subk, g.drlevel);
+        kssd_shuf_release(&g);
+    }
+    int rc = kssd_shuf_read(s, path);
+    if (rc) die(EIO, "read_dim_shuffle_file(): %s: %s", path, kssd_host_strerror(rc));
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * stage I on the GPU (run_stageI, command_dist.c:258-380)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t *off;
+    uint32_t *ids;
+    uint64_t n_ids, cap_ids;
+    uint32_t n;
+} csr_acc;
+
+static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *acc, filelist *fl, uint32_t first_file)
+{
+    uint32_t n = kssd_batch_n_genomes(b);
+    if (!n) return;
+    uint32_t flags = is_fq ? (KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY) : (o->u ? KSSD_SKETCH_UNIQ : KSSD_SKETCH_FASTA);
+    uint64_t *off = NULL;
+    uint32_t *ids = NULL;
+    int64_t bad = -1;
+    int rc = kssd_gpu_sketch_batch(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), n, flags,
+                                   is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &bad);
+    if (rc == KSSD_ERR_CAPACITY)
+        die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
+    gck(rc, "sketch");
+    uint64_t add = off[n];
+    if (acc->n_ids + add > acc->cap_ids) {
+        acc->cap_ids = (acc->n_ids + add) * 2 + 1024;
+        acc->ids = realloc(acc->ids, acc->cap_ids * 4);
+    }
+    memcpy(acc->ids + acc->n_ids, ids, add * 4);
+    for (uint32_t g = 0; g < n; g++) acc->off[acc->n + g + 1] = acc->n_ids + off[g + 1];
+    acc->n += n;
+    acc->n_ids += add;
+    kssd_gpu_free(off);
+    kssd_gpu_free(ids);
+    kssd_batch_clear(b);
+}
+
+static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
+{
+    if (fl->n == 0) die(EINVAL, "no valid input .fas/.fq file");
+    if (o->abundance || o->byread || o->pipecmd[0])
+        die(ENOTSUP, "-A / --byread / --pipecmd are outside the GPU hot path of this build (SURVEY.md section 8f)");
+    kssd_shuf shuf;
+    load_shuf(o, &shuf);
+    kssd_derived d;
+    if (kssd_derive(&d, shuf.k, shuf.subk, shuf.drlevel))
+        die(EINVAL, "get_hashsz(): primer_ind out of range(0 ~ 24): this might caused by too small or too large k (k=%d, level=%d)", shuf.k, shuf.drlevel);
+    printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
+    kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
+    gck(kssd_gpu_create(&g_ctx, &hdr, shuf.table, o->device), "kssd_gpu_create");
+    kssd_shuf_release(&shuf);
+
+    csr_acc acc = {0};
+    acc.off = calloc((size_t)fl->n + 1, sizeof(uint64_t));
+    kssd_batch *cur = kssd_batch_create();
+    const uint64_t max_chunks = 1ull << 19; /* ~2 Gbases per device batch */
+    int threads = o->p > 0 ? o->p : 1;
+    int cur_fq = -1;
+    uint32_t first_file = 0;
+    int done = 0;
+    for (int i0 = 0; i0 < fl->n; i0 += threads) {
+        int i1 = i0 + threads < fl->n ? i0 + threads : fl->n;
+        kssd_batch **tb = calloc((size_t)(i1 - i0), sizeof(kssd_batch *));
+        int *trc = calloc((size_t)(i1 - i0), sizeof(int));
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (int i = i0; i < i1; i++) { /* gunzip + tokenise on host threads, one file each */
+            tb[i - i0] = kssd_batch_create();
+            uint64_t lines = 0;
+            int fq = has_fmt(fl->path[i], fq_fmt);
+            trc[i - i0] = kssd_batch_add_file(tb[i - i0], fl->path[i], fq, o->kmerqlty, &lines);
+            if (fq && trc[i - i0] == 0) printf("%llu reads detected\n", (unsigned long long)lines);
+        }
+        for (int i = i0; i < i1; i++) {
+            if (trc[i - i0]) die(EIO, "%s: %s", fl->path[i], kssd_host_strerror(trc[i - i0]));
+            int fq = has_fmt(fl->path[i], fq_fmt);
+            if (cur_fq != -1 && (fq != cur_fq || kssd_batch_n_chunks(cur) + kssd_batch_n_chunks(tb[i - i0]) > max_chunks)) {
+                flush_batch(cur, cur_fq, o, &acc, fl, first_file);
+                first_file = (uint32_t)i;
+            }
+            cur_fq = fq;
+            if (kssd_batch_append(cur, tb[i - i0])) die(ENOMEM, "out of memory");
+            kssd_batch_destroy(tb[i - i0]);
+            printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i]);
+        }
+        free(tb);
+        free(trc);
+    }
+    if (cur_fq != -1) flush_batch(cur, cur_fq, o, &acc, fl, first_file);
+    printf("\n");
+    kssd_batch_destroy(cur);
+
+    kssd_sketchset s = {0};
+    s.shuf_id = (uint32_t)hdr.id;
+    s.kmerlen = d.kmerlen;
+    s.dim_rd_len = d.dim_rd_len;
+    s.comp_num = d.comp_num;
+    s.n = (uint32_t)fl->n;
+    s.off = acc.off;
+    s.ids = acc.ids ? acc.ids : calloc(1, 4);
+    s.names = fl->path;
+    int rc = kssd_sketchset_write(&s, outdir, d.hashsize, 1);
+    if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
+    free(acc.off);
+    free(s.ids);
+    kssd_gpu_destroy(g_ctx);
+    g_ctx = NULL;
+}
+
+/* stage II (run_stageII, command_dist.c:381-417): the index FILES are for the reference binary; our own search
+ * builds its index on the device straight from the sketches */
+static void build_index_files(const char *codir, const char *mcodir)
+{
+    kssd_sketchset s;
+    int rc = kssd_sketchset_read(&s, codir);
+    if (rc) die(EIO, "run_stageII(): %s: %s", codir, kssd_host_strerror(rc));
+    struct stat st;
+    if (stat(mcodir, &st) == 0) printf("Warning: write mco file to an exists outdir:%s\n", mcodir);
+    if ((rc = kssd_index_write(&s, mcodir)) != 0) die(EIO, "combco2mco(): %s: %s", mcodir, kssd_host_strerror(rc));
+    kssd_sketchset_release(&s);
+}
+
+/* search (mco_cbdco_nobin_dist + dist_print_nobin, command_dist.c:670-808,1161-1250) */
+static void search(const dist_opt *o, const char *refdir, const char *qrydir)
+{
+    kssd_sketchset ref, qry;
+    int rc;
+    if (kssd_probe_dir(refdir) & 1) rc = kssd_sketchset_read(&ref, refdir);
+    else rc = kssd_index_read(&ref, refdir);
+    if (rc) die(EIO, "need provied mco dir path: %s: %s", refdir, kssd_host_strerror(rc));
+    if ((rc = kssd_sketchset_read(&qry, qrydir)) != 0) die(EIO, "need provied co dir path: %s: %s", qrydir, kssd_host_strerror(rc));
+    if (ref.comp_num != qry.comp_num)
+        die(EINVAL, "query args not match ref args: ref.comp_num = %d vs. %d = qry.comp_num", ref.comp_num, qry.comp_num);
+    if (ref.shuf_id != qry.shuf_id)
+        die(EINVAL, "query args not match ref args: ref.shuf_id = %d vs. %d = qry.shuf_id", (int)ref.shuf_id, (int)qry.shuf_id);
+    mkdir(o->outdir, 0700);
+    char skf[KSSD_PATHLEN + 32], distf[KSSD_PATHLEN + 32];
+    snprintf(skf, sizeof skf, "%s/sharedk_ct.dat", o->outdir);
+    snprintf(distf, sizeof distf, "%s/distance.out", o->outdir);
+    const size_t cells = (size_t)ref.n * qry.n;
+    uint32_t *shared = malloc((cells ? cells : 1) * 4);
+    if (!shared) die(ENOMEM, "out of memory for %zu pairs", cells);
+    if (o->skf[0]) { /* -f: reuse a kept shared-k-mer file (command_dist.c:735-738) */
+        FILE *f = fopen(o->skf, "rb");
+        if (!f || fread(shared, 4, cells, f) != cells) die(EIO, "open %s failed", o->skf);
+        fclose(f);
+    } else {
+        if (access(skf, F_OK) == 0) die(EEXIST, " mco_cbdco_nobin_dist():%s", skf); /* the reference refuses to overwrite */
+        printf("disf_sz=%zu\trefnum=%u\tqrynum=%u\n", cells * 4, ref.n, qry.n);
+        gck(kssd_gpu_create_for_dist(&g_ctx, qry.kmerlen, o->device), "kssd_gpu_create_for_dist");
+        gck(kssd_gpu_dist(g_ctx, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
+        kssd_gpu_destroy(g_ctx);
+        g_ctx = NULL;
+        FILE *f = fopen(skf, "wb");
+        if (!f || fwrite(shared, 4, cells, f) != cells) die(EIO, "mco_cbdco_nobin_dist()::%s", skf);
+        fclose(f);
+    }
+    kssd_print_opt po = {o->metric, o->outfields, o->correction, o->mut_dist_max, o->num_neigb, o->p};
+    if ((rc = kssd_distance_print(distf, shared, &ref, &qry, &po)) != 0)
+        die(rc == KSSD_HOST_ERR_PARAM ? EINVAL : EIO, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, ref.n);
+    if (!o->keep_skf && !o->skf[0]) remove(skf);
+    free(shared);
+    kssd_sketchset_release(&ref);
+    kssd_sketchset_release(&qry);
+}
+
+static int cmd_dist(int argc, char **argv)
+{
+    dist_opt o;
+    memset(&o, 0, sizeof o);
+    o.k = 8; o.dr_level = 2; o.kmerocrs = 1; o.mut_dist_max = 1; o.outfields = 2;
+    strcpy(o.outdir, ".");
+    o.device = getenv("KSSD_DEVICE") ? atoi(getenv("KSSD_DEVICE")) : 0;
+    static struct option lo[] = {
+        {"halfKmerlength", 1, 0, 'k'}, {"threadN", 1, 0, 'p'},      {"list", 1, 0, 'l'},       {"DimRdcLevel", 1, 0, 'L'},
+        {"maxMemory", 1, 0, 'm'},      {"LstKmerOcrs", 1, 0, 'n'},  {"quality", 1, 0, 'Q'},    {"reference_dir", 1, 0, 'r'},
+        {"outdir", 1, 0, 'o'},         {"neighborN_max", 1, 0, 'N'}, {"mutDist_max", 1, 0, 'D'}, {"metric", 1, 0, 'M'},
+        {"outfields", 1, 0, 'O'},      {"correction", 1, 0, 333},   {"abundance", 0, 0, 'A'},  {"dedup", 0, 0, 'u'},
+        {"keepcofile", 0, 0, 888},     {"pipecmd", 1, 0, 'P'},      {"keepskf", 0, 0, 777},    {"skf", 1, 0, 'f'},
+        {"byread", 0, 0, 555},         {"seed", 1, 0, 998},         {0, 0, 0, 0}};
+    if (argc < 2) die(EINVAL, "usage: kssd dist [-L <.shuf|level>] [-k K] [-r <reference>] [-o <outdir>] [<query> ...]");
+    int c;
+    while ((c = getopt_long(argc, argv, "k:p:l:L:m:n:Q:r:o:N:D:M:O:AuP:f:", lo, NULL)) != -1) {
+        switch (c) {
+        case 'k': o.k = atoi(optarg); break;
+        case 'p': o.p = atoi(optarg); break;
+        case 'l': snprintf(o.fpath, sizeof o.fpath, "%s", optarg); break;
+        case 'L': {
+            struct stat st;
+            if (stat(optarg, &st) == 0 && S_ISREG(st.st_mode)) snprintf(o.dr_file, sizeof o.dr_file, "%s", optarg);
+            else {
+                if (atoi(optarg) >= o.k - 2 || atoi(optarg) < 0)
+                    die(EINVAL, "-L: dimension reduction level should never larger than Kmer length - 2, which is %d here", o.k - 2);
+                o.dr_level = atoi(optarg);
+            }
+            break;
+        }
+        case 'm': break; /* memory budgeting of the CPU hash tables: nothing to budget here */
+        case 'n': o.kmerocrs = atoi(optarg) > 7 ? 7 : atoi(optarg) < 1 ? 1 : atoi(optarg); break;
+        case 'Q': o.kmerqlty = atoi(optarg); break;
+        case 'r': snprintf(o.refpath, sizeof o.refpath, "%s", optarg); break;
+        case 'o': snprintf(o.outdir, sizeof o.outdir, "%s", optarg); break;
+        case 'N': o.num_neigb = atoi(optarg); break;
+        case 'D': o.mut_dist_max = atof(optarg); break;
+        case 'M': o.metric = atoi(optarg) ? 1 : 0; break;
+        case 'O': o.outfields = atoi(optarg) < 0 ? 0 : atoi(optarg) > 2 ? 2 : atoi(optarg); break;
+        case 333: o.correction = atoi(optarg); break;
+        case 'A': o.abundance = 1; break;
+        case 'u': o.u = 1; break;
+        case 888: break;
+        case 'P': snprintf(o.pipecmd, sizeof o.pipecmd, "%s", optarg); break;
+        case 777: o.keep_skf = 1; break;
+        case 'f': snprintf(o.skf, sizeof o.skf, "%s", optarg); break;
+        case 555: o.byread = 1; break;
+        case 998: o.seed = strtoull(optarg, NULL, 10); break;
+        default: die(EINVAL, "dist: unknown option");
+        }
+    }
+    if (o.p == 0) {
+#ifdef _OPENMP
+        o.p = omp_get_num_procs();
+#else
+        o.p = 1;
+#endif
+    }
+    o.nargs = argc - optind;
+    o.args = argv + optind;
+
+    /* dist_dispatch (command_dist.c:53-192) */
+    if (o.refpath[0]) {
+        int probe = kssd_probe_dir(o.refpath);
+        if (probe == 0) { /* raw sequences as reference: sketch and index them into -o */
+            filelist fl = {0};
+            struct stat st;
+            if (stat(o.refpath, &st) != 0) die(errno, "dist_organize_refpath():%s", o.refpath);
+            char *one[1] = {o.refpath};
+            if (S_ISDIR(st.st_mode) || has_fmt(o.refpath, acpt)) collect_inputs(&fl, 1, one, NULL);
+            else collect_inputs(&fl, 0, NULL, o.refpath);
+            sketch_files(&o, &fl, o.outdir);
+            build_index_files(o.outdir, o.outdir);
+        }
+        /* probe == 1 (sketches without mco.*): the reference would run stage II here (command_dist.c:100-103) only
+         * because its search needs the 2 GiB offset file; the device index is built from the sketches, so nothing
+         * has to be written.  `kssd dist -o <dir> <dir>` still writes mco.* for the reference binary. */
+    }
+    if (o.nargs > 0 || o.fpath[0]) {
+        int qprobe = (o.nargs > 0 && !o.pipecmd[0]) ? kssd_probe_dir(o.args[0]) : 0;
+        if (o.refpath[0]) {
+            if (!kssd_probe_dir(o.refpath)) die(EINVAL, "need speficy the ref-sketch path for -r to run the query-ref search model");
+            if (qprobe & 1) search(&o, o.refpath, o.args[0]);
+            else if (qprobe & 2) die(EINVAL, "when -r specified, the query sould not be .mco format, the valid query format shoulde be .fas/.fq file or .co");
+            else die(EINVAL, "please sketch the query sequences first (kssd dist -L <.shuf> -o <qrydir> <seqs>), then search with -r");
+        } else if (qprobe & 1) {
+            if (o.nargs == 1) build_index_files(o.args[0], o.outdir);
+            else die(ENOTSUP, "combining several sketch directories is outside the GPU hot path of this build (SURVEY.md section 8f)");
+        } else {
+            filelist fl = {0};
+            collect_inputs(&fl, o.nargs, o.args, o.fpath);
+            sketch_files(&o, &fl, o.outdir);
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    setvbuf(stdout, NULL, _IOLBF, 0);
+    if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
+        printf("%s\n\nUsage: kssd <subcommand> [OPTION...] [arguments ...]\nSupported subcommands are:\n\n"
+               "  shuffle\tshuffle/sampling k-mer substring space.\n\n  dist   \tsequences sketching and distance estimation.\n",
+               VERSION);
+        return argc < 2;
+    }
+    if (!strcmp(argv[1], "--version") || !strcmp(argv[1], "-V")) { printf("%s\n", VERSION); return 0; }
+    if (!strcmp(argv[1], "shuffle")) return cmd_shuffle(argc - 1, argv + 1);
+    if (!strcmp(argv[1], "dist")) return cmd_dist(argc - 1, argv + 1);
+    die(EINVAL, "%s is not a valid subcommand (this build implements: shuffle, dist)", argv[1]);
+    return 1;
+}

@@ -1,0 +1,495 @@
+/*
+ * kssd_formats.c -- the reference's on-disk formats and its distance report.
+ * Everything here is host C on purpose: these files are the interoperability contract with the reference
+ * binary, and the report uses the host libm so that its text is the reference's text.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <fcntl.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "kssd_host.h"
+
+#define COMPONENT_SZ 7      /* reference Makefile:4 */
+#define CTX_SPC_USE_L 8     /* global_basic.h:45-47 */
+#define LD_FCTR 0.6         /* global_basic.h:49 */
+
+/* hash-table sizes of the reference (global_basic.c:74-81): they fix the capacity rule and the dump order */
+static const uint32_t primes[25] = {251u, 509u, 1021u, 2039u, 4093u, 8191u, 16381u, 32749u, 65521u, 131071u,
+                                    262139u, 524287u, 1048573u, 2097143u, 4194301u, 8388593u, 16777213u,
+                                    33554393u, 67108859u, 134217689u, 268435399u, 536870909u, 1073741789u,
+                                    2147483647u, 4294967291u};
+
+int kssd_derive(kssd_derived *d, int k, int subk, int drlevel)
+{
+    memset(d, 0, sizeof *d);
+    if (k < subk || subk >= 8 || subk < 1 || drlevel < 0 || k > 15) return KSSD_HOST_ERR_PARAM;
+    int pidx = 4 * (k - drlevel) - CTX_SPC_USE_L - 7;
+    if (pidx < 0 || pidx > 24) return KSSD_HOST_ERR_PARAM;
+    d->k = k;
+    d->subk = subk;
+    d->drlevel = drlevel;
+    d->kmerlen = 2 * k;
+    d->dim_rd_len = 2 * drlevel;
+    int extra = k - drlevel - COMPONENT_SZ;
+    d->comp_bits = extra > 0 ? 4 * extra : 0;
+    d->comp_num = extra > 0 ? 1 << d->comp_bits : 1;
+    d->hashsize = primes[pidx];
+    d->hashlimit = (uint32_t)(d->hashsize * LD_FCTR);
+    return KSSD_HOST_OK;
+}
+
+void kssd_sketchset_release(kssd_sketchset *s)
+{
+    if (!s) return;
+    free(s->off);
+    free(s->ids);
+    free(s->names);
+    memset(s, 0, sizeof *s);
+}
+
+/* ---- slot order ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t slot, id;
+} slot_id;
+
+static int cmp_slot(const void *a, const void *b)
+{
+    uint32_t x = ((const slot_id *)a)->slot, y = ((const slot_id *)b)->slot;
+    return x < y ? -1 : x > y;
+}
+
+void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
+{
+    if (n < 2) return;
+    /* replay the reference's insertions (ascending id order) into a sparse image of its table */
+    uint64_t cap = 16;
+    while (cap < 4 * n) cap <<= 1;
+    uint32_t *occ = malloc(cap * sizeof(uint32_t)); /* open-addressing set of occupied slots, 0xFFFFFFFF = free */
+    slot_id *sl = malloc(n * sizeof(slot_id));
+    if (!occ || !sl) { free(occ); free(sl); return; }
+    memset(occ, 0xFF, cap * sizeof(uint32_t));
+    const uint64_t S = hashsize;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t key = ids[i];
+        const uint64_t h1 = key % S, h2 = 1 + key % (S - 1);
+        for (uint64_t t = 0;; t++) {
+            uint32_t slot = (uint32_t)((h1 + t * h2) % S);
+            uint64_t p = ((uint64_t)slot * 0x9E3779B97F4A7C15ull) >> 32 & (cap - 1);
+            int taken = 0;
+            while (occ[p] != 0xFFFFFFFFu) {
+                if (occ[p] == slot) { taken = 1; break; }
+                p = (p + 1) & (cap - 1);
+            }
+            if (!taken) {
+                occ[p] = slot;
+                sl[i].slot = slot;
+                sl[i].id = ids[i];
+                break;
+            }
+        }
+    }
+    qsort(sl, n, sizeof(slot_id), cmp_slot);
+    for (uint64_t i = 0; i < n; i++) ids[i] = sl[i].id;
+    free(occ);
+    free(sl);
+}
+
+/* ---- stat files ---------------------------------------------------------------------------------------- */
+static int write_stat(const kssd_sketchset *s, const char *dir, int mco)
+{
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s", dir, mco ? "mcofiles.stat" : "cofiles.stat");
+    FILE *f = fopen(path, "wb");
+    if (!f) return KSSD_HOST_ERR_IO;
+    uint64_t total = s->off[s->n];
+    if (mco) { /* mco_dstat_t, command_dist.h:57-64 */
+        int32_t h[5] = {(int32_t)s->shuf_id, s->kmerlen, s->dim_rd_len, s->comp_num, (int32_t)s->n};
+        fwrite(h, sizeof h, 1, f);
+    } else { /* co_dstat_t, global_basic.h:94-103: 32 bytes with the bool padded to 4 */
+        unsigned char h[32];
+        memset(h, 0, sizeof h);
+        memcpy(h + 0, &s->shuf_id, 4);
+        h[4] = (unsigned char)(s->koc != 0);
+        int32_t v[4] = {s->kmerlen, s->dim_rd_len, s->comp_num, (int32_t)s->n};
+        memcpy(h + 8, v, 16);
+        memcpy(h + 24, &total, 8);
+        fwrite(h, sizeof h, 1, f);
+    }
+    for (uint32_t g = 0; g < s->n; g++) {
+        uint32_t sz = (uint32_t)(s->off[g + 1] - s->off[g]);
+        fwrite(&sz, 4, 1, f);
+    }
+    fwrite(s->names, KSSD_PATHLEN, s->n, f);
+    return fclose(f) == 0 ? KSSD_HOST_OK : KSSD_HOST_ERR_IO;
+}
+
+static int read_stat(kssd_sketchset *s, const char *dir, int mco, uint32_t **sizes)
+{
+    char path[4096];
+    snprintf(path, sizeof path, "%s/%s", dir, mco ? "mcofiles.stat" : "cofiles.stat");
+    FILE *f = fopen(path, "rb");
+    if (!f) return KSSD_HOST_ERR_IO;
+    memset(s, 0, sizeof *s);
+    int ok = 1;
+    if (mco) {
+        int32_t h[5];
+        ok = fread(h, sizeof h, 1, f) == 1;
+        s->shuf_id = (uint32_t)h[0]; s->kmerlen = h[1]; s->dim_rd_len = h[2]; s->comp_num = h[3]; s->n = (uint32_t)h[4];
+    } else {
+        unsigned char h[32];
+        ok = fread(h, sizeof h, 1, f) == 1;
+        int32_t v[4];
+        memcpy(&s->shuf_id, h, 4);
+        s->koc = h[4];
+        memcpy(v, h + 8, 16);
+        s->kmerlen = v[0]; s->dim_rd_len = v[1]; s->comp_num = v[2]; s->n = (uint32_t)v[3];
+    }
+    if (!ok || s->comp_num < 1 || s->comp_num > 65536) { fclose(f); return KSSD_HOST_ERR_FORMAT; }
+    *sizes = malloc(((size_t)s->n + 1) * 4);
+    s->names = malloc(((size_t)s->n + 1) * KSSD_PATHLEN);
+    if (!*sizes || !s->names) { fclose(f); return KSSD_HOST_ERR_NOMEM; }
+    ok = fread(*sizes, 4, s->n, f) == s->n && fread(s->names, KSSD_PATHLEN, s->n, f) == s->n;
+    fclose(f);
+    return ok ? KSSD_HOST_OK : KSSD_HOST_ERR_FORMAT;
+}
+
+int kssd_probe_dir(const char *dir)
+{
+    char p[4096];
+    struct stat st;
+    int r = 0;
+    if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return 0;
+    snprintf(p, sizeof p, "%s/cofiles.stat", dir);
+    if (access(p, R_OK) == 0) r |= 1;
+    snprintf(p, sizeof p, "%s/mcofiles.stat", dir);
+    if (access(p, R_OK) == 0) r |= 2;
+    return r;
+}
+
+/* ---- sketch container ---------------------------------------------------------------------------------- */
+static int comp_bits_of(int comp_num)
+{
+    int b = 0;
+    while ((1 << b) < comp_num) b++;
+    return b;
+}
+
+int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hashsize, int slot_order)
+{
+    mkdir(dir, 0777);
+    if (slot_order)
+        for (uint32_t g = 0; g < s->n; g++) kssd_slot_order(s->ids + s->off[g], s->off[g + 1] - s->off[g], hashsize);
+    const int cb = comp_bits_of(s->comp_num);
+    const uint32_t cmask = (uint32_t)s->comp_num - 1u;
+    char path[4096];
+    uint64_t *idx = malloc(((size_t)s->n + 1) * sizeof(uint64_t));
+    if (!idx) return KSSD_HOST_ERR_NOMEM;
+    for (int c = 0; c < s->comp_num; c++) { /* command_dist.c:314-357 */
+        snprintf(path, sizeof path, "%s/combco.%d", dir, c);
+        FILE *f = fopen(path, "wb");
+        if (!f) { free(idx); return KSSD_HOST_ERR_IO; }
+        uint64_t run = 0;
+        idx[0] = 0;
+        for (uint32_t g = 0; g < s->n; g++) {
+            if (s->comp_num == 1) {
+                uint64_t cnt = s->off[g + 1] - s->off[g];
+                fwrite(s->ids + s->off[g], 4, cnt, f);
+                run += cnt;
+            } else {
+                for (uint64_t i = s->off[g]; i < s->off[g + 1]; i++)
+                    if ((s->ids[i] & cmask) == (uint32_t)c) { /* drtuple % component_num, iseq2comem.c:543 */
+                        uint32_t id = s->ids[i] >> cb;
+                        fwrite(&id, 4, 1, f);
+                        run++;
+                    }
+            }
+            idx[g + 1] = run;
+        }
+        if (fclose(f) != 0) { free(idx); return KSSD_HOST_ERR_IO; }
+        snprintf(path, sizeof path, "%s/combco.index.%d", dir, c);
+        f = fopen(path, "wb");
+        if (!f) { free(idx); return KSSD_HOST_ERR_IO; }
+        fwrite(idx, sizeof(uint64_t), (size_t)s->n + 1, f);
+        if (fclose(f) != 0) { free(idx); return KSSD_HOST_ERR_IO; }
+    }
+    free(idx);
+    return write_stat(s, dir, 0);
+}
+
+static void *slurp_file(const char *path, size_t *len)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    void *p = malloc((size_t)(n > 0 ? n : 1));
+    if (p && n > 0 && fread(p, 1, (size_t)n, f) != (size_t)n) { free(p); p = NULL; }
+    fclose(f);
+    *len = (size_t)(n > 0 ? n : 0);
+    return p;
+}
+
+int kssd_sketchset_read(kssd_sketchset *s, const char *dir)
+{
+    uint32_t *sizes = NULL;
+    int rc = read_stat(s, dir, 0, &sizes);
+    if (rc) { free(sizes); kssd_sketchset_release(s); return rc; }
+    s->off = malloc(((size_t)s->n + 1) * sizeof(uint64_t));
+    if (!s->off) { free(sizes); kssd_sketchset_release(s); return KSSD_HOST_ERR_NOMEM; }
+    s->off[0] = 0;
+    for (uint32_t g = 0; g < s->n; g++) s->off[g + 1] = s->off[g] + sizes[g];
+    free(sizes);
+    s->ids = malloc((size_t)(s->off[s->n] ? s->off[s->n] : 1) * 4);
+    uint64_t *fill = calloc((size_t)s->n + 1, sizeof(uint64_t));
+    if (!s->ids || !fill) { free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_NOMEM; }
+    const int cb = comp_bits_of(s->comp_num);
+    char path[4096];
+    for (int c = 0; c < s->comp_num; c++) {
+        size_t li = 0, lc = 0;
+        snprintf(path, sizeof path, "%s/combco.index.%d", dir, c);
+        uint64_t *idx = slurp_file(path, &li);
+        snprintf(path, sizeof path, "%s/combco.%d", dir, c);
+        uint32_t *co = slurp_file(path, &lc);
+        if (!idx || !co || li != ((size_t)s->n + 1) * 8 || lc != (size_t)idx[s->n] * 4) {
+            free(idx); free(co); free(fill); kssd_sketchset_release(s);
+            return KSSD_HOST_ERR_FORMAT;
+        }
+        for (uint32_t g = 0; g < s->n; g++)
+            for (uint64_t i = idx[g]; i < idx[g + 1]; i++) {
+                uint64_t w = s->off[g] + fill[g]++;
+                if (w >= s->off[g + 1]) { free(idx); free(co); free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_FORMAT; }
+                s->ids[w] = (co[i] << cb) | (uint32_t)c;
+            }
+        free(idx);
+        free(co);
+    }
+    free(fill);
+    return KSSD_HOST_OK;
+}
+
+/* ---- inverted index files ---------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t id, gid;
+} id_gid;
+
+static int cmp_id_gid(const void *a, const void *b)
+{
+    const id_gid *x = a, *y = b;
+    if (x->id != y->id) return x->id < y->id ? -1 : 1;
+    return x->gid < y->gid ? -1 : x->gid > y->gid;
+}
+
+int kssd_index_write(const kssd_sketchset *s, const char *dir)
+{
+    mkdir(dir, 0777);
+    const int cb = comp_bits_of(s->comp_num);
+    const uint32_t cmask = (uint32_t)s->comp_num - 1u;
+    const uint64_t comp_sz = 1ull << (4 * COMPONENT_SZ);
+    const uint64_t total = s->off[s->n];
+    id_gid *pairs = malloc((size_t)(total ? total : 1) * sizeof(id_gid));
+    const size_t BLK = 1u << 20;
+    uint64_t *blk = malloc(BLK * sizeof(uint64_t));
+    if (!pairs || !blk) { free(pairs); free(blk); return KSSD_HOST_ERR_NOMEM; }
+    char path[4096];
+    int rc = KSSD_HOST_OK;
+    for (int c = 0; c < s->comp_num && rc == KSSD_HOST_OK; c++) {
+        uint64_t np = 0;
+        for (uint32_t g = 0; g < s->n; g++)
+            for (uint64_t i = s->off[g]; i < s->off[g + 1]; i++)
+                if ((s->ids[i] & cmask) == (uint32_t)c) {
+                    pairs[np].id = s->ids[i] >> cb;
+                    pairs[np].gid = g;
+                    np++;
+                }
+        qsort(pairs, np, sizeof(id_gid), cmp_id_gid);
+        /* mco.index.<c>: inclusive prefix sums of the posting lengths over the whole 16^7 id space (co2mco.c:57-62) */
+        snprintf(path, sizeof path, "%s/mco.index.%d", dir, c);
+        FILE *f = fopen(path, "wb");
+        if (!f) { rc = KSSD_HOST_ERR_IO; break; }
+        uint64_t p = 0;
+        for (uint64_t base = 0; base < comp_sz; base += BLK) {
+            for (size_t j = 0; j < BLK; j++) {
+                const uint64_t id = base + j;
+                while (p < np && pairs[p].id <= id) p++;
+                blk[j] = p;
+            }
+            if (fwrite(blk, sizeof(uint64_t), BLK, f) != BLK) { rc = KSSD_HOST_ERR_IO; break; }
+        }
+        if (fclose(f) != 0) rc = KSSD_HOST_ERR_IO;
+        if (rc) break;
+        /* mco.<c>: the postings, ascending genome index inside each (co2mco.c:63-72) */
+        snprintf(path, sizeof path, "%s/mco.%d", dir, c);
+        f = fopen(path, "wb");
+        if (!f) { rc = KSSD_HOST_ERR_IO; break; }
+        for (uint64_t i = 0; i < np; i++) fwrite(&pairs[i].gid, 4, 1, f);
+        if (fclose(f) != 0) rc = KSSD_HOST_ERR_IO;
+    }
+    free(pairs);
+    free(blk);
+    if (rc) return rc;
+    return write_stat(s, dir, 1);
+}
+
+int kssd_index_read(kssd_sketchset *s, const char *dir)
+{
+    uint32_t *sizes = NULL;
+    int rc = read_stat(s, dir, 1, &sizes);
+    if (rc) { free(sizes); kssd_sketchset_release(s); return rc; }
+    s->off = malloc(((size_t)s->n + 1) * sizeof(uint64_t));
+    s->off[0] = 0;
+    for (uint32_t g = 0; g < s->n; g++) s->off[g + 1] = s->off[g] + sizes[g];
+    free(sizes);
+    s->ids = malloc((size_t)(s->off[s->n] ? s->off[s->n] : 1) * 4);
+    uint64_t *fill = calloc((size_t)s->n + 1, sizeof(uint64_t));
+    const int cb = comp_bits_of(s->comp_num);
+    const uint64_t comp_sz = 1ull << (4 * COMPONENT_SZ);
+    char path[4096];
+    for (int c = 0; c < s->comp_num; c++) {
+        snprintf(path, sizeof path, "%s/mco.index.%d", dir, c);
+        int fd = open(path, O_RDONLY);
+        if (fd < 0) { free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_IO; }
+        struct stat st;
+        fstat(fd, &st);
+        if ((uint64_t)st.st_size != comp_sz * 8) { close(fd); free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_FORMAT; }
+        const uint64_t *idx = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        size_t lp = 0;
+        snprintf(path, sizeof path, "%s/mco.%d", dir, c);
+        uint32_t *post = slurp_file(path, &lp);
+        if (idx == MAP_FAILED || !post) { free(post); free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_IO; }
+        uint64_t prev = 0;
+        for (uint64_t id = 0; id < comp_sz; id++) {
+            const uint64_t end = idx[id];
+            for (uint64_t p = prev; p < end && p * 4 < lp; p++) {
+                const uint32_t g = post[p];
+                if (g < s->n && s->off[g] + fill[g] < s->off[g + 1]) s->ids[s->off[g] + fill[g]++] = ((uint32_t)id << cb) | (uint32_t)c;
+            }
+            prev = end;
+        }
+        munmap((void *)idx, (size_t)st.st_size);
+        free(post);
+    }
+    free(fill);
+    return KSSD_HOST_OK;
+}
+
+/* ---- distance report ------------------------------------------------------------------------------------ */
+static inline double dist_arg(int metric, double m) { return metric == 0 ? 1 / (2 * m) + 0.5 : 1 / m; }
+
+/* one line of distance.out, the arithmetic and the formats of output_ctrl (command_dist.c:1251-1287) */
+static int format_line(char *buf, size_t cap, const char *qn, const char *rn, uint32_t X, uint32_t Y, uint32_t s,
+                       int kmerlen, int dim_rd_len, const kssd_print_opt *o, uint64_t cmprsn)
+{
+    double rs = 0;
+    if (o->correction) {
+        uint32_t xo = X - s, yo = Y - s;
+        double miss = 1 - 1 / pow((double)4, (double)(kmerlen - dim_rd_len));
+        double px = 1 - pow(miss, (double)xo), py = 1 - pow(miss, (double)yo);
+        rs = px * py * (uint32_t)(xo + yo) / (px + py - 2 * px * py);
+    }
+    uint32_t den = o->metric == 0 ? X + Y - s : (X < Y ? X : Y);
+    double m = ((double)s - rs) / den;
+    double d = log(dist_arg(o->metric, m)) / kmerlen;
+    if (d > 1) d = 1;
+    if (d > o->dthreshold) return 0;
+    int len = snprintf(buf, cap, "%s\t%s\t%u-%u|%u|%u\t%.6lf\t%.6lf", qn, rn, s, (uint32_t)rs, X, Y, m, d);
+    if (o->pfield > 0) {
+        double sd = pow(m * (1 - m) / den, 0.5);
+        double pv = 0.5 * erfc(m / sd * pow(0.5, 0.5));
+        len += snprintf(buf + len, cap - (size_t)len, "\t%E\t%E", pv, pv * cmprsn);
+        if (o->pfield > 1) {
+            double m1 = m - 1.96 * sd, m2 = m + 1.96 * sd;
+            double d1 = log(dist_arg(o->metric, m2)) / kmerlen, d2 = log(dist_arg(o->metric, m1)) / kmerlen;
+            len += snprintf(buf + len, cap - (size_t)len, "\t[%.6lf,%.6lf]\t[%.6lf,%.6lf]", m1, m2, d1, d2);
+        }
+    }
+    len += snprintf(buf + len, cap - (size_t)len, "\n");
+    return len;
+}
+
+typedef struct {
+    char *p;
+    size_t n, cap;
+} strbuf;
+
+static void sb_add(strbuf *b, const char *s, size_t n)
+{
+    if (b->n + n > b->cap) {
+        size_t nc = b->cap ? b->cap * 2 : 1 << 16;
+        while (nc < b->n + n) nc *= 2;
+        b->p = realloc(b->p, nc);
+        b->cap = nc;
+    }
+    memcpy(b->p + b->n, s, n);
+    b->n += n;
+}
+
+int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_sketchset *ref, const kssd_sketchset *qry,
+                        const kssd_print_opt *o)
+{
+    static const char *cols[2][3] = {{"Jaccard\tMashD", "P-value(J)\tFDR(J)", "Jaccard_CI\tMashD_CI"},
+                                     {"ContainmentM\tAafD", "P-value(C)\tFDR(C)", "ContainmentM_CI\tAafD_CI"}};
+    const uint32_t R = ref->n, Q = qry->n;
+    if (o->n_max > 1024 || (uint32_t)o->n_max > R) return KSSD_HOST_ERR_PARAM; /* command_dist.c:1198 */
+    FILE *f = fopen(path, "w");
+    if (!f) return KSSD_HOST_ERR_IO;
+    fprintf(f, "Qry\tRef\tShared_k|Ref_s|Qry_s");
+    for (int i = 0; i <= o->pfield; i++) fprintf(f, "\t%s", cols[o->metric][i]);
+    fprintf(f, "\n");
+    const uint64_t cmprsn = (uint32_t)(R * Q); /* 32-bit product like command_dist.c:1186 */
+    const int kmerlen = qry->kmerlen, drl = qry->dim_rd_len;
+    int threads = o->threads > 0 ? o->threads : 1;
+    const uint32_t QB = 64; /* queries formatted per parallel batch, written back in order */
+    strbuf *sb = calloc(QB, sizeof(strbuf));
+    for (uint32_t q0 = 0; q0 < Q; q0 += QB) {
+        const uint32_t q1 = q0 + QB < Q ? q0 + QB : Q;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (uint32_t q = q0; q < q1; q++) {
+            strbuf *b = &sb[q - q0];
+            b->n = 0;
+            char line[1024];
+            const uint32_t *row = shared + (size_t)q * R;
+            const uint32_t Y = (uint32_t)(qry->off[q + 1] - qry->off[q]);
+            if (o->n_max) { /* -N: the n_max largest raw metrics, earlier reference wins ties (:1212-1227) */
+                double bm[1026];
+                int bi[1026];
+                for (int i = 0; i < o->n_max; i++) { bm[i] = 0; bi[i] = -1; }
+                for (uint32_t r = 0; r < R; r++) {
+                    const uint32_t X = (uint32_t)(ref->off[r + 1] - ref->off[r]), s = row[r];
+                    const double m = o->metric == 1 ? (double)s / (X < Y ? X : Y) : (double)s / (X + Y - s);
+                    for (int i = o->n_max - 1; i >= 0; i--) {
+                        if (m > bm[i]) { bm[i + 1] = bm[i]; bi[i + 1] = bi[i]; bm[i] = m; bi[i] = (int)r; }
+                        else break;
+                    }
+                }
+                for (int i = 0; i < o->n_max; i++) {
+                    if (bi[i] < 0) continue;
+                    const uint32_t r = (uint32_t)bi[i];
+                    int len = format_line(line, sizeof line, qry->names[q], ref->names[r],
+                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, row[r], kmerlen, drl, o, cmprsn);
+                    if (len > 1) sb_add(b, line, (size_t)len);
+                }
+            } else {
+                for (uint32_t r = 0; r < R; r++) {
+                    int len = format_line(line, sizeof line, qry->names[q], ref->names[r],
+                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, row[r], kmerlen, drl, o, cmprsn);
+                    if (len > 1) sb_add(b, line, (size_t)len);
+                }
+            }
+        }
+        for (uint32_t q = q0; q < q1; q++) fwrite(sb[q - q0].p, 1, sb[q - q0].n, f);
+    }
+    for (uint32_t i = 0; i < QB; i++) free(sb[i].p);
+    free(sb);
+    return fclose(f) == 0 ? KSSD_HOST_OK : KSSD_HOST_ERR_IO;
+}

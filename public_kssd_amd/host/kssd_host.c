@@ -440,3 +440,22 @@ const uint64_t *kssd_batch_chunk_off(const kssd_batch *b) { return b->chunk_off;
 uint64_t kssd_batch_n_chunks(const kssd_batch *b) { return b->n_chunks; }
 uint32_t kssd_batch_n_genomes(const kssd_batch *b) { return b->n_genomes; }
 uint64_t kssd_batch_n_positions(const kssd_batch *b, uint32_t g) { return g < b->n_genomes ? b->n_pos[g] : 0; }
+
+int kssd_batch_append(kssd_batch *dst, const kssd_batch *src)
+{
+    for (uint32_t g = 0; g < src->n_genomes; g++) {
+        int rc = batch_begin(dst);
+        if (rc) return rc;
+        const uint64_t c0 = src->chunk_off[g], nc = src->chunk_off[g + 1] - c0;
+        if ((rc = batch_reserve_chunks(dst, dst->n_chunks + nc + 1)) != 0) return rc;
+        if (nc) {
+            memcpy(dst->packed + dst->n_chunks * CHUNK_WORDS, src->packed + c0 * CHUNK_WORDS, (size_t)nc * CHUNK_WORDS * 4);
+            memcpy(dst->mask + dst->n_chunks * CHUNK_MASKW, src->mask + c0 * CHUNK_MASKW, (size_t)nc * CHUNK_MASKW * 4);
+        }
+        dst->n_pos[dst->n_genomes] = src->n_pos[g];
+        dst->n_chunks += nc;
+        dst->n_genomes++;
+        dst->chunk_off[dst->n_genomes] = dst->n_chunks;
+    }
+    return KSSD_HOST_OK;
+}

@@ -58,8 +58,63 @@ uint64_t kssd_batch_n_chunks(const kssd_batch *b);
 uint32_t kssd_batch_n_genomes(const kssd_batch *b);
 uint64_t kssd_batch_n_positions(const kssd_batch *b, uint32_t genome); /* bases + run breaks */
 
+/* append every genome of src to dst (used to tokenise files in parallel, one batch per thread) */
+int kssd_batch_append(kssd_batch *dst, const kssd_batch *src);
+
 /* whole file into memory through zlib; caller frees *buf */
 int kssd_slurp(const char *path, unsigned char **buf, size_t *len);
+
+/* ---- derived constants (seq2co_global_var_initial iseq2comem.c:54-77, get_hashsz command_dist.c:217-236) */
+typedef struct kssd_derived {
+    int k, subk, drlevel, kmerlen, dim_rd_len;
+    int comp_num, comp_bits;
+    uint32_t hashsize, hashlimit;
+} kssd_derived;
+int kssd_derive(kssd_derived *d, int k, int subk, int drlevel);
+
+/* ---- on-disk sketch / index formats -------------------------------------------- */
+typedef struct kssd_sketchset {
+    uint32_t shuf_id;
+    int koc;                 /* abundance flag of co_dstat_t, always 0 here */
+    int kmerlen, dim_rd_len; /* 2k, 2*drlevel */
+    int comp_num;
+    uint32_t n;              /* genomes */
+    uint64_t *off;           /* n+1, exclusive prefix */
+    uint32_t *ids;           /* FULL reduced tuples (component folded back in), genome after genome */
+    char (*names)[KSSD_PATHLEN];
+} kssd_sketchset;
+void kssd_sketchset_release(kssd_sketchset *s);
+
+/* Order one genome's distinct ids the way the reference's dump leaves them: ascending slot of its
+ * double-hashing table (global_basic.h:228-230, iseq2comem.c:538-546).  Ties between ids that probe
+ * the same slot depend on which the reference met first in the sequence; here the smaller id wins, so
+ * the result is byte-identical to the reference's file unless two ids of the genome collide. */
+void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize);
+
+/* write cofiles.stat + combco.<c> + combco.index.<c> like run_stageI (command_dist.c:314-378).
+ * slot_order != 0 applies kssd_slot_order per genome (ids are modified in place). */
+int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hashsize, int slot_order);
+/* read them back (all components folded into full tuples) */
+int kssd_sketchset_read(kssd_sketchset *s, const char *dir);
+/* mcofiles.stat + mco.index.<c> + mco.<c> from a sketch set: combco2mco + run_stageII
+ * (co2mco.c:25-77, command_dist.c:381-417).  mco.index.<c> is the dense size_t[16^7] the reference maps. */
+int kssd_index_write(const kssd_sketchset *s, const char *dir);
+/* rebuild a sketch set from mcofiles.stat + mco.* when no combco.* is around */
+int kssd_index_read(kssd_sketchset *s, const char *dir);
+/* 1 if dir holds cofiles.stat, 2 if mcofiles.stat, 3 both, 0 none (dist_dispatch probing, command_dist.c:62-63) */
+int kssd_probe_dir(const char *dir);
+
+/* ---- distance report (dist_print_nobin + output_ctrl, command_dist.c:1161-1287) ------------------------- */
+typedef struct kssd_print_opt {
+    int metric;        /* -M 0 Jaccard / 1 containment */
+    int pfield;        /* -O 0/1/2 */
+    int correction;    /* --correction */
+    double dthreshold; /* -D */
+    int n_max;         /* -N, 0 = all */
+    int threads;
+} kssd_print_opt;
+int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_sketchset *ref, const kssd_sketchset *qry,
+                        const kssd_print_opt *opt);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,90 @@
+"""-m gpu: the `kssd` command line end to end on the golden inputs: same directory protocol and files as the
+reference, distance.out byte-identical to what the reference binary printed (tests/golden)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kssd_oracle as ko
+import public_kssd_amd as K
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+BIN = os.path.join(ROOT, "public_kssd_amd", "kssd")
+META = json.load(open(os.path.join(G, "golden.json")))
+SK = np.load(os.path.join(G, "sketches.npz"))
+
+
+def run(args, cwd):
+    r = subprocess.run([BIN] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
+    return r.stdout.decode()
+
+
+def test_tutorial_flow_on_golden_inputs(tmp_path):
+    d = str(tmp_path)
+    out = run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
+    assert "shuf_id=%d" % META["shuf"]["id"] in out
+    out = run(["dist", "-L", "L3K10.shuf", "-o", "ref", os.path.join(G, "ref_fa")], d)
+    assert "hashsize=2097143\thashlimit=1258285" in out
+    run(["dist", "-L", "L3K10.shuf", "-o", "qry", os.path.join(G, "qry_fa")], d)
+    for sub in ("ref", "qry"):
+        sets = ko.sketch_sets_by_name(os.path.join(d, sub))
+        assert len(sets) == len(os.listdir(os.path.join(G, sub + "_fa")))
+        for nm, ids in sets.items():
+            assert np.array_equal(ids, SK["%s/%s" % (sub, nm)]), nm
+        hdr, sizes, names = ko.read_stat(os.path.join(d, sub, "cofiles.stat"))
+        assert (hdr["shuf_id"], hdr["kmerlen"], hdr["dim_rd_len"], hdr["comp_num"]) == (META["shuf"]["id"], 20, 6, 1)
+        assert hdr["all_ctx_ct"] == int(sizes.sum())
+    # file order inside a genome = the reference's hash-slot order
+    sk = ko.Sketcher(K.Shuf.read(os.path.join(d, "L3K10.shuf")).table, 10, 6, 3)
+    hdr, names, off, ids = ko.read_sketch_dir(os.path.join(d, "qry"))
+    for i, nm in enumerate(names):
+        assert np.array_equal(ids[int(off[i]):int(off[i + 1])], sk.file(nm)), nm
+    # search in the three renderings the goldens hold; names differ only by the directory prefix
+    for tag, extra in (("M0_O2", []), ("M1_O1", ["-M", 1, "-O", 1]), ("M0_N2_D", ["-N", 2, "-D", "0.2", "--correction", 1])):
+        run(["dist", "-r", "ref"] + extra + ["-o", "dist_" + tag, "qry"], d)
+        got = open(os.path.join(d, "dist_" + tag, "distance.out")).read()
+        got = got.replace(os.path.join(G, "qry_fa"), "QRY").replace(os.path.join(G, "ref_fa"), "REF")
+        want = open(os.path.join(G, "distance_%s.out" % tag)).read()
+        # the reference shuffles its file order with time(NULL); ours is sorted: compare as sets of lines
+        assert got.splitlines()[0] == want.splitlines()[0]
+        if "N2" in tag:   # -N keeps rank order inside a query
+            assert sorted(got.splitlines()[1:]) == sorted(want.splitlines()[1:])
+        else:
+            assert sorted(got.splitlines()[1:]) == sorted(want.splitlines()[1:])
+        assert not os.path.exists(os.path.join(d, "dist_" + tag, "sharedk_ct.dat"))
+    # --keepskf + -f: the kept shared-k-mer matrix reproduces the report
+    run(["dist", "-r", "ref", "--keepskf", "-o", "keep", "qry"], d)
+    sh = np.fromfile(os.path.join(d, "keep", "sharedk_ct.dat"), np.uint32)
+    assert sh.size == 3 * 6 and sh.sum() > 0
+    run(["dist", "-r", "ref", "-f", os.path.join(d, "keep", "sharedk_ct.dat"), "-o", "again", "qry"], d)
+    assert open(os.path.join(d, "again", "distance.out")).read() == open(os.path.join(d, "keep", "distance.out")).read()
+
+
+def test_fastq_and_auto_shuf(tmp_path):
+    d = str(tmp_path)
+    run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
+    for M in (1, 2):
+        out = run(["dist", "-n", M, "-L", "L3K10.shuf", "-o", "fq%d" % M, os.path.join(G, "reads.fq.gz")], d)
+        assert "12000 reads detected" in out
+        (nm, ids), = ko.sketch_sets_by_name(os.path.join(d, "fq%d" % M)).items()
+        assert np.array_equal(ids, SK["fq%d/reads.fq.gz" % M])
+    # -L <level>: a default.shuf is generated in the output directory (get_dim_shuffle, command_dist.c:193-216)
+    run(["dist", "-k", 9, "-L", 3, "--seed", 7, "-o", "auto", os.path.join(G, "ref_fa")], d)
+    sh = K.Shuf.read(os.path.join(d, "auto", "default.shuf"))
+    assert (sh.k, sh.subk, sh.drlevel) == (9, 6, 3)
+    sk = ko.Sketcher(sh.table, 9, 6, 3)
+    for nm, ids in ko.sketch_sets_by_name(os.path.join(d, "auto")).items():
+        assert np.array_equal(ids, np.sort(sk.file(os.path.join(G, "ref_fa", nm))))
+
+
+def test_errors_match_the_reference(tmp_path):
+    d = str(tmp_path)
+    r = subprocess.run([BIN, "shuffle", "-k", "10", "-s", "8", "-l", "5", "-o", "x"], cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"subk shoud smaller than 8" in r.stderr
+    r = subprocess.run([BIN, "dist", "-k", "10", "-L", "5", "-o", "o", os.path.join(G, "ref_fa")], cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"subk shoud smaller than 8" in r.stderr     # auto -L 5 is rejected

@@ -1,0 +1,93 @@
+"""Interoperability with the real reference binary (oracle/_ref/kssd, present in the dev container; these tests
+skip where it is not): our files are consumed by it and vice versa, byte for byte where the format allows."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import kssd_oracle as ko
+import public_kssd_amd as K
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+pytestmark = pytest.mark.skipif(not ko.have_ref(), reason="oracle/_ref/kssd not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def work(tmp_path_factory, shuf_l3k10):
+    d = tmp_path_factory.mktemp("interop")
+    sp = str(d / "L3K10.shuf")
+    shuf_l3k10.write(sp)
+    ko.run_ref(["dist", "-p", 2, "-L", sp, "-o", "ref", os.path.join(G, "ref_fa")], cwd=str(d))
+    ko.run_ref(["dist", "-p", 2, "-L", sp, "-o", "qry", os.path.join(G, "qry_fa")], cwd=str(d))
+    return d
+
+
+def test_reference_sketch_dir_roundtrips_through_our_reader_and_writer(work, shuf_l3k10):
+    for sub in ("ref", "qry"):
+        s = K.SketchSet.read(str(work / sub))
+        hdr, names, off, ids = ko.read_sketch_dir(str(work / sub))
+        assert s.names == names and np.array_equal(s.off, off) and np.array_equal(s.ids, ids)
+        assert (s.shuf_id, s.kmerlen, s.dim_rd_len, s.comp_num) == (shuf_l3k10.id, 20, 6, 1)
+        # write it back from SORTED ids: the slot-order replay must restore the reference's byte order
+        srt = np.concatenate([np.sort(ids[int(off[i]):int(off[i + 1])]) for i in range(len(names))])
+        out = str(work / (sub + "_ours"))
+        K.SketchSet(s.shuf_id, 20, 6, 1, names, off, srt).write(out, K.derive(10, 6, 3).hashsize, slot_order=True)
+        assert filecmp.cmp(os.path.join(out, "combco.index.0"), str(work / sub / "combco.index.0"), shallow=False)
+        a = np.fromfile(os.path.join(out, "combco.0"), np.uint32)
+        assert np.array_equal(a, ids)   # no probe collisions at these sizes: byte-identical
+        h2, sizes2, names2 = ko.read_stat(os.path.join(out, "cofiles.stat"))
+        assert h2 == hdr and names2 == names
+
+
+def test_slot_order_matches_oracle_dump_order(shuf_l3k10):
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    txt = open(os.path.join(G, "qry_fa", "edge.fa"), "rb").read()
+    dump = sk.fasta(txt)                      # hash-slot order, as the reference writes it
+    assert np.array_equal(K.slot_order(np.sort(dump), sk.p.hashsize), dump)
+
+
+def test_reference_consumes_our_index_and_agrees(work, tmp_path):
+    """our mco.* (2 GiB dense offsets) == the reference's own stage II output, and the reference searches with it"""
+    ref = K.SketchSet.read(str(work / "ref"))
+    ours = tmp_path / "ours"
+    ours.mkdir()
+    ref.write(str(ours), K.derive(10, 6, 3).hashsize, slot_order=False)
+    ref.write_index(str(ours))
+    theirs = tmp_path / "theirs"
+    ko.run_ref(["dist", "-p", 1, "-o", str(theirs), str(work / "ref")])
+    assert filecmp.cmp(str(ours / "mco.0"), str(theirs / "mco.0"), shallow=False)
+    assert filecmp.cmp(str(ours / "mco.index.0"), str(theirs / "mco.index.0"), shallow=False)
+    os.remove(str(theirs / "mco.index.0"))
+    h1, s1, n1 = ko.read_stat(str(ours / "mcofiles.stat"), mco=True)
+    h2, s2, n2 = ko.read_stat(str(theirs / "mcofiles.stat"), mco=True)
+    assert h1 == h2 and n1 == n2 and np.array_equal(s1, s2)
+    back = K.SketchSet.read_index(str(ours))
+    assert back.sets_by_name().keys() == ref.sets_by_name().keys()
+    for k, v in ref.sets_by_name().items():
+        assert np.array_equal(back.sets_by_name()[k], v)
+    # the reference binary searches against OUR files; our printer gives the same bytes
+    ko.run_ref(["dist", "-p", 2, "-r", str(ours), "--keepskf", "-o", str(tmp_path / "d"), str(work / "qry")])
+    qry = K.SketchSet.read(str(work / "qry"))
+    sh = np.fromfile(str(tmp_path / "d" / "sharedk_ct.dat"), np.uint32).reshape(len(qry.names), len(ref.names))
+    assert np.array_equal(sh, ko.shared_counts(ref.off, ref.ids, qry.off, qry.ids))
+    K.distance_print(str(tmp_path / "mine.out"), sh, ref, qry, threads=2)
+    assert filecmp.cmp(str(tmp_path / "mine.out"), str(tmp_path / "d" / "distance.out"), shallow=False)
+    os.remove(str(ours / "mco.index.0"))
+
+
+def test_config1_test_fna_tutorial_oracle_vs_reference(tmp_path, shuf_l3k10):
+    """BASELINE configs[0]: the README quick tutorial on test_fna (reference repo data, dev container only)"""
+    src = "/root/reference/test_fna"
+    if not os.path.isdir(src):
+        pytest.skip("reference test data not present")
+    sp = str(tmp_path / "L3K10.shuf")
+    shuf_l3k10.write(sp)
+    ko.run_ref(["dist", "-p", 4, "-L", sp, "-o", "reference", os.path.join(src, "seqs1")], cwd=str(tmp_path))
+    ko.run_ref(["dist", "-p", 4, "-L", sp, "-o", "query", os.path.join(src, "seqs2")], cwd=str(tmp_path))
+    rs, qs = K.SketchSet.read(str(tmp_path / "reference")), K.SketchSet.read(str(tmp_path / "query"))
+    off, ids = ko.sketch_files(shuf_l3k10.table, 10, 6, 3, rs.names + qs.names, threads=8)
+    for i, nm in enumerate(rs.names + qs.names):
+        want = (rs if i < len(rs.names) else qs).sets_by_name()[os.path.basename(nm)]
+        assert np.array_equal(np.sort(ids[int(off[i]):int(off[i + 1])]), want), nm
+    assert 1100 < np.diff(rs.off).min() and np.diff(rs.off).max() < 1600   # ~5.4 Mb / 4096
