@@ -184,11 +184,9 @@ def main():
     ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
     R = G * world
     if world > 1:
-        off_all = torch.zeros(world * (G + 1), dtype=torch.int64, device=dev)
-        ids_all = torch.zeros(world * cap, dtype=torch.int32, device=dev)
-        roff = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-        rids = torch.zeros(world * cap, dtype=torch.int32, device=dev)
-        jj = torch.arange(world * cap, device=dev, dtype=torch.int64)
+        from public_kssd_amd.shard import SketchGather, query_block
+        gather = SketchGather(world, G, cap, dev)
+        qb, qe = query_block(rank, G)
     shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
     planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
     stream = torch.cuda.current_stream().cuda_stream
@@ -200,21 +198,11 @@ def main():
             ctx.dist_device(off_l, ids_l, G, 0, G, shared, *planes, stream=stream)
         else:
             # the one exchange step of the path: all-gather of every rank's packed sketches (RCCL over xGMI),
-            # fixed-size padded units so that no size has to visit the host
-            dist.all_gather_into_tensor(off_all, off_l)
-            dist.all_gather_into_tensor(ids_all, ids_l)
-            o = off_all.view(world, G + 1)
-            sizes = (o[:, 1:] - o[:, :-1]).reshape(-1)
-            roff[1:] = torch.cumsum(sizes, 0)
-            tot = o[:, G]                                   # ids per rank
-            ends = torch.cumsum(tot, 0)
-            starts = ends - tot
-            rk = torch.searchsorted(ends, jj, right=True).clamp_(max=world - 1)
-            src = (jj - starts[rk] + rk * cap).clamp_(max=world * cap - 1)
-            torch.index_select(ids_all, 0, src, out=rids)   # compact CSR of all references, on the device
+            # fixed-size padded units compacted on the device, so that no size has to visit the host
+            roff, rids = gather(off_l, ids_l)
             ctx.index_build_device(roff, rids, R, world * cap, stream)
             # this rank's query block = its own genomes = rows [rank*G, (rank+1)*G) of the global matrix
-            ctx.dist_device(roff, rids, R, rank * G, (rank + 1) * G, shared, *planes, stream=stream)
+            ctx.dist_device(roff, rids, R, qb, qe, shared, *planes, stream=stream)
 
     def sync():
         if world > 1:
