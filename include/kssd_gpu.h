@@ -107,6 +107,13 @@ int kssd_gpu_sketch_device(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const ui
  */
 int kssd_gpu_sketch_status(kssd_gpu_ctx *ctx, uint64_t *total_ids, int64_t *bad_genome, void *stream);
 
+/*
+ * Telemetry of the last kssd_gpu_sketch_device call (synchronises `stream`): how many window positions passed
+ * the stage-1 group filter and how many of those passed the Bloom test of the exact pattern (= the candidates
+ * handed to the exact stage).  Any pointer may be NULL.
+ */
+int kssd_gpu_scan_stats(kssd_gpu_ctx *ctx, uint64_t *stage1, uint64_t *bloom, void *stream);
+
 /* host-level convenience: HOST packed/mask in, malloc'd HOST CSR out (free with kssd_gpu_free) */
 int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
                           const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,

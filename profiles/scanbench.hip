@@ -161,6 +161,11 @@ int main(int argc, char **argv)
     kssd_gpu_kernel_time(ctx, 0, 1, &ms, &nl);
     rc = kssd_gpu_sketch_status(ctx, &total, &bad, nullptr);
 
+    uint64_t s1 = 0, bl = 0;
+    kssd_gpu_scan_stats(ctx, &s1, &bl, nullptr);
+    printf("stats: stage1 %llu (%.4f %%) bloom %llu (%.4f %%)\n", (unsigned long long)s1,
+           100.0 * s1 / ((double)G * chunks * KSSD_CHUNK_BASES), (unsigned long long)bl,
+           100.0 * bl / ((double)G * chunks * KSSD_CHUNK_BASES));
     std::vector<uint32_t> ids(total);
     std::vector<uint64_t> off(G + 1);
     CK(hipMemcpy(ids.data(), d_ids, total * 4, hipMemcpyDeviceToHost));

@@ -3,7 +3,7 @@
 // Everything here is a restatement of what the reference computes per k-mer
 // (iseq2comem.c:54-77 constants, :245-253 canonical strand / .shuf filter / reduced tuple), arranged
 // for a two-stage GPU scan:
-//   stage 1  a superset filter evaluated for 4 window positions per LDS lookup ("quad core" table)
+//   stage 1  a superset filter evaluated for KSSD_GW window positions per LDS lookup (group-filter table)
 //   stage 2  the exact evaluation of the few surviving candidates
 // Functions marked KSSD_HD compile for host and device so that tests can drive the same bit
 // manipulation on the CPU (tests/emu) -- the product only ever runs them on the device.
@@ -17,8 +17,8 @@
 #endif
 
 #define KSSD_CHUNK 4096      // positions per chunk (one wave-iteration: 64 lanes x 64 positions)
-#define KSSD_T1_BITS 18      // log2(entries) of the quad-core nibble table
-#define KSSD_T1_BYTES (1u << (KSSD_T1_BITS - 1))
+#define KSSD_T1_BYTES (1u << 17)  // stage-1 group-filter table: one byte per 17-bit index
+#define KSSD_GW 5                // windows per table read (KssdGrp)
 #define KSSD_MIN_DIM_SMP 4096  // MIN_SUBCTX_DIM_SMP_SZ, command_shuffle.h:29
 #define KSSD_COMPONENT_SZ 7    // reference Makefile:4
 #define KSSD_CTX_SPC_USE_L 8   // global_basic.h:45-47
@@ -32,7 +32,8 @@ struct KssdParams {
     uint32_t comp_num; // iseq2comem.c:63-64
     uint32_t dim_end;  // accepted permutation ranks are [0, dim_end)          iseq2comem.c:74-76
     uint32_t hashsize, hashlimit;  // command_dist.c:217-236, iseq2comem.c:61
-    uint32_t g_log2;   // exact table G has 2^g_log2 slots
+    uint32_t g_log2;   // exact table G: two cuckoo halves of 2^g_log2 slots each
+    uint32_t g_mul[2]; // their multiplicative hashes (chosen by kssd_build_tables)
     uint64_t dim_mask; // 4*subk ones
 };
 
@@ -49,7 +50,7 @@ static inline int kssd_params_init(KssdParams *p, int k, int subk, int drlevel)
     if (k < subk || subk >= 8 || subk < 1 || drlevel < 0 || k > 15) return -1;  // command_shuffle.c:163-168
     int pidx = 4 * (k - drlevel) - KSSD_CTX_SPC_USE_L - 7;                        // command_dist.c:220
     if (pidx < 0 || pidx > 24) return -1;
-    if (subk < 2) return -2;                       // quad-core filter needs >= 4 bases of sub-context
+    if (subk < 2) return -2;                       // group filter needs >= 4 bases of sub-context
     if (4 * (k - drlevel) > 32) return -2;         // reduced tuple must fit the u32 the formats store
     if (subk < drlevel) return -1;
     p->k = k; p->subk = subk; p->drlevel = drlevel;
@@ -65,8 +66,10 @@ static inline int kssd_params_init(KssdParams *p, int k, int subk, int drlevel)
     p->hashsize = kssd_primes[pidx];
     p->hashlimit = (uint32_t)(p->hashsize * 0.6);  // LD_FCTR, global_basic.h:49
     uint32_t lg = 0;
-    while ((1u << lg) < 4u * p->dim_end) lg++;
+    while ((1u << lg) < 2u * p->dim_end) lg++;
     p->g_log2 = lg;
+    p->g_mul[0] = 0x9E3779B1u;
+    p->g_mul[1] = 0x85EBCA6Bu;
     p->dim_mask = (1ull << (4 * subk)) - 1;
     return 0;
 }
@@ -74,6 +77,12 @@ static inline int kssd_params_init(KssdParams *p, int k, int subk, int drlevel)
 // reverse complement of the low `nbases` bases of x (2 bits per base, A=0 C=1 G=2 T=3)
 KSSD_HD uint64_t kssd_revcomp(uint64_t x, int nbases)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_bfrev_b32 x2 reverses the base order and swaps the two bits of every base; swap those back
+    uint64_t r = __builtin_bitreverse64(x);
+    r = ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    return (~r) >> (64 - 2 * nbases);
+#endif
     x = ~x;
     x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
@@ -83,79 +92,142 @@ KSSD_HD uint64_t kssd_revcomp(uint64_t x, int nbases)
     return x >> (64 - 2 * nbases);
 }
 
-// index of a quad core in the nibble table: identity while it fits, multiplicative hash beyond
-template <int CORE_BITS>
-KSSD_HD uint32_t kssd_t1_index(uint32_t core)
-{
-    if (CORE_BITS <= KSSD_T1_BITS) return core;
-    return (core * 0x9E3779B1u) >> (32 - KSSD_T1_BITS);
-}
+// ---------------------------------------------------------------------------------------------------
+// Stage 1, group filter: a superset test evaluated for GW window positions per LDS read.
+// The canonical k-mer's sub-context is either the forward middle 2*subk bases m or their reverse complement,
+// so a position can only be sampled if m is in S = A u rc(A) (A = the dim_end accepted sub-contexts).
+// GW consecutive windows share the C = 2*subk + 1 - GW bases in the middle (the "group core").  The table is
+// indexed by the first IDXB stream bits from the core on; entry bit j <=> "some pattern of S, placed at window
+// j of the group, agrees with these bits" (index bits beyond a window's end are wildcards for that window).
+// Byte entries: no sub-byte select, answers merge with one shift-or.  Every position is tested under two
+// alignments (A: groups at GW*q, B: groups at GW*q + SB - GW); 0.8 % of the positions survive at L3K10
+// (true rate 0.049 %).  The two alignments are separate issue / merge halves so that the kernel can keep one
+// batch of LDS reads in flight while it works on the other (s_waitcnt lgkmcnt can only count to 15).
+// ---------------------------------------------------------------------------------------------------
+template <int SUBK, int GW>
+struct KssdGrp {
+    static constexpr int LP = 2 * SUBK;                       // bases of a sub-context
+    static constexpr int W = (LP >= GW + 1) ? GW : (LP - 1);  // windows per group (>= 1 shared base)
+    static constexpr int C = LP + 1 - W;                      // bases shared by the windows of a group
+    static constexpr int IDXB = (2 * LP < 17) ? 2 * LP : 17;  // index bits (128 KiB of byte entries at most)
+    static constexpr int SB = W / 2;                          // offset of the second alignment
+    static constexpr int NA = (63 / W) + 1;                   // groups of alignment A: Q = W*q
+    static constexpr int QB0 = SB - W;                        // first group of alignment B
+    static constexpr int NB = (63 - QB0) / W + 1;             // groups of alignment B: Q = QB0 + W*q
+    static constexpr int NMAX = NA > NB ? NA : NB;
+    static constexpr int count(int aln) { return aln ? NB : NA; }
+    static constexpr int first(int aln) { return aln ? QB0 : 0; }
+};
 
-KSSD_HD uint32_t kssd_t1_index_rt(uint32_t core, int core_bits)
+// index field of the group that starts at lane position Q (compile-time): IDXB stream bits from the core on
+template <int IDXB>
+KSSD_HD uint32_t kssd_grp_field(const uint32_t (&Wd)[5], const uint32_t (&V)[4], int start)
 {
-    if (core_bits <= KSSD_T1_BITS) return core;
-    return (core * 0x9E3779B1u) >> (32 - KSSD_T1_BITS);
-}
-
-KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t g_log2) { return (dim * 0x9E3779B1u) >> (32 - g_log2); }
-
-// Stage 1 for one lane: W[0..4] = the 5 packed words covering the lane's 64 window-start positions
-// plus the 2*subk-1 bases after them.  Bit i of the result <=> the sub-context that starts at the
-// lane's position i MAY be one of the accepted sub-contexts or the reverse complement of one.
-// One table read answers 4 consecutive positions: they share the 2*subk-3 bases in the middle ("quad
-// core").  Every position is tested under two quad alignments (quads starting at 4q and at 4q+2): the
-// two cores together pin 2*subk-1 of its 2*subk bases, which cuts the candidates ~10x (3.1 % -> 0.3 %
-// at subk = 6) for the price of a second LDS read per 4 positions.
-// One quad lookup.  The core is pulled out of the 64-bit window with 2 spare bits below it, so that
-//   byte address = field >> 3, nibble select = field & 4   (identity index, CB <= 18)
-// costs one shift/alignbit, one bfe, one and, one bfe after the LDS read.
-template <int CB, typename T1PTR>
-KSSD_HD uint32_t kssd_quad_nibble(uint32_t whi, uint32_t wlo, int bo, T1PTR T1)
-{
-    const uint64_t win = ((uint64_t)whi << 32) | wlo;
-    if (CB <= KSSD_T1_BITS) {
+    const int i = start >> 5, off = start & 31;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int sh = 62 - bo - CB;  // compile-time after unrolling
-        const uint32_t field = sh >= 32 ? (whi >> (sh - 32)) : __builtin_amdgcn_alignbit(whi, wlo, sh);
-        const uint32_t byte = T1[__builtin_amdgcn_ubfe(field, 3, CB - 1)];
-        return __builtin_amdgcn_ubfe(byte, field & 4u, 4);
+    if (off + IDXB <= 32) return __builtin_amdgcn_ubfe(Wd[i], 32 - off - IDXB, IDXB);
+    return __builtin_amdgcn_ubfe(V[i < 4 ? i : 3], 48 - off - IDXB, IDXB);  // V[i] = stream bits [32i+16, 32i+48)
 #else
-        const uint32_t field = (uint32_t)(win >> (62 - bo - CB));  // core in bits [2, 2+CB)
-        const uint32_t byte = T1[(field >> 3) & ((1u << (CB - 1)) - 1u)];
-        return (byte >> (field & 4u)) & 0xFu;
+    (void)V;
+    const uint64_t win = ((uint64_t)Wd[i] << 32) | (i < 4 ? Wd[i + 1] : 0u);
+    return (uint32_t)(win >> (64 - off - IDXB)) & ((1u << IDXB) - 1u);
 #endif
-    } else {
-        const uint32_t core = (uint32_t)(win >> (64 - bo - CB)) & ((1u << CB) - 1u);
-        const uint32_t idx = kssd_t1_index<CB>(core);
-        return ((uint32_t)T1[idx >> 1] >> ((idx & 1u) * 4u)) & 0xFu;
+}
+
+// issue the table reads of one alignment (ALN 0 = A, 1 = B); raw[q] = answer bits of group q
+template <int SUBK, int GW, int ALN, typename T1PTR>
+KSSD_HD void kssd_grp_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[KssdGrp<SUBK, GW>::NMAX])
+{
+    typedef KssdGrp<SUBK, GW> Gp;
+    uint32_t V[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        V[i] = __builtin_amdgcn_alignbit(Wd[i], Wd[i + 1], 16);
+#else
+        V[i] = (Wd[i] << 16) | (Wd[i + 1] >> 16);
+#endif
+    }
+#pragma unroll
+    for (int q = 0; q < Gp::NMAX; q++) {
+        if (q < Gp::count(ALN)) {
+            const int Q = Gp::first(ALN) + Gp::W * q;
+            raw[q] = T1[kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1))];
+        } else {
+            raw[q] = 0;
+        }
     }
 }
 
-template <int SUBK, typename T1PTR>
-KSSD_HD void kssd_stage1(const uint32_t (&W)[5], T1PTR T1, uint32_t &cand_lo, uint32_t &cand_hi)
+// merge the answers of one alignment into the 64-position masks (bit p <=> lane position p may be sampled)
+template <int SUBK, int GW, int ALN>
+KSSD_HD void kssd_grp_merge(const uint32_t (&raw)[KssdGrp<SUBK, GW>::NMAX], uint32_t &lo, uint32_t &hi)
 {
-    constexpr int CB = 2 * (2 * SUBK - 3);  // bits of a quad core
-    uint32_t lo = 0, hi = 0;
+    typedef KssdGrp<SUBK, GW> Gp;
+    lo = 0;
+    hi = 0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int o = 8 * q + 6;  // bit offset of the core of quad q, counted from the top of W[0]
-        const uint32_t nib = kssd_quad_nibble<CB>(W[o >> 5], W[(o >> 5) + 1], o & 31, T1);
-        if (q < 8) lo |= nib << (4 * q);
-        else hi |= nib << (4 * (q - 8));
+    for (int q = 0; q < Gp::count(ALN); q++) {
+        int Q = Gp::first(ALN) + Gp::W * q;
+        uint32_t n = raw[q];
+        if (Q < 0) { n >>= -Q; Q = 0; }
+        if (Q < 32) {
+            lo |= n << Q;
+            if (Q + Gp::W > 32) hi |= n >> (32 - Q);
+        } else {
+            hi |= n << (Q - 32);  // answers for positions >= 64 fall off the top
+        }
     }
-    uint32_t lo2 = 0, hi2 = 0;
-#pragma unroll
-    for (int q = -1; q < 16; q++) {
-        const int o = 8 * q + 10;  // quads shifted by two positions: windows 4q+2 .. 4q+5
-        const int wi = o >> 5;
-        const uint32_t nib = kssd_quad_nibble<CB>(W[wi], wi < 4 ? W[wi < 4 ? wi + 1 : 4] : 0u, o & 31, T1);
-        if (q < 0) lo2 |= nib >> 2;  // windows -2,-1 belong to the previous lane
-        else if (q < 7) lo2 |= nib << (4 * q + 2);
-        else if (q == 7) { lo2 |= nib << 30; hi2 |= nib >> 2; }  // windows 30..33 straddle the two words
-        else hi2 |= nib << (4 * q - 30);  // q = 15: windows 64,65 fall off the top
-    }
-    cand_lo = lo & lo2;
-    cand_hi = hi & hi2;
+}
+
+// both alignments at once (CPU emulation in tests/emu; the kernel interleaves the halves)
+template <int SUBK, int GW, typename T1PTR>
+KSSD_HD void kssd_stage1g(const uint32_t (&Wd)[5], T1PTR T1, uint32_t &cand_lo, uint32_t &cand_hi)
+{
+    uint32_t ra[KssdGrp<SUBK, GW>::NMAX], rb[KssdGrp<SUBK, GW>::NMAX];
+    uint32_t alo, ahi, blo, bhi;
+    kssd_grp_issue<SUBK, GW, 0>(Wd, T1, ra);
+    kssd_grp_issue<SUBK, GW, 1>(Wd, T1, rb);
+    kssd_grp_merge<SUBK, GW, 0>(ra, alo, ahi);
+    kssd_grp_merge<SUBK, GW, 1>(rb, blo, bhi);
+    cand_lo = alo & blo;
+    cand_hi = ahi & bhi;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stage 1.5: exact-pattern Bloom test of the few candidates stage 1 lets through.  Stage 1 only proves that
+// each alignment agrees with SOME pattern of S; 94 % of its candidates are not in S at all.  The lane that owns
+// the candidate still holds the bases in registers, so the 2*subk-base pattern m is cut out of them (no memory
+// access) and looked up in a blocked Bloom filter of S in LDS: one 32-bit word per lookup, 3 bits per pattern,
+// 16 bits of filter per pattern -> ~1.6 % false positives.  What survives (~0.06 % of the positions, half of
+// them true samples) is all that ever reaches the exact stage 2 and its global-memory reads.
+// ---------------------------------------------------------------------------------------------------
+#define KSSD_BLOOM_WORDS 4096u
+KSSD_HD uint32_t kssd_bloom_hash(uint32_t m) { return m * 0x9E3779B1u; }
+KSSD_HD uint32_t kssd_bloom_word(uint32_t h) { return h >> 20; }
+KSSD_HD uint32_t kssd_bloom_bits(uint32_t h)
+{
+    return (1u << ((h >> 15) & 31u)) | (1u << ((h >> 10) & 31u)) | (1u << ((h >> 5) & 31u));
+}
+
+// the 2*SUBK bases that start at lane position b (0..63), out of the lane's 5 packed words
+template <int SUBK>
+KSSD_HD uint32_t kssd_extract_m(const uint32_t (&W)[5], uint32_t b)
+{
+    // bit-select on all-ones / all-zeros masks (v_bfi_b32): written as a select or an indexed array the
+    // compiler turns W into a scratch-memory array, and every lookup into a memory round trip
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 4, 1), s2 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 5, 1);
+#else
+    const uint32_t s1 = 0u - ((b >> 4) & 1u), s2 = 0u - ((b >> 5) & 1u);
+#endif
+#define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
+    const uint32_t hi = KSSD_BSEL(s2, KSSD_BSEL(s1, W[3], W[2]), KSSD_BSEL(s1, W[1], W[0]));
+    const uint32_t lo = KSSD_BSEL(s2, KSSD_BSEL(s1, W[4], W[3]), KSSD_BSEL(s1, W[2], W[1]));
+#undef KSSD_BSEL
+    const uint32_t sh = (b & 15u) * 2u;
+    const uint32_t top = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
+    return top >> (32 - 4 * SUBK);
 }
 
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank
@@ -163,7 +235,41 @@ struct KssdG {  // one slot of the exact table: accepted sub-context -> permutat
     uint32_t rank;
 };
 
-// Stage 2: exact evaluation of the k-mer whose sub-context starts at global position s.
+// The exact table is a two-choice cuckoo table: G[0 .. 2^g_log2) is addressed by g_mul[0], G[2^g_log2 .. 2*2^g_log2)
+// by g_mul[1]; an accepted sub-context sits in exactly one of its two slots, so a lookup is two INDEPENDENT
+// 8-byte reads and never a probe loop (the scan kernel keeps them in flight across a whole chunk).
+KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t mul, uint32_t g_log2) { return (dim * mul) >> (32 - g_log2); }
+
+// Stage 2, arithmetic only (shared by the pipelined device path and the plain function below).
+// p0..p2 = packed words (b0>>4)+0..2, m0,m1 = mask words (b0>>5)+0..1, b0 = first base of the k-mer.
+// Returns true if all 2k bases are valid (run counter "base > TL", iseq2comem.c:243); u = canonical k-mer
+// (iseq2comem.c:245), dim = its sub-context (:246).
+KSSD_HD bool kssd_s2_decode(const KssdParams &P, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t m0, uint32_t m1,
+                            uint32_t b0_low, uint64_t &u, uint32_t &dim)
+{
+    const int mo = (int)(b0_low & 31u);
+    const uint64_t m64 = (uint64_t)m0 | ((uint64_t)m1 << 32);
+    const uint64_t need = (1ull << P.nb) - 1ull;
+    const bool valid = ((m64 >> mo) & need) == need;
+    const int sh = (int)(b0_low & 15u) * 2;
+    const uint64_t hi64 = ((uint64_t)p0 << 32) | p1;
+    const uint64_t top = sh ? ((hi64 << sh) | ((uint64_t)p2 >> (32 - sh))) : hi64;
+    const uint64_t fwd = top >> (64 - 2 * P.nb);
+    const uint64_t rev = kssd_revcomp(fwd, P.nb);
+    u = fwd < rev ? fwd : rev;
+    dim = (uint32_t)((u >> (2 * P.out)) & P.dim_mask);
+    return valid;
+}
+
+// reduced tuple (iseq2comem.c:250-253): outer bases packed above the rank, literally as the reference adds them
+KSSD_HD uint32_t kssd_s2_tuple(const KssdParams &P, uint64_t u, uint32_t rank)
+{
+    const uint64_t upper = u & (((1ull << (2 * P.out)) - 1ull) << (2 * (P.k + P.subk)));
+    const uint64_t lower = u & ((1ull << (2 * P.out)) - 1ull);
+    return (uint32_t)(((upper + (lower << (2 * P.nb - 4 * P.out))) >> (4 * P.drlevel)) + rank);
+}
+
+// Stage 2 in one piece: exact evaluation of the k-mer whose sub-context starts at global position s.
 // [lo_ok, hi_ok) = positions the k-mer may touch (same genome, inside the batch).
 // Returns true and the reduced tuple when the reference would insert it (iseq2comem.c:243-253).
 KSSD_HD bool kssd_stage2(const KssdParams &P, int64_t s, int64_t lo_ok, int64_t hi_ok,
@@ -172,37 +278,15 @@ KSSD_HD bool kssd_stage2(const KssdParams &P, int64_t s, int64_t lo_ok, int64_t 
 {
     const int64_t b0 = s - P.out;  // first base of the k-mer
     if (b0 < lo_ok || b0 + P.nb > hi_ok) return false;
-    // validity: all nb mask bits set  (run counter "base > TL", iseq2comem.c:243)
-    const uint64_t mw = (uint64_t)b0 >> 5;
-    const int mo = (int)(b0 & 31);
-    uint64_t m64 = (uint64_t)mask[mw] | ((uint64_t)mask[mw + 1] << 32);
-    const uint64_t need = (1ull << P.nb) - 1ull;
-    if (((m64 >> mo) & need) != need) return false;
-    // the 2*nb bits of the forward k-mer out of three packed words
-    const uint64_t pw = (uint64_t)b0 >> 4;
-    const int sh = (int)(b0 & 15) * 2;
-    uint64_t hi64 = ((uint64_t)packed[pw] << 32) | packed[pw + 1];
-    uint64_t w2 = packed[pw + 2];
-    uint64_t top = sh ? ((hi64 << sh) | (w2 >> (32 - sh))) : hi64;
-    uint64_t fwd = top >> (64 - 2 * P.nb);
-    uint64_t rev = kssd_revcomp(fwd, P.nb);
-    uint64_t u = fwd < rev ? fwd : rev;                       // iseq2comem.c:245
-    uint32_t dim = (uint32_t)((u >> (2 * P.out)) & P.dim_mask);  // :246
+    const uint64_t mw = (uint64_t)b0 >> 5, pw = (uint64_t)b0 >> 4;
+    uint64_t u;
+    uint32_t dim;
+    if (!kssd_s2_decode(P, packed[pw], packed[pw + 1], packed[pw + 2], mask[mw], mask[mw + 1], (uint32_t)b0, u, dim)) return false;
     // exact membership + rank (the reference reads the 16^subk-entry permutation here, :247-249)
-    uint32_t slot = kssd_g_slot(dim, P.g_log2);
-    const uint32_t gmask = (1u << P.g_log2) - 1u;
-    uint32_t rank;
-    for (;;) {
-        KssdG e = G[slot];
-        if (e.key == dim) { rank = e.rank; break; }
-        if (e.key == KSSD_EMPTY_KEY) return false;
-        slot = (slot + 1) & gmask;
-    }
-    // reduced tuple (:250-253): outer bases packed above the rank, literally as the reference adds them
-    uint64_t upper = u & (((1ull << (2 * P.out)) - 1ull) << (2 * (P.k + P.subk)));
-    uint64_t lower = u & ((1ull << (2 * P.out)) - 1ull);
-    uint64_t dr = ((upper + (lower << (2 * P.nb - 4 * P.out))) >> (4 * P.drlevel)) + rank;
-    dr_out = (uint32_t)dr;
+    const KssdG e1 = G[kssd_g_slot(dim, P.g_mul[0], P.g_log2)];
+    const KssdG e2 = G[(1u << P.g_log2) + kssd_g_slot(dim, P.g_mul[1], P.g_log2)];
+    if (e1.key != dim && e2.key != dim) return false;
+    dr_out = kssd_s2_tuple(P, u, e1.key == dim ? e1.rank : e2.rank);
     return true;
 }
 
@@ -210,30 +294,65 @@ KSSD_HD bool kssd_stage2(const KssdParams &P, int64_t s, int64_t lo_ok, int64_t 
 // Host-side construction of the two device tables from the accepted sub-contexts
 // (accepted[r] = the sub-context whose permutation rank is r, r < dim_end).
 //   T1  stage-1 pattern set: accepted sub-contexts and their reverse complements, every one entered
-//       under the 4 alignments a quad can see it in; nibble bit j <=> window = quad position j
-//   G   stage-2 exact map sub-context -> rank (open addressing, linear probing)
-static inline void kssd_build_tables(const KssdParams &P, const std::vector<uint32_t> &accepted,
-                                     std::vector<uint8_t> &T1, std::vector<KssdG> &G)
+//       at the GW window offsets a group can see it in; entry bit j <=> window j of the group
+//   bloom  stage-1.5 blocked Bloom filter of the same pattern set
+//   G   stage-2 exact map sub-context -> rank (two-choice cuckoo, see KssdG)
+static inline void kssd_build_tables(KssdParams &P, const std::vector<uint32_t> &accepted, int GW,
+                                     std::vector<uint8_t> &T1, std::vector<uint32_t> &bloom, std::vector<KssdG> &G)
 {
-    const int Lp = 2 * P.subk, Lc = Lp - 3, CB = 2 * Lc;
+    // stage-1 group-filter table (see KssdGrp): W, IDXB as the kernel instantiation uses them
+    const int LP = 2 * P.subk;
+    const int W = (LP >= GW + 1) ? GW : (LP - 1);
+    const int IDXB = (2 * LP < 17) ? 2 * LP : 17;
     T1.assign(KSSD_T1_BYTES, 0);
     auto add = [&](uint64_t x) {
-        for (int j = 0; j < 4; j++) {
-            uint32_t core = (uint32_t)((x >> (2 * j)) & ((1ull << CB) - 1ull));  // bases [3-j, 3-j+Lc) of x
-            uint32_t idx = kssd_t1_index_rt(core, CB);
-            T1[idx >> 1] |= (uint8_t)((1u << j) << ((idx & 1u) * 4u));
+        for (int j = 0; j < W; j++) {
+            const int start = 2 * (W - 1 - j);                                // index field starts here, counted from the pattern's top bit
+            const int avail = IDXB < 2 * LP - start ? IDXB : 2 * LP - start;  // field bits that lie inside window j
+            const uint32_t known = (uint32_t)((x >> (2 * LP - start - avail)) & ((1ull << avail) - 1ull));
+            const int wild = IDXB - avail;
+            for (uint32_t fill = 0; fill < (1u << wild); fill++) T1[(known << wild) | fill] |= (uint8_t)(1u << j);
         }
     };
+    bloom.assign(KSSD_BLOOM_WORDS, 0);
+    auto add_bloom = [&](uint32_t x) {
+        const uint32_t h = kssd_bloom_hash(x);
+        bloom[kssd_bloom_word(h)] |= kssd_bloom_bits(h);
+    };
     for (size_t r = 0; r < accepted.size(); r++) {
+        const uint32_t rc = (uint32_t)kssd_revcomp(accepted[r], LP);
         add(accepted[r]);
-        add(kssd_revcomp(accepted[r], Lp));
+        add(rc);
+        add_bloom(accepted[r]);
+        add_bloom(rc);
     }
-    const size_t gn = (size_t)1 << P.g_log2;
-    G.assign(gn, KssdG{KSSD_EMPTY_KEY, 0});
-    for (size_t r = 0; r < accepted.size(); r++) {
-        uint32_t slot = kssd_g_slot(accepted[r], P.g_log2);
-        while (G[slot].key != KSSD_EMPTY_KEY) slot = (slot + 1) & (uint32_t)(gn - 1);
-        G[slot] = KssdG{accepted[r], (uint32_t)r};
+    // two-choice cuckoo insertion; a walk that does not end picks new multipliers and starts over
+    const size_t half = (size_t)1 << P.g_log2;
+    uint64_t seed = 0x243F6A8885A308D3ull;
+    for (int attempt = 0;; attempt++) {
+        G.assign(2 * half, KssdG{KSSD_EMPTY_KEY, 0});
+        bool ok = true;
+        for (size_t r = 0; r < accepted.size() && ok; r++) {
+            KssdG cur{accepted[r], (uint32_t)r};
+            int side = 0;
+            ok = false;
+            for (int hop = 0; hop < 512; hop++) {
+                const size_t slot = side * half + kssd_g_slot(cur.key, P.g_mul[side], P.g_log2);
+                if (G[slot].key == KSSD_EMPTY_KEY) { G[slot] = cur; ok = true; break; }
+                const KssdG t = G[slot];
+                G[slot] = cur;
+                cur = t;
+                side ^= 1;
+            }
+        }
+        if (ok) break;
+        for (int i = 0; i < 2; i++) {  // splitmix64 -> odd multipliers
+            seed += 0x9E3779B97F4A7C15ull;
+            uint64_t z = seed;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            P.g_mul[i] = (uint32_t)(z ^ (z >> 31)) | 1u;
+        }
     }
 }
 

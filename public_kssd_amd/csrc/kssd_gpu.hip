@@ -53,12 +53,12 @@ extern "C" const char *kssd_gpu_strerror(int code)
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define QCAP 256          // per-wave candidate queue (u32: chunk offset << 12 | position), lives across chunks
-#define EBUF 64           // per-wave emission buffer (u32 reduced tuples)
+#define CBUF 128          // per-wave buffer of candidates on their way to the list (u32: chunk offset << 12 | position)
 #define DEDUP_THREADS 256
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
-#define SCAN_LDS_BYTES (KSSD_T1_BYTES + SCAN_WAVES * QCAP * 4 + SCAN_WAVES * EBUF * 4)
+#define SCAN_TAB_BYTES (KSSD_T1_BYTES + KSSD_BLOOM_WORDS * 4)  // stage-1 table + stage-1.5 Bloom filter, contiguous
+#define SCAN_LDS_BYTES (SCAN_TAB_BYTES + SCAN_WAVES * CBUF * 4)
 
 struct SketchStatus {
     unsigned long long total_ids;
@@ -66,6 +66,10 @@ struct SketchStatus {
     unsigned int out_overflow;     // d_out_ids too small
     unsigned int max_need_q8;      // max over genomes of emitted / capacity, in 1/256 units
     unsigned int capacity_genome_p1;  // 1 + first genome over the reference's hash limit (0 = none)
+    // telemetry of the last scan: positions that passed stage 1, that passed the Bloom test
+    unsigned long long n_stage1, n_bloom;
+    unsigned int cand_overflow;    // a shard of the candidate list was too small
+    unsigned int cand_need;        // entries the fullest shard wanted
 };
 
 struct kssd_gpu_ctx {
@@ -85,6 +89,12 @@ struct kssd_gpu_ctx {
     size_t cap_chunk_off, cap_reg_off, cap_cursor, cap_kept;
     uint32_t *d_regions;
     size_t cap_regions;
+    uint64_t *d_cand;       // candidate list of the last scan (one slice per scan wave)
+    size_t cap_cand;
+    uint32_t *d_cand_count;
+    size_t cap_cand_count;
+    uint64_t last_cand_cap;
+    double cand_factor;
     SketchStatus *d_status;
     double region_factor;
     uint32_t last_n_genomes;
@@ -107,14 +117,16 @@ struct kssd_gpu_ctx {
 
 static int ctx_upload_tables(kssd_gpu_ctx *c, const std::vector<uint32_t> &accepted)
 {
-    const KssdParams &P = c->P;
+    KssdParams &P = c->P;  // the builder picks the cuckoo multipliers
     std::vector<uint8_t> T1;
+    std::vector<uint32_t> bloom;
     std::vector<KssdG> G;
-    kssd_build_tables(P, accepted, T1, G);
+    kssd_build_tables(P, accepted, KSSD_GW, T1, bloom, G);
     const size_t gn = G.size();
-    HIPCK(hipMalloc(&c->d_T1, KSSD_T1_BYTES));
+    HIPCK(hipMalloc(&c->d_T1, SCAN_TAB_BYTES));
     HIPCK(hipMalloc(&c->d_G, gn * sizeof(KssdG)));
     HIPCK(hipMemcpy(c->d_T1, T1.data(), KSSD_T1_BYTES, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(c->d_T1 + KSSD_T1_BYTES, bloom.data(), KSSD_BLOOM_WORDS * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(c->d_G, G.data(), gn * sizeof(KssdG), hipMemcpyHostToDevice));
     return KSSD_OK;
 }
@@ -138,6 +150,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
     c->cu_count = prop.multiProcessorCount;
     c->P = P;
     c->region_factor = 2.0;
+    c->cand_factor = 1.5;
     int rc = ctx_upload_tables(c, accepted);
     if (rc != KSSD_OK) { delete c; return rc; }
     if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) {
@@ -203,7 +216,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post};
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (int w = 0; w < 2; w++)
@@ -289,193 +302,233 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
 
 // ---------------------------------------------------------------------------------------------------
 // kernel 1: the scan.  One wave per 4096-position chunk iteration, one lane per 64 positions.
-//   HBM -> registers: 16 B of packed bases + 8 B of mask per lane, coalesced, next chunk prefetched
-//   stage 1: 33 LDS nibble reads per lane decide 64 positions (quad-core table, 128 KiB of LDS)
-//   ballot compaction of the ~0.3 % candidate positions into a per-wave LDS queue that lives ACROSS
-//   chunks: stage 2 only runs on full rounds of 64 candidates (it costs the same for 1 lane as for 64)
-//   stage 2: exact evaluation, survivors staged in LDS and appended to the genome's region
+//   HBM -> registers: 16 B of packed bases + 4 B halo + 8 B of mask per lane, coalesced, two chunks ahead
+//   stage 1    27 LDS byte reads per lane decide 64 positions (group-filter table, 128 KiB of LDS, kssd_core.h)
+//   stage 1.5  the ~0.8 % surviving positions: pattern cut out of the lane's registers, Bloom test in LDS
+//   output     the ~0.06 % that pass (global position, u64) are compacted by ballot into a per-wave LDS buffer
+//              and appended to a candidate list in HBM: 8 B per candidate, ~1 % on top of the streamed bytes
+// The exact evaluation (stage 2) is kernel 1b: it needs scattered reads and 64-bit arithmetic that would
+// cost this kernel registers, SGPRs and issue slots in its hot loop for work done on 1 position in 1 700.
 // ---------------------------------------------------------------------------------------------------
+
 struct ScanArgs {
     const uint32_t *packed;
     const uint32_t *mask;
-    const uint32_t *chunk_gid;
-    const unsigned long long *chunk_off;  // per genome, in chunks
     unsigned long long n_chunks;
-    const uint8_t *T1;
-    const KssdG *G;
-    const unsigned long long *reg_off;
-    uint32_t *cursor;
-    uint32_t *regions;
+    const uint8_t *tab;             // stage-1 table followed by the Bloom filter (SCAN_TAB_BYTES)
+    unsigned long long *cand;       // (waves of the grid) * cand_cap global positions
+    unsigned long long cand_cap;    // per wave
+    uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
+    SketchStatus *status;
 };
 
-__device__ __forceinline__ void flush_emissions(const ScanArgs &a, uint32_t gid, uint32_t n, const uint32_t *ebuf,
-                                                uint32_t lane)
-{
-    // one returning atomic per flush, not per k-mer: a single cursor word saturates at ~90 atomics/us
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&a.cursor[gid], n);
-    base = __builtin_amdgcn_readfirstlane(base);
-    const unsigned long long r0 = a.reg_off[gid];
-    const unsigned long long cap = a.reg_off[gid + 1] - r0;
-    if (lane < n && (unsigned long long)base + lane < cap) a.regions[r0 + base + lane] = ebuf[lane];
-}
-
-// per-wave state of the scan that the helpers below share
-struct WaveState {
-    uint32_t *queue;   // LDS, QCAP entries: (chunk - c0) << 12 | position in chunk
-    uint32_t *ebuf;    // LDS, EBUF reduced tuples waiting for the next region append
-    uint32_t qn;       // queued candidates (wave-uniform)
-    uint32_t ecount;   // staged emissions (wave-uniform)
-    uint32_t gid;      // genome all queued candidates and staged emissions belong to
-    long long glo, ghi;  // positions of that genome: [glo, ghi)
-    unsigned long long c0;
+// one chunk of the lane's share of the stream: 64 positions + halo, and their validity bits
+struct ChunkRegs {
+    uint32_t W[5];
+    uint32_t M[2];
 };
 
-// stage 2 for one round of up to 64 queued candidates (entries [first, first+n) of the queue)
-__device__ __forceinline__ void stage2_round(const KssdParams &P, const ScanArgs &a, WaveState &w, uint32_t first, uint32_t n,
-                                             uint32_t lane)
+__device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long c, uint32_t lane, ChunkRegs &r)
 {
-    bool ok = false;
-    uint32_t dr = 0;
-    if (lane < n) {
-        const uint32_t e = w.queue[first + lane];
-        const long long s = (long long)((w.c0 + (e >> 12)) * KSSD_CHUNK) + (long long)(e & 4095u);
-        ok = kssd_stage2(P, s, w.glo, w.ghi, a.packed, a.mask, a.G, dr);
-    }
-    const uint64_t bal = __ballot(ok);
-    const uint32_t m = __builtin_popcountll(bal);
-    if (m) {
-        if (w.ecount + m > EBUF) {
-            wave_lds_sync();
-            flush_emissions(a, w.gid, w.ecount, w.ebuf, lane);
-            wave_lds_sync();
-            w.ecount = 0;
-        }
-        if (ok) w.ebuf[w.ecount + rank_in(bal)] = dr;
-        w.ecount += m;
+    const uint32_t *pp = a.packed + c * 256 + lane * 4;
+    const uint4 v = *reinterpret_cast<const uint4 *>(pp);
+    r.W[0] = v.x; r.W[1] = v.y; r.W[2] = v.z; r.W[3] = v.w;
+    r.W[4] = pp[4];
+    const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + c * 128 + lane * 2);
+    r.M[0] = m.x; r.M[1] = m.y;
+}
+
+// append the wave's buffered candidates to its slice of the list (plain stores, nothing to wait for)
+__device__ __forceinline__ void flush_candidates(const ScanArgs &a, unsigned long long wid, unsigned long long c0,
+                                                 const uint32_t *cbuf, uint32_t n, uint32_t stored, uint32_t lane)
+{
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t e = cbuf[i];
+        if ((unsigned long long)stored + i < a.cand_cap)
+            a.cand[wid * a.cand_cap + stored + i] = ((c0 + (e >> 12)) << 12) | (e & 4095u);
     }
 }
 
-// run stage 2 on full rounds of 64 (all = false) or on everything that is queued (all = true)
-__device__ __forceinline__ void drain_queue(const KssdParams &P, const ScanArgs &a, WaveState &w, bool all, uint32_t lane)
-{
-    wave_lds_sync();
-    while (w.qn >= 64) {
-        w.qn -= 64;
-        stage2_round(P, a, w, w.qn, 64, lane);
-    }
-    if (all && w.qn) {
-        stage2_round(P, a, w, 0, w.qn, lane);
-        w.qn = 0;
-    }
-    wave_lds_sync();
-}
-
-// ABL != 0: development-only ablations for profiling (1 = loads only, 2 = + stage 1, 3 = + queue push);
-// never used by the product path
+// ABL != 0: development-only ablations for profiling (1 = loads only, 2 = + stage 1, 3 = + stage 1.5 without
+// the candidate list); never used by the product path.
+//
+// Software pipeline of one wave over its chunks (c = the chunk whose candidates are being tested):
+//   HBM   chunk c+2 is being read into registers while chunk c is worked on
+//   LDS   the table reads of alignment A of chunk c+1 are in flight during the merge / Bloom / push work of
+//         chunk c, those of alignment B across the loop edge: at any time one batch of <= 15 reads is
+//         outstanding behind the one being waited for, which is what s_waitcnt lgkmcnt can express
 template <int SUBK, int ABL = 0>
-__global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(KssdParams P, ScanArgs a)
+__global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
 {
+    typedef KssdGrp<SUBK, KSSD_GW> Gp;
     uint32_t abl_acc = 0;
     // static LDS: the table sits at LDS address 0, so its byte reads need no base add
     __shared__ __attribute__((aligned(16))) unsigned char smem[SCAN_LDS_BYTES];
     uint8_t *T1 = smem;
+    const uint32_t *bloom = reinterpret_cast<const uint32_t *>(smem + KSSD_T1_BYTES);
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
-    WaveState w;
-    w.queue = reinterpret_cast<uint32_t *>(smem + KSSD_T1_BYTES) + wave * QCAP;
-    w.ebuf = reinterpret_cast<uint32_t *>(smem + KSSD_T1_BYTES + SCAN_WAVES * QCAP * 4) + wave * EBUF;
-    w.qn = 0;
-    w.ecount = 0;
+    uint32_t *cbuf = reinterpret_cast<uint32_t *>(smem + SCAN_TAB_BYTES) + wave * CBUF;
+    uint32_t cn = 0, stored = 0;  // buffered / already listed candidates (wave-uniform)
 
-    for (uint32_t i = threadIdx.x * 16; i < KSSD_T1_BYTES; i += SCAN_THREADS * 16)
-        *reinterpret_cast<uint4 *>(T1 + i) = *reinterpret_cast<const uint4 *>(a.T1 + i);
+    for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
+        *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
     __syncthreads();
 
-    // static partition: every wave of the grid owns one contiguous run of chunks, so a wave stays inside
-    // one genome for long stretches and concurrent waves append to different genomes
+    // static partition: every wave of the grid owns one contiguous run of chunks
     const unsigned long long total_waves = (unsigned long long)gridDim.x * SCAN_WAVES;
     const unsigned long long wid = (unsigned long long)blockIdx.x * SCAN_WAVES + wave;
     const unsigned long long per = (a.n_chunks + total_waves - 1) / total_waves;
     unsigned long long c0 = wid * per, c1 = c0 + per;
     if (c1 > a.n_chunks) c1 = a.n_chunks;
     if (c0 >= c1) return;
-    w.c0 = c0;
-    w.gid = 0xFFFFFFFFu;
-    w.glo = w.ghi = 0;
+    const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
+    uint32_t n_stage1 = 0, n_bloom = 0;  // telemetry (wave-uniform)
 
-    uint32_t W[5], M[2];
-    {
-        const uint4 v = *reinterpret_cast<const uint4 *>(a.packed + c0 * 256 + lane * 4);
-        W[0] = v.x; W[1] = v.y; W[2] = v.z; W[3] = v.w;
-        W[4] = a.packed[c0 * 256 + lane * 4 + 4];
-        const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + c0 * 128 + lane * 2);
-        M[0] = m.x; M[1] = m.y;
-    }
-    uint32_t gid_next = a.chunk_gid[c0];
+    // prologue: chunk c0 through both alignments, chunk c0+1 requested
+    ChunkRegs cur, nxt, far;
+    uint32_t raw[Gp::NMAX];
+    uint32_t alo, ahi;
+    load_chunk(a, c0, lane, cur);
+    load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, nxt);
+    kssd_grp_issue<SUBK, KSSD_GW, 0>(cur.W, T1, raw);
+    kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
+    kssd_grp_issue<SUBK, KSSD_GW, 1>(cur.W, T1, raw);  // alignment B of chunk c0 in flight
+
     for (unsigned long long c = c0; c < c1; ++c) {
-        // prefetch the next chunk while this one is processed
-        uint32_t Wn[5] = {0, 0, 0, 0, 0}, Mn[2] = {0, 0};
-        const uint32_t gid = gid_next;
-        if (c + 1 < c1) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.packed + (c + 1) * 256 + lane * 4);
-            Wn[0] = v.x; Wn[1] = v.y; Wn[2] = v.z; Wn[3] = v.w;
-            Wn[4] = a.packed[(c + 1) * 256 + lane * 4 + 4];
-            const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + (c + 1) * 128 + lane * 2);
-            Mn[0] = m.x; Mn[1] = m.y;
-            gid_next = a.chunk_gid[c + 1];
-        }
+        // state: cur = chunk c, nxt = chunk c+1 (requested an iteration ago), raw = alignment-B reads of
+        //        chunk c (in flight), alo/ahi = alignment A of chunk c
+        load_chunk(a, c + 2 < clast ? c + 2 : clast, lane, far);
+        uint32_t rawa[Gp::NMAX];
+        if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
         if (ABL == 1) {
-            abl_acc ^= W[0] ^ W[1] ^ W[2] ^ W[3] ^ W[4] ^ M[0] ^ M[1] ^ gid;
+            abl_acc ^= cur.W[0] ^ cur.W[1] ^ cur.W[2] ^ cur.W[3] ^ cur.W[4] ^ cur.M[0] ^ cur.M[1];
         } else {
-            if (gid != w.gid) {
-                // genome boundary: everything queued or staged belongs to the previous genome
-                if (w.qn) drain_queue(P, a, w, true, lane);
-                if (w.ecount) { wave_lds_sync(); flush_emissions(a, w.gid, w.ecount, w.ebuf, lane); wave_lds_sync(); }
-                w.ecount = 0;
-                w.gid = gid;
-                w.glo = (long long)(a.chunk_off[gid] * KSSD_CHUNK);
-                w.ghi = (long long)(a.chunk_off[gid + 1] * KSSD_CHUNK);
-            }
-            uint32_t cl, ch;
-            kssd_stage1<SUBK>(W, T1, cl, ch);
-            cl &= M[0];  // the window start itself must be a base: kills padding / N stretches early
-            ch &= M[1];
+            uint32_t blo, bhi;
+            kssd_grp_merge<SUBK, KSSD_GW, 1>(raw, blo, bhi);  // waits for the B reads of chunk c only
+            uint32_t cl = alo & blo & cur.M[0];  // the window start itself must be a base: kills padding / N stretches early
+            uint32_t ch = ahi & bhi & cur.M[1];
             if (ABL == 2) {
                 abl_acc ^= cl ^ ch;
             } else {
-                // ballot compaction: every pass moves one candidate of every lane that still has one
+                // every pass takes one candidate of every lane that still has one: cut its pattern out of the lane's
+                // registers, Bloom-test it against S, buffer the survivors by ballot compaction
                 const uint32_t ebase = ((uint32_t)(c - c0) << 12) | (lane << 6);
                 for (;;) {
                     const bool has = (cl | ch) != 0;
-                    const uint64_t bal = __ballot(has);
-                    if (!bal) break;
-                    if (w.qn + 64 > QCAP) drain_queue(P, a, w, false, lane);
+                    const uint64_t hbal = __ballot(has);
+                    if (!hbal) break;
+                    n_stage1 += __builtin_popcountll(hbal);
+                    bool pass = false;
+                    uint32_t b = 0;
                     if (has) {
-                        uint32_t b;
                         if (cl) { b = __builtin_ctz(cl); cl &= cl - 1; }
                         else { b = 32 + __builtin_ctz(ch); ch &= ch - 1; }
-                        w.queue[w.qn + rank_in(bal)] = ebase | b;
+                        const uint32_t h = kssd_bloom_hash(kssd_extract_m<SUBK>(cur.W, b));
+                        const uint32_t bits = kssd_bloom_bits(h);
+                        pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
                     }
-                    w.qn += __builtin_popcountll(bal);
-                }
-                if (ABL == 3) {
-                    if (w.qn >= 64) { wave_lds_sync(); abl_acc ^= w.queue[lane]; w.qn = 0; wave_lds_sync(); }
-                } else if (w.qn >= 64) {
-                    drain_queue(P, a, w, false, lane);
+                    const uint64_t bal = __ballot(pass);
+                    if (bal) {
+                        if (pass) cbuf[cn + rank_in(bal)] = ebase | b;
+                        cn += __builtin_popcountll(bal);
+                        n_bloom += __builtin_popcountll(bal);
+                        if (cn >= 64) {  // room for another pass of up to 64 is needed
+                            wave_lds_sync();
+                            if (ABL == 0) flush_candidates(a, wid, c0, cbuf, cn, stored, lane);
+                            else abl_acc ^= cbuf[lane];
+                            wave_lds_sync();
+                            stored += cn;
+                            cn = 0;
+                        }
+                    }
                 }
             }
+            // chunk c+1: alignment A is in, alignment B goes in flight across the loop edge
+            kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
+            kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
         }
-#pragma unroll
-        for (int i = 0; i < 5; i++) W[i] = Wn[i];
-        M[0] = Mn[0];
-        M[1] = Mn[1];
+        cur = nxt;
+        nxt = far;
     }
-    if (ABL == 0 || ABL == 3) {
-        if (w.qn && ABL == 0) drain_queue(P, a, w, true, lane);
-        if (w.ecount) { wave_lds_sync(); flush_emissions(a, w.gid, w.ecount, w.ebuf, lane); }
+    if (ABL == 0 && cn) { wave_lds_sync(); flush_candidates(a, wid, c0, cbuf, cn, stored, lane); }
+    if (lane == 0) {
+        a.cand_count[wid] = stored + cn;
+        atomicAdd(&a.status->n_stage1, (unsigned long long)n_stage1);
+        atomicAdd(&a.status->n_bloom, (unsigned long long)n_bloom);
     }
-    if (ABL != 0 && abl_acc == 0x9e3779b9u) a.regions[0] = abl_acc;  // keeps the ablated work alive
+    if (ABL != 0) {
+        for (int i = 0; i < Gp::NMAX; i++) abl_acc ^= raw[i];
+        if (abl_acc == 0x9e3779b9u) a.cand[0] = abl_acc;  // keeps the ablated work alive
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel 1b: stage 2, the exact evaluation of the candidates (kssd_stage2 in kssd_core.h: validity of all
+// 2k bases, canonical strand, sub-context -> rank through the cuckoo table, reduced tuple), one lane per
+// candidate at full occupancy.  Survivors are appended to their genome's staging region with one returning
+// atomic per wave and genome.
+// ---------------------------------------------------------------------------------------------------
+struct ExactArgs {
+    const uint32_t *packed;
+    const uint32_t *mask;
+    const uint32_t *chunk_gid;
+    const unsigned long long *chunk_off;  // per genome, in chunks
+    const KssdG *G;
+    const unsigned long long *cand;
+    unsigned long long cand_cap;
+    const uint32_t *cand_count;
+    uint32_t n_slices;
+    const unsigned long long *reg_off;
+    uint32_t *cursor;
+    uint32_t *regions;
+    SketchStatus *status;
+};
+
+__global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactArgs x)
+{
+    const uint32_t lane = lane_id();
+    const unsigned long long total = (unsigned long long)x.n_slices * x.cand_cap;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    if (blockIdx.x == 0)
+        for (uint32_t w = threadIdx.x; w < x.n_slices; w += blockDim.x)
+            if (x.cand_count[w] > x.cand_cap) {
+                atomicOr(&x.status->cand_overflow, 1u);
+                atomicMax(&x.status->cand_need, x.cand_count[w]);
+            }
+    // wave-uniform trip count: the emission below uses ballots
+    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < total; base += stride) {
+        const unsigned long long idx = base + threadIdx.x;
+        bool ok = false;
+        uint32_t dr = 0, gid = 0;
+        if (idx < total) {
+            const uint32_t shard = (uint32_t)(idx / x.cand_cap);  // = the scan wave that listed it
+            const unsigned long long i = idx - shard * x.cand_cap;
+            if (i < x.cand_count[shard]) {
+                const unsigned long long s = x.cand[idx];
+                gid = x.chunk_gid[s >> 12];
+                const long long glo = (long long)(x.chunk_off[gid] * KSSD_CHUNK), ghi = (long long)(x.chunk_off[gid + 1] * KSSD_CHUNK);
+                ok = kssd_stage2(P, (long long)s, glo, ghi, x.packed, x.mask, x.G, dr);
+            }
+        }
+        // group the wave's survivors by genome (candidates arrive in stream order: almost always one genome)
+        uint64_t todo = __ballot(ok);
+        while (todo) {
+            const uint32_t leader = __builtin_ctzll(todo);
+            const uint32_t g = __builtin_amdgcn_readlane(gid, leader);
+            const bool mine = ok && gid == g;
+            const uint64_t grp = __ballot(mine);
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(&x.cursor[g], (uint32_t)__builtin_popcountll(grp));
+            at = __builtin_amdgcn_readlane(at, leader);
+            if (mine) {
+                const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
+                const unsigned long long pos = (unsigned long long)at + rank_in(grp);
+                if (pos < cap) x.regions[r0 + pos] = dr;
+            }
+            todo &= ~grp;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -627,7 +680,7 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
 template <int SUBK, int ABL = 0>
 static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, c->P, a);
+    hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -676,6 +729,16 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     if ((rc = ensure(&c->d_cursor, &c->cap_cursor, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_kept, &c->cap_kept, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_regions, &c->cap_regions, (size_t)acc + 1)) != KSSD_OK) return rc;
+    // candidate list between the scan and the exact stage: patterns of S (both strands) + Bloom false positives
+    // (one private slice per wave of the scan grid)
+    const uint64_t want_blocks = (n_chunks + SCAN_WAVES - 1) / SCAN_WAVES;
+    const int grid = (int)(want_blocks < (uint64_t)c->cu_count ? want_blocks : (uint64_t)c->cu_count);
+    const uint32_t n_slices = (uint32_t)(grid > 0 ? grid : 1) * SCAN_WAVES;
+    const uint64_t cand_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * (2.0 * rate + 0.0005) * c->cand_factor / n_slices) + 256;
+    if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
+    c->last_cand_cap = cand_cap;
+    HIPCK(hipMemsetAsync(c->d_cand_count, 0, (size_t)n_slices * 4, s));
 
     HIPCK(hipMemcpyAsync(c->d_chunk_off, h_chunk_off, ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCK(hipMemcpyAsync(c->d_reg_off, c->h_reg_off.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
@@ -684,12 +747,9 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, n_genomes, n_chunks, c->d_chunk_gid);
         ScanArgs a;
-        a.packed = d_packed; a.mask = d_mask; a.chunk_gid = c->d_chunk_gid; a.n_chunks = n_chunks;
-        a.chunk_off = (const unsigned long long *)c->d_chunk_off;
-        a.T1 = c->d_T1; a.G = c->d_G; a.reg_off = (const unsigned long long *)c->d_reg_off;
-        a.cursor = c->d_cursor; a.regions = c->d_regions;
-        uint64_t want = (n_chunks + SCAN_WAVES - 1) / SCAN_WAVES;
-        int grid = (int)(want < (uint64_t)c->cu_count ? want : (uint64_t)c->cu_count);
+        a.packed = d_packed; a.mask = d_mask; a.n_chunks = n_chunks; a.tab = c->d_T1;
+        a.cand = (unsigned long long *)c->d_cand; a.cand_cap = cand_cap; a.cand_count = c->d_cand_count;
+        a.status = c->d_status;
         const unsigned evi = c->ev_n[0] % EV_RING;
         HIPCK(hipEventRecord(c->ev_a[0][evi], s));
         switch (c->P.subk) {
@@ -711,6 +771,15 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         if (rc != KSSD_OK) return rc;
         HIPCK(hipEventRecord(c->ev_b[0][evi], s));
         c->ev_n[0]++;
+        ExactArgs x;
+        x.packed = d_packed; x.mask = d_mask; x.chunk_gid = c->d_chunk_gid;
+        x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;
+        x.cand = (const unsigned long long *)c->d_cand; x.cand_cap = cand_cap; x.cand_count = c->d_cand_count;
+        x.n_slices = n_slices;
+        x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
+        x.status = c->d_status;
+        const uint64_t eblocks = (cand_cap * n_slices + 255) / 256;
+        hipLaunchKernelGGL(sketch_exact_kernel, dim3((unsigned)(eblocks < 65536 ? eblocks : 65536)), dim3(256), 0, s, c->P, x);
     }
     uint32_t np = 1;
     while (np < max_cap) np <<= 1;
@@ -741,6 +810,11 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
     HIPCK(hipMemcpyAsync(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     if (total_ids) *total_ids = st.total_ids;
+    if (st.cand_overflow) {
+        const double need = (double)st.cand_need / (double)(c->last_cand_cap ? c->last_cand_cap : 1);
+        c->cand_factor *= (need > 1.0 ? need : 1.0) * 1.5;
+        return KSSD_ERR_OVERFLOW;
+    }
     if (st.region_overflow) {
         double need = (double)st.max_need_q8 / 256.0;  // emitted / capacity of the worst genome
         c->region_factor *= (need > 1.0 ? need : 1.0) * 1.25;
@@ -751,6 +825,19 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
         if (bad_genome) *bad_genome = (int64_t)(0xFFFFFFFFu - st.capacity_genome_p1);
         return KSSD_ERR_CAPACITY;
     }
+    return KSSD_OK;
+}
+
+extern "C" int kssd_gpu_scan_stats(kssd_gpu_ctx *c, uint64_t *stage1, uint64_t *bloom, void *stream)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(hipSetDevice(c->device));
+    SketchStatus st;
+    HIPCK(hipMemcpyAsync(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    if (stage1) *stage1 = st.n_stage1;
+    if (bloom) *bloom = st.n_bloom;
     return KSSD_OK;
 }
 

@@ -8,9 +8,9 @@
 #include <vector>
 #include "../../public_kssd_amd/csrc/kssd_core.h"
 
-template <int SUBK>
+template <int SUBK, int GW>
 static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mask, uint64_t n_chunks, const uint32_t *gid,
-                const uint8_t *T1, const KssdG *G, std::vector<uint64_t> &out, uint64_t *n_cand)
+                const uint8_t *T1, const uint32_t *bloom, const KssdG *G, std::vector<uint64_t> &out, uint64_t *n_cand)
 {
     const int64_t total = (int64_t)n_chunks * KSSD_CHUNK;
     for (uint64_t c = 0; c < n_chunks; c++) {
@@ -23,13 +23,17 @@ static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mas
             uint32_t W[5];
             for (int i = 0; i < 5; i++) W[i] = packed[c * 256 + lane * 4 + i];
             uint32_t cl, ch;
-            kssd_stage1<SUBK>(W, T1, cl, ch);
+            kssd_stage1g<SUBK, GW>(W, T1, cl, ch);
             cl &= mask[c * 128 + lane * 2];
             ch &= mask[c * 128 + lane * 2 + 1];
             for (int b = 0; b < 64; b++) {
                 const uint32_t bit = b < 32 ? (cl >> b) & 1u : (ch >> (b - 32)) & 1u;
                 if (!bit) continue;
-                (*n_cand)++;
+                n_cand[0]++;
+                const uint32_t h = kssd_bloom_hash(kssd_extract_m<SUBK>(W, (uint32_t)b));
+                const uint32_t bits = kssd_bloom_bits(h);
+                if ((bloom[kssd_bloom_word(h)] & bits) != bits) continue;
+                n_cand[1]++;
                 uint32_t dr;
                 if (kssd_stage2(P, cbeg + lane * 64 + b, lo, hi, packed, mask, G, dr)) out.push_back(((uint64_t)gid[c] << 32) | dr);
             }
@@ -57,26 +61,32 @@ static void run_all(const KssdParams &P, const uint32_t *packed, const uint32_t 
 
 extern "C" long emu_sketch(int k, int subk, int drlevel, const int32_t *table, const uint32_t *packed, const uint32_t *mask,
                            uint64_t n_chunks, const uint32_t *chunk_gid, int brute, uint64_t *out, uint64_t cap,
-                           uint64_t *n_cand)
+                           uint64_t *n_cand, int gw)
 {
     KssdParams P;
     if (kssd_params_init(&P, k, subk, drlevel) != 0) return -1;
     std::vector<uint32_t> acc;
     if (!kssd_accepted_from_table(P, table, acc)) return -2;
     std::vector<uint8_t> T1;
+    std::vector<uint32_t> bloom;
     std::vector<KssdG> G;
-    kssd_build_tables(P, acc, T1, G);
+    if (gw == 0) gw = KSSD_GW;
+    kssd_build_tables(P, acc, gw, T1, bloom, G);
     std::vector<uint64_t> res;
-    *n_cand = 0;
+    n_cand[0] = n_cand[1] = 0;  // after stage 1, after stage 1.5
     if (brute) run_all(P, packed, mask, n_chunks, chunk_gid, G.data(), res);
-    else switch (subk) {
-        case 2: run<2>(P, packed, mask, n_chunks, chunk_gid, T1.data(), G.data(), res, n_cand); break;
-        case 3: run<3>(P, packed, mask, n_chunks, chunk_gid, T1.data(), G.data(), res, n_cand); break;
-        case 4: run<4>(P, packed, mask, n_chunks, chunk_gid, T1.data(), G.data(), res, n_cand); break;
-        case 5: run<5>(P, packed, mask, n_chunks, chunk_gid, T1.data(), G.data(), res, n_cand); break;
-        case 6: run<6>(P, packed, mask, n_chunks, chunk_gid, T1.data(), G.data(), res, n_cand); break;
-        case 7: run<7>(P, packed, mask, n_chunks, chunk_gid, T1.data(), G.data(), res, n_cand); break;
-        default: return -3;
+    else {
+#define RUN(S)                                                                                           \
+    case S:                                                                                              \
+        if (gw == 4) run<S, 4>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand); \
+        else if (gw == 5) run<S, 5>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand); \
+        else return -5;                                                                                  \
+        break;
+        switch (subk) {
+            RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
+            default: return -3;
+        }
+#undef RUN
     }
     if (res.size() > cap) return -4;
     memcpy(out, res.data(), res.size() * 8);
