@@ -53,12 +53,12 @@ extern "C" const char *kssd_gpu_strerror(int code)
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define CBUF 128          // per-wave buffer of candidates on their way to the list (u32: chunk offset << 12 | position)
+#define CBUF 128          // per-wave buffer of stage-1 candidates waiting for the Bloom test (8 B each)
 #define DEDUP_THREADS 256
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
 #define SCAN_TAB_BYTES (KSSD_T1_BYTES + KSSD_BLOOM_WORDS * 4)  // stage-1 table + stage-1.5 Bloom filter, contiguous
-#define SCAN_LDS_BYTES (SCAN_TAB_BYTES + SCAN_WAVES * CBUF * 4)
+#define SCAN_LDS_BYTES (SCAN_TAB_BYTES + SCAN_WAVES * CBUF * 8)
 
 struct SketchStatus {
     unsigned long long total_ids;
@@ -338,22 +338,36 @@ __device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long
     r.M[0] = m.x; r.M[1] = m.y;
 }
 
-// append the wave's buffered candidates to its slice of the list (plain stores, nothing to wait for)
-__device__ __forceinline__ void flush_candidates(const ScanArgs &a, unsigned long long wid, unsigned long long c0,
-                                                 const uint32_t *cbuf, uint32_t n, uint32_t stored, uint32_t lane)
+// Stage 1.5 for up to 64 buffered stage-1 candidates (entries [first, first+n) of the wave's buffer): Bloom test
+// of the pattern the owning lane cut out of its registers, survivors go straight to the wave's slice of the
+// candidate list (plain stores, nothing to wait for).  Returns how many survived (wave-uniform).
+template <int ABL>
+__device__ __forceinline__ uint32_t bloom_round(const ScanArgs &a, const uint32_t *bloom, unsigned long long wid,
+                                                unsigned long long c0, const uint2 *cbuf, uint32_t first, uint32_t n,
+                                                uint32_t stored, uint32_t lane, uint32_t &abl_acc)
 {
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t e = cbuf[i];
-        if ((unsigned long long)stored + i < a.cand_cap)
-            a.cand[wid * a.cand_cap + stored + i] = ((c0 + (e >> 12)) << 12) | (e & 4095u);
+    bool pass = false;
+    uint2 e = make_uint2(0u, 0u);
+    if (lane < n) {
+        e = cbuf[first + lane];
+        const uint32_t h = kssd_bloom_hash(e.y);
+        const uint32_t bits = kssd_bloom_bits(h);
+        pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
     }
+    const uint64_t bal = __ballot(pass);
+    if (pass) {
+        const unsigned long long at = (unsigned long long)stored + rank_in(bal);
+        if (ABL != 0) abl_acc ^= e.x;
+        else if (at < a.cand_cap) a.cand[wid * a.cand_cap + at] = ((c0 + (e.x >> 12)) << 12) | (e.x & 4095u);
+    }
+    return (uint32_t)__builtin_popcountll(bal);
 }
 
 // ABL != 0: development-only ablations for profiling (1 = loads only, 2 = + stage 1, 3 = + stage 1.5 without
 // the candidate list); never used by the product path.
 //
 // Software pipeline of one wave over its chunks (c = the chunk whose candidates are being tested):
-//   HBM   chunk c+2 is being read into registers while chunk c is worked on
+//   HBM   chunks c+2 and c+3 are being read into registers while chunk c is worked on
 //   LDS   the table reads of alignment A of chunk c+1 are in flight during the merge / Bloom / push work of
 //         chunk c, those of alignment B across the loop edge: at any time one batch of <= 15 reads is
 //         outstanding behind the one being waited for, which is what s_waitcnt lgkmcnt can express
@@ -368,8 +382,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const uint32_t *bloom = reinterpret_cast<const uint32_t *>(smem + KSSD_T1_BYTES);
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
-    uint32_t *cbuf = reinterpret_cast<uint32_t *>(smem + SCAN_TAB_BYTES) + wave * CBUF;
-    uint32_t cn = 0, stored = 0;  // buffered / already listed candidates (wave-uniform)
+    uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // (chunk offset << 12 | position, pattern)
+    uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
     for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
@@ -385,20 +399,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
     uint32_t n_stage1 = 0, n_bloom = 0;  // telemetry (wave-uniform)
 
-    // prologue: chunk c0 through both alignments, chunk c0+1 requested
-    ChunkRegs cur, nxt, far;
+    // prologue: chunk c0 through both alignments, chunks c0+1 and c0+2 requested
+    ChunkRegs r0, r1, r2, r3;
     uint32_t raw[Gp::NMAX];
     uint32_t alo, ahi;
-    load_chunk(a, c0, lane, cur);
-    load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, nxt);
-    kssd_grp_issue<SUBK, KSSD_GW, 0>(cur.W, T1, raw);
+    load_chunk(a, c0, lane, r0);
+    load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, r1);
+    load_chunk(a, c0 + 2 < clast ? c0 + 2 : clast, lane, r2);
+    kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
     kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
-    kssd_grp_issue<SUBK, KSSD_GW, 1>(cur.W, T1, raw);  // alignment B of chunk c0 in flight
+    kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of chunk c0 in flight
 
-    for (unsigned long long c = c0; c < c1; ++c) {
-        // state: cur = chunk c, nxt = chunk c+1 (requested an iteration ago), raw = alignment-B reads of
+    // one chunk.  The four register sets rotate by name (the loop below is unrolled four times): copying one
+    // set into another would make every iteration wait for the reads it has just issued.
+    auto step = [&](const ChunkRegs &cur, const ChunkRegs &nxt, ChunkRegs &far, const unsigned long long c) {
+        // state: cur = chunk c, nxt = chunk c+1 (requested two iterations ago), chunk c+2 in flight, far = free, raw = alignment-B reads of
         //        chunk c (in flight), alo/ahi = alignment A of chunk c
-        load_chunk(a, c + 2 < clast ? c + 2 : clast, lane, far);
+        load_chunk(a, c + 3 < clast ? c + 3 : clast, lane, far);
         uint32_t rawa[Gp::NMAX];
         if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
         if (ABL == 1) {
@@ -412,48 +429,60 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 abl_acc ^= cl ^ ch;
             } else {
                 // every pass takes one candidate of every lane that still has one: cut its pattern out of the lane's
-                // registers, Bloom-test it against S, buffer the survivors by ballot compaction
+                // registers and buffer (position, pattern) by ballot compaction.  No LDS read in this loop: a read
+                // would have to wait behind the table reads of chunk c+1 that are in flight
                 const uint32_t ebase = ((uint32_t)(c - c0) << 12) | (lane << 6);
                 for (;;) {
                     const bool has = (cl | ch) != 0;
                     const uint64_t hbal = __ballot(has);
                     if (!hbal) break;
-                    n_stage1 += __builtin_popcountll(hbal);
-                    bool pass = false;
-                    uint32_t b = 0;
+                    if (cn + 64 > CBUF) {  // dense parameter sets only: make room
+                        wave_lds_sync();
+                        const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - 64, 64, stored, lane, abl_acc);
+                        stored += m;
+                        n_bloom += m;
+                        cn -= 64;
+                        wave_lds_sync();
+                    }
                     if (has) {
+                        uint32_t b;
                         if (cl) { b = __builtin_ctz(cl); cl &= cl - 1; }
                         else { b = 32 + __builtin_ctz(ch); ch &= ch - 1; }
-                        const uint32_t h = kssd_bloom_hash(kssd_extract_m<SUBK>(cur.W, b));
-                        const uint32_t bits = kssd_bloom_bits(h);
-                        pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
+                        cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b, kssd_extract_m<SUBK>(cur.W, b));
                     }
-                    const uint64_t bal = __ballot(pass);
-                    if (bal) {
-                        if (pass) cbuf[cn + rank_in(bal)] = ebase | b;
-                        cn += __builtin_popcountll(bal);
-                        n_bloom += __builtin_popcountll(bal);
-                        if (cn >= 64) {  // room for another pass of up to 64 is needed
-                            wave_lds_sync();
-                            if (ABL == 0) flush_candidates(a, wid, c0, cbuf, cn, stored, lane);
-                            else abl_acc ^= cbuf[lane];
-                            wave_lds_sync();
-                            stored += cn;
-                            cn = 0;
-                        }
-                    }
+                    cn += __builtin_popcountll(hbal);
+                    n_stage1 += __builtin_popcountll(hbal);
                 }
             }
-            // chunk c+1: alignment A is in, alignment B goes in flight across the loop edge
+            // chunk c+1: alignment A is in; nothing is outstanding in LDS now, which is the cheap moment for a
+            // stage-1.5 round; then alignment B goes in flight across the loop edge
             kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
+            if (ABL != 2 && cn >= 64) {
+                wave_lds_sync();
+                const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - 64, 64, stored, lane, abl_acc);
+                stored += m;
+                n_bloom += m;
+                cn -= 64;
+            }
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
         }
-        cur = nxt;
-        nxt = far;
+    };
+    for (unsigned long long c = c0; c < c1; c += 4) {
+        step(r0, r1, r3, c);
+        if (c + 1 < c1) step(r1, r2, r0, c + 1);
+        if (c + 2 < c1) step(r2, r3, r1, c + 2);
+        if (c + 3 < c1) step(r3, r0, r2, c + 3);
     }
-    if (ABL == 0 && cn) { wave_lds_sync(); flush_candidates(a, wid, c0, cbuf, cn, stored, lane); }
+    while (cn) {
+        const uint32_t n = cn < 64 ? cn : 64;
+        wave_lds_sync();
+        const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - n, n, stored, lane, abl_acc);
+        stored += m;
+        n_bloom += m;
+        cn -= n;
+    }
     if (lane == 0) {
-        a.cand_count[wid] = stored + cn;
+        a.cand_count[wid] = stored;
         atomicAdd(&a.status->n_stage1, (unsigned long long)n_stage1);
         atomicAdd(&a.status->n_bloom, (unsigned long long)n_bloom);
     }
