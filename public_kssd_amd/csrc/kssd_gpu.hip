@@ -516,47 +516,56 @@ struct ExactArgs {
 
 __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactArgs x)
 {
+    // grid = (blocks per slice, slices): block (bx, w) takes candidates [256 bx, 256 bx + 256) of scan wave w
     const uint32_t lane = lane_id();
-    const unsigned long long total = (unsigned long long)x.n_slices * x.cand_cap;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    if (blockIdx.x == 0)
-        for (uint32_t w = threadIdx.x; w < x.n_slices; w += blockDim.x)
-            if (x.cand_count[w] > x.cand_cap) {
-                atomicOr(&x.status->cand_overflow, 1u);
-                atomicMax(&x.status->cand_need, x.cand_count[w]);
-            }
-    // wave-uniform trip count: the emission below uses ballots
-    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < total; base += stride) {
-        const unsigned long long idx = base + threadIdx.x;
-        bool ok = false;
-        uint32_t dr = 0, gid = 0;
-        if (idx < total) {
-            const uint32_t shard = (uint32_t)(idx / x.cand_cap);  // = the scan wave that listed it
-            const unsigned long long i = idx - shard * x.cand_cap;
-            if (i < x.cand_count[shard]) {
-                const unsigned long long s = x.cand[idx];
-                gid = x.chunk_gid[s >> 12];
-                const long long glo = (long long)(x.chunk_off[gid] * KSSD_CHUNK), ghi = (long long)(x.chunk_off[gid + 1] * KSSD_CHUNK);
-                ok = kssd_stage2(P, (long long)s, glo, ghi, x.packed, x.mask, x.G, dr);
-            }
+    const uint32_t w = blockIdx.y;
+    const uint32_t want = x.cand_count[w];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && want > x.cand_cap) {
+        atomicOr(&x.status->cand_overflow, 1u);
+        atomicMax(&x.status->cand_need, want);
+    }
+    const uint32_t n = want < x.cand_cap ? want : (uint32_t)x.cand_cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n) return;  // whole block past the end of the slice
+    bool ok = false;
+    uint32_t dr = 0, gid = 0;
+    if (i < n) {
+        // same arithmetic as kssd_stage2 (kssd_core.h), arranged so that the reads that do not depend on each
+        // other are issued together: {genome of the chunk, packed words, mask words}, then {genome bounds, both
+        // cuckoo slots} -- three memory round trips instead of five.  Out-of-genome k-mers are rejected at the end;
+        // their reads stay inside the batch (position clamped at 0, slack words after the last chunk).
+        const long long s = (long long)x.cand[(unsigned long long)w * x.cand_cap + i];
+        const long long b0 = s - P.out;
+        const unsigned long long b0c = b0 < 0 ? 0ull : (unsigned long long)b0;
+        gid = x.chunk_gid[(unsigned long long)s >> 12];
+        const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
+        const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], m0 = mp[0], m1 = mp[1];
+        uint64_t u;
+        uint32_t dim;
+        const bool valid = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u, dim);
+        const KssdG e1 = x.G[kssd_g_slot(dim, P.g_mul[0], P.g_log2)];
+        const KssdG e2 = x.G[(1u << P.g_log2) + kssd_g_slot(dim, P.g_mul[1], P.g_log2)];
+        const long long glo = (long long)(x.chunk_off[gid] * KSSD_CHUNK), ghi = (long long)(x.chunk_off[gid + 1] * KSSD_CHUNK);
+        const bool h1 = e1.key == dim, h2 = e2.key == dim;
+        ok = valid && (h1 || h2) && b0 >= glo && b0 + P.nb <= ghi;
+        dr = kssd_s2_tuple(P, u, h1 ? e1.rank : e2.rank);
+    }
+    // group the wave's survivors by genome (candidates arrive in stream order: almost always one genome)
+    uint64_t todo = __ballot(ok);
+    while (todo) {
+        const uint32_t leader = __builtin_ctzll(todo);
+        const uint32_t g = __builtin_amdgcn_readlane(gid, leader);
+        const bool mine = ok && gid == g;
+        const uint64_t grp = __ballot(mine);
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(&x.cursor[g], (uint32_t)__builtin_popcountll(grp));
+        at = __builtin_amdgcn_readlane(at, leader);
+        if (mine) {
+            const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
+            const unsigned long long pos = (unsigned long long)at + rank_in(grp);
+            if (pos < cap) x.regions[r0 + pos] = dr;
         }
-        // group the wave's survivors by genome (candidates arrive in stream order: almost always one genome)
-        uint64_t todo = __ballot(ok);
-        while (todo) {
-            const uint32_t leader = __builtin_ctzll(todo);
-            const uint32_t g = __builtin_amdgcn_readlane(gid, leader);
-            const bool mine = ok && gid == g;
-            const uint64_t grp = __ballot(mine);
-            uint32_t at = 0;
-            if (lane == leader) at = atomicAdd(&x.cursor[g], (uint32_t)__builtin_popcountll(grp));
-            at = __builtin_amdgcn_readlane(at, leader);
-            if (mine) {
-                const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
-                const unsigned long long pos = (unsigned long long)at + rank_in(grp);
-                if (pos < cap) x.regions[r0 + pos] = dr;
-            }
-            todo &= ~grp;
-        }
+        todo &= ~grp;
     }
 }
 
@@ -807,8 +816,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         x.n_slices = n_slices;
         x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
         x.status = c->d_status;
-        const uint64_t eblocks = (cand_cap * n_slices + 255) / 256;
-        hipLaunchKernelGGL(sketch_exact_kernel, dim3((unsigned)(eblocks < 65536 ? eblocks : 65536)), dim3(256), 0, s, c->P, x);
+        hipLaunchKernelGGL(sketch_exact_kernel, dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
     }
     uint32_t np = 1;
     while (np < max_cap) np <<= 1;
