@@ -32,7 +32,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_create_for_dist",
     "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
-    "kssd_gpu_dist", "kssd_gpu_kernel_time",
+    "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats",
 ]
 
 
@@ -106,6 +106,7 @@ def gpu_lib():
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
+        L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
         _gpu = L
     return _gpu
 
@@ -450,6 +451,12 @@ class GpuCtx:
                     stream=None):
         _gck(gpu_lib().kssd_gpu_dist_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_shared),
                                             _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
+
+    def scan_stats(self, stream=None):
+        """(positions that passed the stage-1 filter, positions that also passed the Bloom test) of the last scan"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _gck(gpu_lib().kssd_gpu_scan_stats(self.h, C.byref(a), C.byref(b), stream))
+        return a.value, b.value
 
     def kernel_time(self, which, reset=False):
         """(average ms, launches) of the dominant kernel: 0 = sketch scan, 1 = distance rows"""

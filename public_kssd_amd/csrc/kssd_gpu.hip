@@ -6,6 +6,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC kssd_gpu.hip -o libkssd_gpu.so
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,6 +101,11 @@ struct kssd_gpu_ctx {
     uint32_t last_n_genomes;
     int last_launch_rc;
     std::vector<uint64_t> h_reg_off;
+    std::vector<uint32_t> h_big;  // genomes of the last batch that take the global-memory dedup path
+    uint32_t *d_big_alt;          // sort output | tile counts | 2 accumulators
+    size_t cap_big_alt;
+    void *d_big_tmp;              // rocPRIM temporary storage
+    size_t cap_big_tmp;
     // inverted index (dist)
     uint32_t n_ref;
     uint64_t n_ref_ids;
@@ -216,7 +222,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count};
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (int w = 0; w < 2; w++)
@@ -594,10 +600,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum /
 __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
                                                                       const uint32_t *__restrict__ cursor,
                                                                       uint32_t *__restrict__ regions, uint32_t *__restrict__ kept,
-                                                                      uint32_t flags, uint32_t min_occ, SketchStatus *st)
+                                                                      uint32_t flags, uint32_t min_occ, uint32_t big_min,
+                                                                      SketchStatus *st)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *a = reinterpret_cast<uint32_t *>(smem);
+    if (reg_off[blockIdx.x + 1] - reg_off[blockIdx.x] > big_min) return;  // too large for LDS: the global-memory path below
     __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
     __shared__ uint32_t s_distinct, s_zero_occ;
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
@@ -673,6 +681,110 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kernel 2b: dedup of a genome whose staged tuples do not fit LDS (> DEDUP_MAX_N: > ~60 Mb at L3K10, FASTQ
+// runs, chromosomes).  The staging region is padded with 0xFFFFFFFF, sorted by rocPRIM's device radix sort
+// (a plain library sort: not worth a hand-written kernel for a handful of genomes per batch), then the same
+// keep rules as sketch_dedup_kernel are applied by a count pass, a one-block scan and a write pass.
+// ---------------------------------------------------------------------------------------------------
+#define BIG_THREADS 256
+#define BIG_TILE 2048  // sorted entries per workgroup
+
+__global__ void big_pad_kernel(uint32_t *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
+                               uint32_t *__restrict__ kept_g, uint32_t *__restrict__ acc /*[2]: distinct, zero occurrences*/,
+                               SketchStatus *st)
+{
+    const unsigned long long n = *cursor_g;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        acc[0] = acc[1] = 0;
+        if (n > cap) {
+            atomicOr(&st->region_overflow, 1u);
+            unsigned long long need = (n * 256ull + cap - 1) / (cap ? cap : 1);
+            atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
+            *kept_g = 0;
+        }
+    }
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * blockDim.x)
+        if (i >= n) region[i] = 0xFFFFFFFFu;
+}
+
+// WRITE = false: per-tile count of kept ids (+ the genome's distinct / zero-occurrence totals);
+// WRITE = true: compaction into `out` at the tile's scanned offset
+template <bool WRITE>
+__global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const uint32_t *__restrict__ a /*sorted*/, unsigned long long cap,
+                                                                const uint32_t *__restrict__ cursor_g, uint32_t flags,
+                                                                uint32_t min_occ, uint32_t *__restrict__ tile_cnt,
+                                                                uint32_t *__restrict__ acc, uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
+    const unsigned long long n = *cursor_g;
+    if (n > cap) return;
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * BIG_TILE;
+    if (t0 >= n) { if (!WRITE && threadIdx.x == 0) tile_cnt[blockIdx.x] = 0; return; }
+    uint32_t out_base = WRITE ? tile_cnt[blockIdx.x] : 0, distinct = 0, zero_occ = 0;
+    for (uint32_t i0 = 0; i0 < BIG_TILE; i0 += BIG_THREADS) {
+        const unsigned long long i = t0 + i0 + threadIdx.x;
+        bool keep = false;
+        uint32_t v = 0;
+        if (i < n) {
+            v = a[i];
+            if (i == 0 || a[i - 1] != v) {
+                unsigned long long lo = i + 1, hi = n;  // first index > i with a different value
+                while (lo < hi) {
+                    const unsigned long long mid = (lo + hi) >> 1;
+                    if (a[mid] == v) lo = mid + 1;
+                    else hi = mid;
+                }
+                const unsigned long long len = lo - i;
+                keep = len >= min_occ;
+                if ((flags & KSSD_SKETCH_UNIQ) && len > 1) keep = false;
+                if (v == 0 && !(flags & KSSD_SKETCH_KEEP_ZERO)) {
+                    keep = false;  // fasta2co leaves the slot empty (iseq2comem.c:258-261) ...
+                    zero_occ += (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len);  // ... but counts every occurrence
+                } else {
+                    distinct++;
+                }
+            }
+        }
+        uint32_t tot;
+        const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
+        if (WRITE && keep) out[out_base + pos] = v;
+        out_base += tot;
+    }
+    if (!WRITE) {
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = out_base;
+        if (distinct) atomicAdd(&acc[0], distinct);
+        if (zero_occ) atomicAdd(&acc[1], zero_occ);
+    }
+}
+
+// one workgroup: exclusive scan of the tile counts, kept[g], the capacity rule (iseq2comem.c:261-263)
+__global__ __launch_bounds__(1024) void big_scan_kernel(uint32_t *__restrict__ tile_cnt, uint32_t n_tiles, const uint32_t *__restrict__ acc,
+                                                         uint32_t hashlimit, uint32_t flags, uint32_t g, unsigned long long cap,
+                                                         const uint32_t *__restrict__ cursor_g, uint32_t *__restrict__ kept_g,
+                                                         SketchStatus *st)
+{
+    __shared__ uint32_t part[1024];
+    if (*cursor_g > cap) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_tiles + 1023) / 1024;
+    const uint32_t b = tid * per, e = (b + per < n_tiles) ? b + per : n_tiles;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += tile_cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; i++) { const uint32_t t = part[i]; part[i] = run; run += t; }
+        *kept_g = run;
+        if (!(flags & KSSD_SKETCH_NO_CAPACITY) && (unsigned long long)acc[0] + acc[1] > hashlimit)
+            atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
+    }
+    __syncthreads();
+    uint32_t run = part[tid];
+    for (uint32_t i = b; i < e; i++) { const uint32_t t = tile_cnt[i]; tile_cnt[i] = run; run += t; }
+}
+
 // kernel 3: exclusive scan of the kept counts -> CSR offsets (single workgroup, n_genomes is small)
 __global__ __launch_bounds__(1024) void sketch_offsets_kernel(const uint32_t *__restrict__ kept, uint32_t n,
                                                                unsigned long long *__restrict__ out_off,
@@ -742,22 +854,26 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     // staging regions: expected emissions = positions * dim_end / 16^subk, times a safety factor
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     c->h_reg_off.resize((size_t)n_genomes + 1);
-    uint64_t acc = 0, max_cap = 0;
+    c->h_big.clear();
+    const uint32_t big_min_env = getenv("KSSD_DEV_BIG_MIN") ? (uint32_t)atoi(getenv("KSSD_DEV_BIG_MIN")) : 0u;  // tests only
+    const uint32_t big_min = big_min_env ? big_min_env : DEDUP_MAX_N;
+    uint64_t acc = 0, max_cap = 0, max_big = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
         if (h_chunk_off[g + 1] < h_chunk_off[g]) return KSSD_ERR_PARAM;
         const uint64_t pos = (h_chunk_off[g + 1] - h_chunk_off[g]) * KSSD_CHUNK;
         uint64_t cap = (uint64_t)((double)pos * rate * c->region_factor) + 256;
         if (cap > pos) cap = pos;  // a genome cannot emit more tuples than it has positions
-        if (cap > DEDUP_MAX_N) {
-            if ((uint64_t)((double)pos * rate * 1.25) + 64 > DEDUP_MAX_N) {
-                c->last_launch_rc = KSSD_ERR_UNSUPPORTED;  // genome too large for the LDS dedup (next: global sort path)
-                return KSSD_ERR_UNSUPPORTED;
+        if (cap > big_min) {
+            if ((uint64_t)((double)pos * rate * 1.25) + 64 <= big_min) cap = big_min;  // still fits the LDS sort
+            else {
+                if (cap >= (1ull << 31)) { c->last_launch_rc = KSSD_ERR_UNSUPPORTED; return KSSD_ERR_UNSUPPORTED; }
+                c->h_big.push_back(g);  // global-memory sort path
             }
-            cap = DEDUP_MAX_N;
         }
         c->h_reg_off[g] = acc;
         acc += cap;
-        if (cap > max_cap) max_cap = cap;
+        if (cap <= big_min && cap > max_cap) max_cap = cap;
+        if (cap > big_min && cap > max_big) max_big = cap;
     }
     c->h_reg_off[n_genomes] = acc;
     int rc;
@@ -825,7 +941,35 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
     hipLaunchKernelGGL(sketch_dedup_kernel, dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
                        (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, c->d_regions, c->d_kept,
-                       flags, min_occ, c->d_status);
+                       flags, min_occ, big_min, c->d_status);
+    if (!c->h_big.empty()) {
+        const size_t n_tiles_max = (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
+        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, (size_t)max_big + n_tiles_max + 8)) != KSSD_OK) return rc;
+        size_t tmp_bytes = 0;
+        HIPCK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)max_big, 0u, 32u, s));
+        if (tmp_bytes > c->cap_big_tmp) {
+            if (c->d_big_tmp) hipFree(c->d_big_tmp);
+            c->d_big_tmp = nullptr;
+            c->cap_big_tmp = 0;
+            if (hipMalloc(&c->d_big_tmp, tmp_bytes) != hipSuccess) return KSSD_ERR_NOMEM;
+            c->cap_big_tmp = tmp_bytes;
+        }
+        for (uint32_t g : c->h_big) {
+            const uint64_t r0 = c->h_reg_off[g], cap = c->h_reg_off[g + 1] - r0;
+            const uint32_t n_tiles = (uint32_t)((cap + BIG_TILE - 1) / BIG_TILE);
+            uint32_t *region = c->d_regions + r0, *sorted = c->d_big_alt, *tile_cnt = c->d_big_alt + max_big, *accum = tile_cnt + n_tiles_max;
+            const uint32_t *cur = c->d_cursor + g;
+            hipLaunchKernelGGL(big_pad_kernel, dim3(1024), dim3(256), 0, s, region, (unsigned long long)cap, cur, c->d_kept + g, accum, c->d_status);
+            size_t tb = c->cap_big_tmp;
+            HIPCK(rocprim::radix_sort_keys(c->d_big_tmp, tb, region, sorted, (size_t)cap, 0u, 32u, s));
+            hipLaunchKernelGGL((big_runs_kernel<false>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const uint32_t *)sorted,
+                               (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(big_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_tiles, (const uint32_t *)accum, c->P.hashlimit,
+                               flags, g, (unsigned long long)cap, cur, c->d_kept + g, c->d_status);
+            hipLaunchKernelGGL((big_runs_kernel<true>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const uint32_t *)sorted,
+                               (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, region);
+        }
+    }
     hipLaunchKernelGGL(sketch_offsets_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)c->d_kept, n_genomes,
                        (unsigned long long *)d_out_off, (unsigned long long)out_cap, c->d_status);
     hipLaunchKernelGGL(sketch_gather_kernel, dim3(n_genomes), dim3(256), 0, s, (const unsigned long long *)c->d_reg_off,

@@ -148,3 +148,70 @@ def test_empty_batch_and_empty_genome(gpu_ctx, shuf_l3k10):
     b.add_fasta(b">x\nACGT\n")
     off, ids = gpu_ctx.sketch_batch(b)
     assert list(off) == [0, 0, 0] and len(ids) == 0
+
+
+@pytest.fixture
+def force_big_path(monkeypatch):
+    """route every genome with more than ~100 expected ids through the global-memory dedup (rocPRIM sort + run kernels)"""
+    monkeypatch.setenv("KSSD_DEV_BIG_MIN", "100")
+    yield
+    monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
+
+
+def test_big_genome_path_matches_oracle(gpu_ctx, shuf_l3k10, force_big_path):
+    """same rules as the LDS dedup: id 0, -u, -n, order, mixed with small genomes in one batch"""
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    gs = clade_genomes(2, 2, 1_500_000, seed=4)            # ~366 ids each: big path (threshold 100)
+    texts = [fasta_text(c, nm, n_mask=m) for nm, c, m in gs]
+    texts.insert(1, b">tiny\n" + bytes(acgt[rng.integers(0, 4, 50_000, dtype=np.uint8)]) + b"\n")  # stays on the LDS path
+    check(gpu_ctx, shuf_l3k10, texts)
+    unit = bytes(acgt[rng.integers(0, 4, 900_000, dtype=np.uint8)])
+    check(gpu_ctx, shuf_l3k10, [b">dup\n" + unit + b"\nN\n" + unit[:500_000] + b"\n"], flags=K.SKETCH_UNIQ, uniq=True)
+    # FASTQ -n through the big path
+    genome = rng.integers(0, 4, 1_200_000, dtype=np.uint8)
+    reads = []
+    for _ in range(20000):
+        s = int(rng.integers(0, len(genome) - 150))
+        r = genome[s:s + 150].copy()
+        reads.append((3 - r)[::-1] if rng.random() < 0.5 else r)
+    fq = fastq_text(reads)
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    for M in (1, 2):
+        b = K.Batch()
+        b.add_fastq(fq, Q=0)
+        off, ids = gpu_ctx.sketch_batch(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY, min_occ=M)
+        assert np.array_equal(ids, np.sort(sk.fastq(fq, Q=0, M=M))), M
+
+
+def test_big_genome_path_capacity_error(force_big_path):
+    shuf = K.Shuf.generate(6, 4, 1, seed=5)   # limit 4914 distinct ids
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        rng = np.random.default_rng(1)
+        b = K.Batch()
+        b.add_fasta(fasta_text(rng.integers(0, 4, 20_000, dtype=np.uint8)))
+        b.add_fasta(fasta_text(rng.integers(0, 4, 400_000, dtype=np.uint8)))
+        with pytest.raises(K.KssdError) as e:
+            ctx.sketch_batch(b)
+        assert e.value.code == -3 and e.value.bad_genome == 1
+    finally:
+        ctx.close()
+
+
+def test_genome_larger_than_the_lds_sort(shuf_l3k10):
+    """a 150 Mb record (~36 600 ids > DEDUP_MAX_N = 32768) takes the global-memory path without any override"""
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        rng = np.random.default_rng(8)
+        t = fasta_text(rng.integers(0, 4, 150_000_000, dtype=np.uint8))
+        b = K.Batch()
+        b.add_fasta(t)
+        off, ids = ctx.sketch_batch(b)
+        want = np.sort(ko.Sketcher(shuf_l3k10.table, 10, 6, 3).fasta(t))
+        assert len(want) > 32768 and np.array_equal(ids, want)
+        s1, bl = ctx.scan_stats()
+        npos = b.n_chunks * 4096
+        assert 0.006 < s1 / npos < 0.010 and 0.0004 < bl / npos < 0.0009  # stage 1 / Bloom pass rates (DESIGN.md)
+    finally:
+        ctx.close()
