@@ -110,10 +110,10 @@ struct kssd_gpu_ctx {
     uint32_t n_ref;
     uint64_t n_ref_ids;
     uint32_t *d_ref_sz;     // n_ref sketch sizes
-    uint32_t *d_hkeys;      // 4 arrays of 2^h_log2 u32: key | count | start | fill cursor
+    uint32_t *d_hkeys;      // 2^h_log2 slots of 16 bytes (IdxSlot) + the posting bump cursor
     uint32_t h_log2;
     size_t cap_hash;
-    uint32_t *d_post;       // postings (genome indices) | entry->slot scratch | scan partials
+    uint32_t *d_post;       // postings (genome indices) | entry -> slot | entry -> place in its posting
     size_t cap_pairs;
     size_t cap_ref;
     // timing: ring of HIP event pairs around the dominant kernel of each path (0 = sketch scan, 1 = dist rows)
