@@ -234,6 +234,7 @@ def main():
         raise SystemExit("sketch status rc=%d after the timed loop" % rc)
     scan_ms, scan_n = ctx.kernel_time(0)
     dist_ms, dist_n = ctx.kernel_time(1)
+    n_stage1, n_bloom = ctx.scan_stats(stream)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -270,7 +271,8 @@ def main():
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
             "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [scan_n, dist_n],
-                        "dist_rows_GBs": dist_bytes / (dist_ms * 1e-3) / 1e9 if dist_ms > 0 else None},
+                        "dist_rows_GBs": dist_bytes / (dist_ms * 1e-3) / 1e9 if dist_ms > 0 else None,
+                        "scan_positions_past_stage1": n_stage1 / n_bases, "scan_positions_past_bloom": n_bloom / n_bases},
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box, through gpurun): profiles/run_round.sh <tag>
-# GPU parity tests, the default bench line, a rocprofv3 kernel-trace summary and the PMC passes of the scan kernel.
+# GPU parity tests, the default bench line, a rocprofv3 kernel-trace summary, the PMC passes of the scan kernel
+# (separate passes, counters + kernel trace only) and the FETCH_SIZE calibration of the three read widths.
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -9,10 +10,14 @@ timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/${tag}_prof.log 2>&1
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_kernel_stats.csv
-rx='sketch_scan_kernel'
-profiles/pmc_pass.sh ${tag}_sq1 "$rx" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS > gpurun_out/${tag}_pmc_sq1.txt 2>&1
-profiles/pmc_pass.sh ${tag}_sq2 "$rx" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE > gpurun_out/${tag}_pmc_sq2.txt 2>&1
-profiles/pmc_pass.sh ${tag}_fetch "$rx" FETCH_SIZE > gpurun_out/${tag}_pmc_fetch.txt 2>&1
-profiles/pmc_pass.sh ${tag}_write "$rx" WRITE_SIZE > gpurun_out/${tag}_pmc_write.txt 2>&1
+rx='sketch_scan_kernel|sketch_exact_kernel'
+{
+profiles/pmc_pass.sh ${tag}_sq1 "$rx" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
+profiles/pmc_pass.sh ${tag}_sq2 "$rx" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE
+profiles/pmc_pass.sh ${tag}_fetch "$rx" FETCH_SIZE
+profiles/pmc_pass.sh ${tag}_write "$rx" WRITE_SIZE
+echo "--- FETCH_SIZE calibration: every calib_read* launch reads exactly 2^30 bytes (profiles/scanbench calib)"
+SB_ARGS=calib profiles/pmc_sb.sh ${tag}_calib FETCH_SIZE
+} > gpurun_out/${tag}_pmc_scan.txt 2>&1
 rm -rf gpurun_out/${tag}_prof gpurun_out/pmc_${tag}_*/
-tail -3 gpurun_out/${tag}_pytest.log; cat gpurun_out/${tag}_bench.json | cut -c1-600
+tail -3 gpurun_out/${tag}_pytest.log; cut -c1-700 gpurun_out/${tag}_bench.json; cat gpurun_out/${tag}_pmc_scan.txt

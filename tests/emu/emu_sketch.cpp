@@ -1,6 +1,6 @@
 // emu_sketch.cpp -- TEST HELPER (not part of the product, never loaded by public_kssd_amd).
-// Drives the host/device-shared bit manipulation of public_kssd_amd/csrc/kssd_core.h (stage 1 quad-core
-// filter, stage 2 exact evaluation) lane by lane on the CPU, so that the packed layout, the table
+// Drives the host/device-shared bit manipulation of public_kssd_amd/csrc/kssd_core.h (stage 1 group
+// filter, stage 1.5 Bloom test, stage 2 exact evaluation) lane by lane on the CPU, so that the packed layout, the table
 // construction and every shift can be checked against the oracle without a GPU.  The wave-level
 // machinery (queues, ballots, atomics, LDS) only exists in the HIP kernels and is covered by -m gpu tests.
 #include <stdint.h>

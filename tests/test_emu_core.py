@@ -1,7 +1,7 @@
 """CPU check of the host/device-shared bit manipulation in public_kssd_amd/csrc/kssd_core.h.
 
-tests/emu/emu_sketch.cpp (a test helper, not product code) runs the stage-1 quad-core filter and the stage-2
-exact evaluation lane by lane on the packed layout the host tokeniser writes; the emitted (genome, id) pairs
+tests/emu/emu_sketch.cpp (a test helper, not product code) runs the stage-1 group filter, the stage-1.5
+Bloom test and the stage-2 exact evaluation lane by lane on the packed layout the host tokeniser writes; the emitted (genome, id) pairs
 must equal the oracle's sketches, and stage 1 must never lose a k-mer that stage 2 on every position finds.
 """
 import ctypes as C
@@ -52,7 +52,7 @@ def texts(rng):
 
 CASES = [(k, s, d, 0) for k, s, d in [(10, 6, 3), (8, 5, 2), (10, 7, 5), (9, 6, 3), (11, 6, 3), (8, 4, 1), (12, 7, 4),
                                       (9, 3, 1)]]
-CASES += [(k, s, d, 4) for k, s, d in [(10, 6, 3), (10, 7, 5)]]  # gw = 0: the kernel's KSSD_GW
+CASES += [(10, 6, 3, 4)]  # gw = 0: the kernel's KSSD_GW; 4: another instantiation of the same templates
 
 
 @pytest.mark.parametrize("k,subk,dr,gw", CASES)
