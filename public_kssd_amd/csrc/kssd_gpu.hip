@@ -55,7 +55,7 @@ extern "C" const char *kssd_gpu_strerror(int code)
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define CBUF 128          // per-wave buffer of stage-1 candidates waiting for the Bloom test (8 B each)
-#define DEDUP_THREADS 256
+#define DEDUP_THREADS 512
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
 #define SCAN_TAB_BYTES (KSSD_T1_BYTES + KSSD_BLOOM_WORDS * 4)  // stage-1 table + stage-1.5 Bloom filter, contiguous
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
 // (a plain library sort: not worth a hand-written kernel for a handful of genomes per batch), then the same
 // keep rules as sketch_dedup_kernel are applied by a count pass, a one-block scan and a write pass.
 // ---------------------------------------------------------------------------------------------------
-#define BIG_THREADS 256
+#define BIG_THREADS DEDUP_THREADS  // block_excl_scan is sized for it
 #define BIG_TILE 2048  // sorted entries per workgroup
 
 __global__ void big_pad_kernel(uint32_t *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
@@ -790,23 +790,34 @@ __global__ __launch_bounds__(1024) void sketch_offsets_kernel(const uint32_t *__
                                                                unsigned long long *__restrict__ out_off,
                                                                unsigned long long out_cap, SketchStatus *st)
 {
-    __shared__ unsigned long long part[1024];
-    const uint32_t tid = threadIdx.x;
+    __shared__ unsigned long long wsum[16];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t per = (n + 1023) / 1024;
     const uint32_t b = tid * per, e = (b + per < n) ? b + per : n;
     unsigned long long s = 0;
     for (uint32_t i = b; i < e; i++) s += kept[i];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 1024; i++) { unsigned long long t = part[i]; part[i] = run; run += t; }
-        out_off[n] = run;
-        st->total_ids = run;
-        if (run > out_cap) st->out_overflow = 1;
+    // block-wide exclusive scan of the per-thread sums: wave scan (64-bit through two 32-bit shuffles) + 16 wave totals
+    unsigned long long incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)incl, d, 64), hi = __shfl_up((uint32_t)(incl >> 32), d, 64);
+        if ((int)lane >= d) incl += ((unsigned long long)hi << 32) | lo;
     }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    unsigned long long run = part[tid];
+    unsigned long long off = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        const unsigned long long t = wsum[w];
+        if (w < wave) off += t;
+        total += t;
+    }
+    if (tid == 0) {
+        out_off[n] = total;
+        st->total_ids = total;
+        if (total > out_cap) st->out_overflow = 1;
+    }
+    unsigned long long run = off + incl - s;
     for (uint32_t i = b; i < e; i++) { out_off[i] = run; run += kept[i]; }
 }
 
