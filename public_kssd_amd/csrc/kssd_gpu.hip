@@ -386,7 +386,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char smem[SCAN_LDS_BYTES];
     uint8_t *T1 = smem;
     const uint32_t *bloom = reinterpret_cast<const uint32_t *>(smem + KSSD_T1_BYTES);
-    const uint32_t wave = threadIdx.x >> 6;
+    // readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; without it the chunk range, the
+    // loop counter and every counter derived from a ballot live in VGPRs and the loops run on exec masks
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = lane_id();
     uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // (chunk offset << 12 | position, pattern)
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
@@ -451,9 +453,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                         wave_lds_sync();
                     }
                     if (has) {
-                        uint32_t b;
-                        if (cl) { b = __builtin_ctz(cl); cl &= cl - 1; }
-                        else { b = 32 + __builtin_ctz(ch); ch &= ch - 1; }
+                        // lowest set bit of (ch:cl) without a branch on which word holds it
+                        const bool in_lo = cl != 0;
+                        const uint32_t word = in_lo ? cl : ch;
+                        const uint32_t b = (uint32_t)__builtin_ctz(word) + (in_lo ? 0u : 32u);
+                        const uint32_t rest = word & (word - 1u);
+                        cl = in_lo ? rest : 0u;
+                        ch = in_lo ? ch : rest;
                         cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b, kssd_extract_m<SUBK>(cur.W, b));
                     }
                     cn += __builtin_popcountll(hbal);
