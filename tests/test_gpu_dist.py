@@ -86,3 +86,26 @@ def test_long_postings_and_empty_rows(gpu_ctx):
     for a, b in ((J, oJ), (MD, oMD), (Cc, oC), (AD, oAD)):
         assert ulp_diff(a, b).max() <= 1
         assert np.array_equal(np.isnan(a), np.isnan(b))
+
+
+def test_more_references_than_one_lds_row(gpu_ctx):
+    """> 36 864 references: the row kernel tiles the reference axis (two tiles here)"""
+    rng = np.random.default_rng(12)
+    R = 40_000
+    sizes = rng.integers(1, 6, R)
+    roff = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    common = np.array([7, 99, 4242], dtype=np.uint32)
+    rids = np.empty(int(roff[-1]), np.uint32)
+    for g in range(R):
+        s, e = int(roff[g]), int(roff[g + 1])
+        own = (1 << 20) + g * 8 + np.arange(e - s, dtype=np.uint32)
+        if g % 3 == 0:
+            own[0] = common[g % 3]  # id 7 sits in every third reference: a posting across both tiles
+        rids[s:e] = np.sort(own)
+    qoff = np.array([0, 3, 5], dtype=np.uint64)
+    qids = np.array([7, 99, (1 << 20) + 39_999 * 8, 7, (1 << 20) + 8], dtype=np.uint32)
+    qids[:3] = np.sort(qids[:3]); qids[3:] = np.sort(qids[3:])
+    shared = gpu_ctx.dist(roff, rids, qoff, qids, planes=False)
+    assert shared.shape == (2, R)
+    assert np.array_equal(shared, ko.shared_counts(roff, rids, qoff, qids, threads=4))
+    assert shared[0, 39_999] >= 1 and shared[:, ::3].min() >= 1
