@@ -7,7 +7,10 @@ One step = one pass of the hot path over one batch that is already resident in H
         (shared counts + Jaccard / MashD / containment / AafD, 36 B per pair)
 Workload = BASELINE.json configs[1]: 1 000 synthetic 5 Mb bacterial genomes per GPU (50 clades x 20 members,
 0.5-5 % substitutions, 1e-4 N), L3K10 shuffle, all-pairs.  Weak scaling: every rank sketches its own 1 000
-genomes; rank r's query block is its own genomes against the gathered N x 1 000 references.
+genomes and computes the block of the all-pairs matrix between ITS genomes and ALL N x 1 000 genomes.  It puts
+its own genomes on the indexed side (all gathered sketches are the query rows): the index build is the part
+that would otherwise be repeated on every rank, and every metric of the path is symmetric in (query, reference),
+so the R x G block a rank writes is the transpose of its G x R query block.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -160,12 +163,18 @@ def main():
                          % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to measure)")
+    if os.environ.get("KSSD_BENCH_ONE_DEVICE"):  # development: every rank on cuda:0 (checks the N > 1 flow on a 1-GPU box)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("KSSD_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; gloo only for the 1-GPU check
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     G, L = a.genomes, a.length
     shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
@@ -200,9 +209,10 @@ def main():
             # the one exchange step of the path: all-gather of every rank's packed sketches (RCCL over xGMI),
             # fixed-size padded units compacted on the device, so that no size has to visit the host
             roff, rids = gather(off_l, ids_l)
-            ctx.index_build_device(roff, rids, R, world * cap, stream)
-            # this rank's query block = its own genomes = rows [rank*G, (rank+1)*G) of the global matrix
-            ctx.dist_device(roff, rids, R, qb, qe, shared, *planes, stream=stream)
+            # index this rank's own sketches only (constant work per rank), query with everybody's: the R x G block
+            # [all genomes] x [this rank's genomes] = transpose of rows [rank*G, (rank+1)*G) of the global matrix
+            ctx.index_build_device(off_l, ids_l, G, cap, stream)
+            ctx.dist_device(roff, rids, R, 0, R, shared, *planes, stream=stream)
 
     def sync():
         if world > 1:
@@ -243,12 +253,12 @@ def main():
 
     if rank == 0:
         # size-independent sanity on the full matrix of this rank
-        sh = shared.view(G, R)
+        sh = shared.view(R, G)  # [all genomes (query rows)] x [this rank's genomes]; world 1: the full G x G matrix
         szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
-        diag = sh[torch.arange(G, device=dev), rank * G + torch.arange(G, device=dev)]
+        diag = sh[rank * G + torch.arange(G, device=dev), torch.arange(G, device=dev)]
         assert torch.equal(diag, szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
-        if world == 1:
-            assert torch.equal(sh, sh.t()), "all-pairs shared-count matrix must be symmetric"
+        own = sh[rank * G:(rank + 1) * G, :]
+        assert torch.equal(own, own.t()), "all-pairs shared-count matrix must be symmetric"
         n_bases = G * L
         scan_bytes = 0.375 * n_bases + 4.0 * total        # 2-bit base + 1-bit mask, 4 B per id
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
@@ -265,8 +275,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
                                    "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
-                       "pairs_per_step": world * pairs, "parallelism": "genomes and query rows sharded x%d, "
-                       "all-gather of sketches" % world if world > 1 else "single GPU"},
+                       "pairs_per_step": world * pairs, "parallelism": "genomes and matrix blocks sharded x%d (own genomes "
+                       "indexed, all gathered sketches as query rows), all-gather of sketches" % world if world > 1
+                       else "single GPU"},
             "pairs_per_s": world * pairs * a.steps / dt,
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),

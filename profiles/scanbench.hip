@@ -156,8 +156,16 @@ int main(int argc, char **argv)
     float ms;
     uint32_t nl;
     kssd_gpu_kernel_time(ctx, 0, 1, &ms, &nl);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, nullptr));
     for (int i = 0; i < reps; i++) kssd_gpu_sketch_device(ctx, d_p, d_m, chunk_off.data(), G, 0, 1, d_off, d_ids, cap, nullptr);
+    CK(hipEventRecord(e1, nullptr));
     CK(hipDeviceSynchronize());
+    float whole_ms = 0;
+    CK(hipEventElapsedTime(&whole_ms, e0, e1));
+    whole_ms /= reps;
     kssd_gpu_kernel_time(ctx, 0, 1, &ms, &nl);
     rc = kssd_gpu_sketch_status(ctx, &total, &bad, nullptr);
 
@@ -174,6 +182,7 @@ int main(int argc, char **argv)
     for (uint64_t i = 0; i < total; i++) h = (h ^ ids[i]) * 1099511628211ull;
     for (uint32_t g = 0; g <= G; g++) h = (h ^ off[g]) * 1099511628211ull;
     const double bytes = 0.375 * (double)G * (double)(chunks * KSSD_CHUNK_BASES) + 4.0 * total;
+    printf("whole sketch call (scan + exact + dedup + CSR): %.4f ms\n", whole_ms);
     printf("variant=%s genomes=%u len=%llu rc=%d ids=%llu checksum=%016llx scan_ms=%.4f (%u launches) algorithmic %.1f GB/s\n",
            getenv("KSSD_DEV_SCAN") ? getenv("KSSD_DEV_SCAN") : "default", G, (unsigned long long)L, rc,
            (unsigned long long)total, (unsigned long long)h, ms, nl, bytes / ms / 1e6);
