@@ -94,6 +94,8 @@ struct kssd_gpu_ctx {
     size_t cap_cand;
     uint32_t *d_cand_count;
     size_t cap_cand_count;
+    unsigned long long *d_lane_valid;  // per chunk, written by the scan (+1 zero word at the end)
+    size_t cap_lane_valid;
     uint64_t last_cand_cap;
     double cand_factor;
     SketchStatus *d_status;
@@ -222,7 +224,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp};
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp, c->d_lane_valid};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (int w = 0; w < 2; w++)
@@ -325,6 +327,8 @@ struct ScanArgs {
     unsigned long long *cand;       // (waves of the grid) * cand_cap global positions
     unsigned long long cand_cap;    // per wave
     uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
+    unsigned long long *lane_valid; // per chunk: bit l <=> all 64 positions of lane l are bases (saves the exact stage
+                                    // its mask read, a second random HBM line per candidate, in all but ~1 % of the cases)
     SketchStatus *status;
 };
 
@@ -424,6 +428,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         // state: cur = chunk c, nxt = chunk c+1 (requested two iterations ago), chunk c+2 in flight, far = free, raw = alignment-B reads of
         //        chunk c (in flight), alo/ahi = alignment A of chunk c
         load_chunk(a, c + 3 < clast ? c + 3 : clast, lane, far);
+        if (ABL == 0) {
+            const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
+            if (lane == 0) a.lane_valid[c] = vb;
+        }
         uint32_t rawa[Gp::NMAX];
         if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
         if (ABL == 1) {
@@ -519,6 +527,7 @@ struct ExactArgs {
     const unsigned long long *cand;
     unsigned long long cand_cap;
     const uint32_t *cand_count;
+    const unsigned long long *lane_valid;
     uint32_t n_slices;
     const unsigned long long *reg_off;
     uint32_t *cursor;
@@ -551,7 +560,13 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         const unsigned long long b0c = b0 < 0 ? 0ull : (unsigned long long)b0;
         gid = x.chunk_gid[(unsigned long long)s >> 12];
         const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
-        const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], m0 = mp[0], m1 = mp[1];
+        const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2];
+        // validity: the scan's per-lane summary (a small, cache-resident array) answers for ~99 % of the k-mers;
+        // only the rest read the mask words themselves
+        const unsigned long long blk0 = b0c >> 6, blk1 = (b0c + (unsigned long long)P.nb - 1ull) >> 6;
+        const bool known = ((x.lane_valid[blk0 >> 6] >> (blk0 & 63ull)) & (x.lane_valid[blk1 >> 6] >> (blk1 & 63ull)) & 1ull) != 0;
+        uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+        if (!known) { m0 = mp[0]; m1 = mp[1]; }
         uint64_t u;
         uint32_t dim;
         const bool valid = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u, dim);
@@ -910,6 +925,8 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
     HIPCK(hipMemsetAsync(c->d_cand_count, 0, (size_t)n_slices * 4, s));
+    if ((rc = ensure(&c->d_lane_valid, &c->cap_lane_valid, (size_t)n_chunks + 2)) != KSSD_OK) return rc;
+    HIPCK(hipMemsetAsync(c->d_lane_valid + n_chunks, 0, 16, s));  // a k-mer that would end past the batch is not "known valid"
 
     HIPCK(hipMemcpyAsync(c->d_chunk_off, h_chunk_off, ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCK(hipMemcpyAsync(c->d_reg_off, c->h_reg_off.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
@@ -920,6 +937,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         ScanArgs a;
         a.packed = d_packed; a.mask = d_mask; a.n_chunks = n_chunks; a.tab = c->d_T1;
         a.cand = (unsigned long long *)c->d_cand; a.cand_cap = cand_cap; a.cand_count = c->d_cand_count;
+        a.lane_valid = c->d_lane_valid;
         a.status = c->d_status;
         const unsigned evi = c->ev_n[0] % EV_RING;
         HIPCK(hipEventRecord(c->ev_a[0][evi], s));
@@ -946,6 +964,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         x.packed = d_packed; x.mask = d_mask; x.chunk_gid = c->d_chunk_gid;
         x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;
         x.cand = (const unsigned long long *)c->d_cand; x.cand_cap = cand_cap; x.cand_count = c->d_cand_count;
+        x.lane_valid = c->d_lane_valid;
         x.n_slices = n_slices;
         x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
         x.status = c->d_status;
