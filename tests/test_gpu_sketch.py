@@ -215,3 +215,26 @@ def test_genome_larger_than_the_lds_sort(shuf_l3k10):
         assert 0.006 < s1 / npos < 0.010 and 0.0004 < bl / npos < 0.0009  # stage 1 / Bloom pass rates
     finally:
         ctx.close()
+
+
+def test_many_tiny_genomes_share_waves_and_chunks(gpu_ctx, shuf_l3k10):
+    """2 000 genomes of 1-3 chunks each: many genomes per scan wave, several genomes per wave of the exact stage,
+    k-mers must not leak across genome boundaries"""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    base = bytes(acgt[rng.integers(0, 4, 12_000, dtype=np.uint8)])
+    texts = []
+    for i in range(2000):
+        n = int(rng.integers(3000, 12_000))
+        s = int(rng.integers(0, 12_000 - n + 1))
+        texts.append(b">g%d\n" % i + base[s:s + n] + b"\n")   # overlapping slices: the same k-mers in many genomes
+    b = K.Batch()
+    for t in texts:
+        b.add_fasta(t)
+    off, ids = gpu_ctx.sketch_batch(b)
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    want_all = np.sort(sk.fasta(b">all\n" + base + b"\n"))
+    for g in rng.choice(2000, 120, replace=False):
+        got = ids[int(off[g]):int(off[g + 1])]
+        assert np.array_equal(got, np.sort(sk.fasta(texts[g]))), g
+        assert np.isin(got, want_all).all()
