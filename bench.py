@@ -200,10 +200,14 @@ def main():
     planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
     stream = torch.cuda.current_stream().cuda_stream
 
+    # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
+    # status read-back has told the host how many ids this batch really has
+    idx_bound = [cap]
+
     def step():
         ctx.sketch_device(packed, mask, chunk_off, off_l, ids_l, cap, K.SKETCH_FASTA, 1, stream)
         if world == 1:
-            ctx.index_build_device(off_l, ids_l, G, cap, stream)
+            ctx.index_build_device(off_l, ids_l, G, idx_bound[0], stream)
             ctx.dist_device(off_l, ids_l, G, 0, G, shared, *planes, stream=stream)
         else:
             # the one exchange step of the path: all-gather of every rank's packed sketches (RCCL over xGMI),
@@ -211,7 +215,7 @@ def main():
             roff, rids = gather(off_l, ids_l)
             # index this rank's own sketches only (constant work per rank), query with everybody's: the R x G block
             # [all genomes] x [this rank's genomes] = transpose of rows [rank*G, (rank+1)*G) of the global matrix
-            ctx.index_build_device(off_l, ids_l, G, cap, stream)
+            ctx.index_build_device(off_l, ids_l, G, idx_bound[0], stream)
             ctx.dist_device(roff, rids, R, 0, R, shared, *planes, stream=stream)
 
     def sync():
@@ -224,6 +228,7 @@ def main():
         step()
         rc, total, bad = ctx.sketch_status(stream)
         if rc == 0:
+            idx_bound[0] = min(cap, int(total) + 1024)
             break
         if rc != K.capi.ERR_OVERFLOW:
             raise SystemExit("sketch failed: rc=%d" % rc)
