@@ -2,7 +2,7 @@
 // genomes without Python, prints a checksum of the sketches so that kernel variants can be compared, and
 // holds the FETCH_SIZE calibration kernels (known byte counts read with 16 / 8 / 4 B per lane).
 //
-//   profiles/scanbench [genomes=400] [length=5000000] [reps=10]      env KSSD_DEV_SCAN=<variant>
+//   profiles/scanbench [genomes=400] [length=5000000] [reps=10]      env KSSD_DEV_ABLATE=<1..3> (profiles/sb_modes.sh)
 //   profiles/scanbench calib                                          (run under rocprofv3 --pmc FETCH_SIZE)
 // build: make -C public_kssd_amd tools
 #include <hip/hip_runtime.h>
@@ -184,7 +184,7 @@ int main(int argc, char **argv)
     const double bytes = 0.375 * (double)G * (double)(chunks * KSSD_CHUNK_BASES) + 4.0 * total;
     printf("whole sketch call (scan + exact + dedup + CSR): %.4f ms\n", whole_ms);
     printf("variant=%s genomes=%u len=%llu rc=%d ids=%llu checksum=%016llx scan_ms=%.4f (%u launches) algorithmic %.1f GB/s\n",
-           getenv("KSSD_DEV_SCAN") ? getenv("KSSD_DEV_SCAN") : "default", G, (unsigned long long)L, rc,
+           getenv("KSSD_DEV_ABLATE") ? getenv("KSSD_DEV_ABLATE") : "product", G, (unsigned long long)L, rc,
            (unsigned long long)total, (unsigned long long)h, ms, nl, bytes / ms / 1e6);
     kssd_gpu_destroy(ctx);
     return 0;
