@@ -48,6 +48,8 @@ extern "C" {
 #define KSSD_SKETCH_KEEP_ZERO 1u    /* fastq2co semantics: id 0 is kept (iseq2comem.c:335-337)         */
 #define KSSD_SKETCH_UNIQ 2u         /* uniq_fasta2co (-u): drop ids seen more than once (:694-696)     */
 #define KSSD_SKETCH_NO_CAPACITY 4u  /* do not raise KSSD_ERR_CAPACITY (fastq2co never does, :338)      */
+#define KSSD_SKETCH_FIRST_POS 8u    /* also report every id's first position inside its genome: what the */
+                                    /*   reference's hash-slot file order depends on (iseq2comem.c:254-268) */
 
 typedef struct kssd_gpu_ctx kssd_gpu_ctx;
 
@@ -114,11 +116,23 @@ int kssd_gpu_sketch_status(kssd_gpu_ctx *ctx, uint64_t *total_ids, int64_t *bad_
  */
 int kssd_gpu_scan_stats(kssd_gpu_ctx *ctx, uint64_t *stage1, uint64_t *bloom, void *stream);
 
+/*
+ * Where kssd_gpu_sketch_device writes the first positions when called with KSSD_SKETCH_FIRST_POS: DEVICE
+ * u32[out_cap], parallel to d_out_ids (position of the id's first occurrence, counted from the genome's first
+ * chunk).  Genomes must be shorter than 2^32 positions in that mode.
+ */
+int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *ctx, uint32_t *d_out_pos);
+
 /* host-level convenience: HOST packed/mask in, malloc'd HOST CSR out (free with kssd_gpu_free) */
 int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
                           const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
                           uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                           int64_t *bad_genome);
+/* same, plus the first position of every id (KSSD_SKETCH_FIRST_POS is added to flags) */
+int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
+                              const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
+                              uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos,
+                              int64_t *bad_genome);
 void kssd_gpu_free(void *p);
 
 /*

@@ -24,6 +24,7 @@ SKETCH_FASTA = 0
 SKETCH_KEEP_ZERO = 1
 SKETCH_UNIQ = 2
 SKETCH_NO_CAPACITY = 4
+SKETCH_FIRST_POS = 8
 
 OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -32,7 +33,8 @@ GPU_SYMBOLS = [
     "kssd_gpu_create_for_dist",
     "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
-    "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats",
+    "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
+    "kssd_gpu_sketch_batch_pos",
 ]
 
 
@@ -100,6 +102,9 @@ def gpu_lib():
         L.kssd_gpu_sketch_status.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_int64), vp]
         L.kssd_gpu_sketch_batch.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp),
                                             C.POINTER(C.c_int64)]
+        L.kssd_gpu_sketch_batch_pos.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                C.POINTER(C.c_int64)]
+        L.kssd_gpu_sketch_set_pos_output.argtypes = [vp, vp]
         L.kssd_gpu_free.argtypes = [vp]
         L.kssd_gpu_free.restype = None
         L.kssd_gpu_index_build_device.argtypes = [vp, vp, vp, u32, u64, vp]
@@ -148,6 +153,8 @@ def host_lib():
         L.kssd_sketchset_release.restype = None
         L.kssd_slot_order.argtypes = [vp, u64, u32]
         L.kssd_slot_order.restype = None
+        L.kssd_slot_order_pos.argtypes = [vp, vp, u64, u32]
+        L.kssd_slot_order_pos.restype = None
         L.kssd_sketchset_write.argtypes = [C.POINTER(_SketchSet), C.c_char_p, u32, i32]
         L.kssd_sketchset_read.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
         L.kssd_index_write.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
@@ -275,6 +282,14 @@ class SketchSet:
                 for i, n in enumerate(self.names)}
 
 
+def slot_order_pos(ids, first_pos, hashsize):
+    """ids of one genome in the reference's file order, insertions replayed in sequence order"""
+    a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+    p = np.ascontiguousarray(first_pos, dtype=np.uint32)
+    host_lib().kssd_slot_order_pos(a.ctypes.data, p.ctypes.data, len(a), hashsize)
+    return a
+
+
 def slot_order(ids, hashsize):
     a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
     host_lib().kssd_slot_order(a.ctypes.data, len(a), hashsize)
@@ -396,6 +411,29 @@ class GpuCtx:
     def sketch_batch(self, batch, flags=SKETCH_FASTA, min_occ=1):
         """(off uint64[n+1], ids uint32) -- ascending distinct ids per genome"""
         return self.sketch_packed(batch.packed(), batch.mask(), batch.chunk_off(), flags, min_occ)
+
+    def sketch_batch_pos(self, batch, flags=SKETCH_FASTA, min_occ=1):
+        """(off, ids, first_pos): as sketch_batch plus every id's first position inside its genome"""
+        chunk_off = np.ascontiguousarray(batch.chunk_off(), dtype=np.uint64)
+        n = len(chunk_off) - 1
+        po, pi, pp, bad = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+        rc = gpu_lib().kssd_gpu_sketch_batch_pos(self.h, _ptr(batch.packed()), _ptr(batch.mask()), chunk_off.ctypes.data, n,
+                                                 flags, min_occ, C.byref(po), C.byref(pi), C.byref(pp), C.byref(bad))
+        if rc != 0:
+            e = KssdError(rc, gpu_lib().kssd_gpu_strerror(rc).decode())
+            e.bad_genome = bad.value
+            raise e
+        try:
+            off = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(po.value), dtype=np.uint64).copy()
+            tot = int(off[-1])
+            ids = (np.frombuffer((C.c_char * (4 * tot)).from_address(pi.value), dtype=np.uint32).copy()
+                   if tot else np.zeros(0, np.uint32))
+            pos = (np.frombuffer((C.c_char * (4 * tot)).from_address(pp.value), dtype=np.uint32).copy()
+                   if tot else np.zeros(0, np.uint32))
+        finally:
+            for q in (po, pi, pp):
+                gpu_lib().kssd_gpu_free(q)
+        return off, ids, pos
 
     def sketch_packed(self, packed, mask, chunk_off, flags=SKETCH_FASTA, min_occ=1):
         chunk_off = np.ascontiguousarray(chunk_off, dtype=np.uint64)

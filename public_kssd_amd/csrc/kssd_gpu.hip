@@ -88,8 +88,9 @@ struct kssd_gpu_ctx {
     uint32_t *d_cursor;     // n_genomes
     uint32_t *d_kept;       // n_genomes
     size_t cap_chunk_off, cap_reg_off, cap_cursor, cap_kept;
-    uint32_t *d_regions;
+    uint32_t *d_regions;    // staging regions: u32 tuples, or u64 (tuple << 32 | position) in first-position mode
     size_t cap_regions;
+    uint32_t *d_out_pos;    // first-position output of the next KSSD_SKETCH_FIRST_POS call (caller's buffer)
     uint64_t *d_cand;       // candidate list of the last scan (one slice per scan wave)
     size_t cap_cand;
     uint32_t *d_cand_count;
@@ -518,6 +519,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
 // candidate at full occupancy.  Survivors are appended to their genome's staging region with one returning
 // atomic per wave and genome.
 // ---------------------------------------------------------------------------------------------------
+// Staged tuples are sorted per genome.  Plain mode: the key is the reduced tuple (u32).  First-position mode
+// (KSSD_SKETCH_FIRST_POS): key = tuple << 32 | position inside the genome, so that the first entry of a run of equal
+// tuples carries the tuple's first occurrence -- what the host needs to replay the reference's hash insertions in
+// sequence order and leave combco.* byte-identical even where two ids of a genome probe the same slot.
+template <typename K> struct KeyOps;
+template <> struct KeyOps<uint32_t> {
+    static __device__ __forceinline__ uint32_t id(uint32_t k) { return k; }
+    static __device__ __forceinline__ uint32_t pos(uint32_t) { return 0u; }
+    static __device__ __forceinline__ uint32_t make(uint32_t dr, uint32_t) { return dr; }
+    static constexpr uint32_t pad() { return 0xFFFFFFFFu; }
+};
+template <> struct KeyOps<unsigned long long> {
+    static __device__ __forceinline__ uint32_t id(unsigned long long k) { return (uint32_t)(k >> 32); }
+    static __device__ __forceinline__ uint32_t pos(unsigned long long k) { return (uint32_t)k; }
+    static __device__ __forceinline__ unsigned long long make(uint32_t dr, uint32_t p) { return ((unsigned long long)dr << 32) | p; }
+    static constexpr unsigned long long pad() { return 0xFFFFFFFFFFFFFFFFull; }
+};
+
 struct ExactArgs {
     const uint32_t *packed;
     const uint32_t *mask;
@@ -531,10 +550,11 @@ struct ExactArgs {
     uint32_t n_slices;
     const unsigned long long *reg_off;
     uint32_t *cursor;
-    uint32_t *regions;
+    void *regions;  // uint32_t[] or, in first-position mode, unsigned long long[]
     SketchStatus *status;
 };
 
+template <typename K>
 __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactArgs x)
 {
     // grid = (blocks per slice, slices): block (bx, w) takes candidates [256 bx, 256 bx + 256) of scan wave w
@@ -549,7 +569,7 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= n) return;  // whole block past the end of the slice
     bool ok = false;
-    uint32_t dr = 0, gid = 0;
+    uint32_t dr = 0, gid = 0, gpos = 0;
     if (i < n) {
         // same arithmetic as kssd_stage2 (kssd_core.h), arranged so that the reads that do not depend on each
         // other are issued together: {genome of the chunk, packed words, mask words}, then {genome bounds, both
@@ -575,6 +595,7 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         const long long glo = (long long)(x.chunk_off[gid] * KSSD_CHUNK), ghi = (long long)(x.chunk_off[gid + 1] * KSSD_CHUNK);
         const bool h1 = e1.key == dim, h2 = e2.key == dim;
         ok = valid && (h1 || h2) && b0 >= glo && b0 + P.nb <= ghi;
+        gpos = (uint32_t)(s - glo);  // first-position mode: genomes are < 2^32 positions there (checked on the host)
         dr = kssd_s2_tuple(P, u, h1 ? e1.rank : e2.rank);
     }
     // group the wave's survivors by genome (candidates arrive in stream order: almost always one genome)
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         if (mine) {
             const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
             const unsigned long long pos = (unsigned long long)at + rank_in(grp);
-            if (pos < cap) x.regions[r0 + pos] = dr;
+            if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = KeyOps<K>::make(dr, gpos);
         }
         todo &= ~grp;
     }
@@ -618,14 +639,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum /
     return off + incl - v;
 }
 
+template <typename K>
 __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
                                                                       const uint32_t *__restrict__ cursor,
-                                                                      uint32_t *__restrict__ regions, uint32_t *__restrict__ kept,
+                                                                      K *__restrict__ regions, uint32_t *__restrict__ kept,
                                                                       uint32_t flags, uint32_t min_occ, uint32_t big_min,
                                                                       SketchStatus *st)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *a = reinterpret_cast<uint32_t *>(smem);
+    K *a = reinterpret_cast<K *>(smem);
     if (reg_off[blockIdx.x + 1] - reg_off[blockIdx.x] > big_min) return;  // too large for LDS: the global-memory path below
     __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
     __shared__ uint32_t s_distinct, s_zero_occ;
@@ -644,7 +666,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
     }
     uint32_t np = 1;
     while (np < n) np <<= 1;
-    for (uint32_t i = tid; i < np; i += DEDUP_THREADS) a[i] = i < n ? regions[r0 + i] : 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < np; i += DEDUP_THREADS) a[i] = i < n ? regions[r0 + i] : KeyOps<K>::pad();
     if (tid == 0) { s_distinct = 0; s_zero_occ = 0; }
     __syncthreads();
     for (uint32_t k = 2; k <= np; k <<= 1) {
@@ -653,27 +675,29 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
                 // t-th compare-exchange pair of this pass
                 const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const uint32_t p = i | j;
-                const uint32_t x = a[i], y = a[p];
+                const K x = a[i], y = a[p];
                 const bool asc = (i & k) == 0;
                 if ((x > y) == asc) { a[i] = y; a[p] = x; }
             }
             __syncthreads();
         }
     }
-    // runs of equal values; only the first n entries are real
+    // runs of equal tuples; only the first n entries are real (in first-position mode the first entry of a run is
+    // the tuple's first occurrence)
     uint32_t out_base = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += DEDUP_THREADS) {
         const uint32_t i = i0 + tid;
         bool keep = false;
-        uint32_t v = 0;
+        K kv = 0;
         if (i < n) {
-            v = a[i];
-            const bool start = (i == 0) || (a[i - 1] != v);
+            kv = a[i];
+            const uint32_t v = KeyOps<K>::id(kv);
+            const bool start = (i == 0) || (KeyOps<K>::id(a[i - 1]) != v);
             if (start) {
-                uint32_t lo = i + 1, hi = n;  // first index > i with a different value
+                uint32_t lo = i + 1, hi = n;  // first index > i with a different tuple
                 while (lo < hi) {
                     uint32_t mid = (lo + hi) >> 1;
-                    if (a[mid] == v) lo = mid + 1;
+                    if (KeyOps<K>::id(a[mid]) == v) lo = mid + 1;
                     else hi = mid;
                 }
                 const uint32_t len = lo - i;
@@ -689,7 +713,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
         }
         uint32_t tot;
         const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
-        if (keep) regions[r0 + out_base + pos] = v;  // out_base+pos <= i: never overtakes unread input (input is in LDS)
+        if (keep) regions[r0 + out_base + pos] = kv;  // out_base+pos <= i: never overtakes unread input (input is in LDS)
         out_base += tot;
     }
     __syncthreads();
@@ -711,7 +735,8 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
 #define BIG_THREADS DEDUP_THREADS  // block_excl_scan is sized for it
 #define BIG_TILE 2048  // sorted entries per workgroup
 
-__global__ void big_pad_kernel(uint32_t *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
+template <typename K>
+__global__ void big_pad_kernel(K *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
                                uint32_t *__restrict__ kept_g, uint32_t *__restrict__ acc /*[2]: distinct, zero occurrences*/,
                                SketchStatus *st)
 {
@@ -726,16 +751,16 @@ __global__ void big_pad_kernel(uint32_t *__restrict__ region, unsigned long long
         }
     }
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * blockDim.x)
-        if (i >= n) region[i] = 0xFFFFFFFFu;
+        if (i >= n) region[i] = KeyOps<K>::pad();
 }
 
 // WRITE = false: per-tile count of kept ids (+ the genome's distinct / zero-occurrence totals);
 // WRITE = true: compaction into `out` at the tile's scanned offset
-template <bool WRITE>
-__global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const uint32_t *__restrict__ a /*sorted*/, unsigned long long cap,
+template <typename K, bool WRITE>
+__global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const K *__restrict__ a /*sorted*/, unsigned long long cap,
                                                                 const uint32_t *__restrict__ cursor_g, uint32_t flags,
                                                                 uint32_t min_occ, uint32_t *__restrict__ tile_cnt,
-                                                                uint32_t *__restrict__ acc, uint32_t *__restrict__ out)
+                                                                uint32_t *__restrict__ acc, K *__restrict__ out)
 {
     __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
     const unsigned long long n = *cursor_g;
@@ -746,14 +771,16 @@ __global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const uint32_t *_
     for (uint32_t i0 = 0; i0 < BIG_TILE; i0 += BIG_THREADS) {
         const unsigned long long i = t0 + i0 + threadIdx.x;
         bool keep = false;
+        K kv = 0;
         uint32_t v = 0;
         if (i < n) {
-            v = a[i];
-            if (i == 0 || a[i - 1] != v) {
-                unsigned long long lo = i + 1, hi = n;  // first index > i with a different value
+            kv = a[i];
+            v = KeyOps<K>::id(kv);
+            if (i == 0 || KeyOps<K>::id(a[i - 1]) != v) {
+                unsigned long long lo = i + 1, hi = n;  // first index > i with a different tuple
                 while (lo < hi) {
                     const unsigned long long mid = (lo + hi) >> 1;
-                    if (a[mid] == v) lo = mid + 1;
+                    if (KeyOps<K>::id(a[mid]) == v) lo = mid + 1;
                     else hi = mid;
                 }
                 const unsigned long long len = lo - i;
@@ -769,7 +796,7 @@ __global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const uint32_t *_
         }
         uint32_t tot;
         const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
-        if (WRITE && keep) out[out_base + pos] = v;
+        if (WRITE && keep) out[out_base + pos] = kv;
         out_base += tot;
     }
     if (!WRITE) {
@@ -843,17 +870,23 @@ __global__ __launch_bounds__(1024) void sketch_offsets_kernel(const uint32_t *__
 }
 
 // kernel 4: gather every genome's kept ids into the dense CSR
+template <typename K>
 __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long long *__restrict__ reg_off,
-                                                             const uint32_t *__restrict__ regions,
+                                                             const K *__restrict__ regions,
                                                              const uint32_t *__restrict__ kept,
                                                              const unsigned long long *__restrict__ out_off,
-                                                             uint32_t *__restrict__ out_ids, const SketchStatus *st)
+                                                             uint32_t *__restrict__ out_ids, uint32_t *__restrict__ out_pos,
+                                                             const SketchStatus *st)
 {
     if (st->out_overflow) return;
     const uint32_t g = blockIdx.x;
     const uint32_t n = kept[g];
     const unsigned long long r0 = reg_off[g], o0 = out_off[g];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) out_ids[o0 + i] = regions[r0 + i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const K kv = regions[r0 + i];
+        out_ids[o0 + i] = KeyOps<K>::id(kv);
+        if (out_pos) out_pos[o0 + i] = KeyOps<K>::pos(kv);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -867,6 +900,61 @@ static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t
     return KSSD_OK;
 }
 
+// per-genome dedup (LDS sort or, for large genomes, rocPRIM sort + run kernels), CSR offsets, gather; K = key type
+template <typename K>
+static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint32_t big_min, uint64_t max_cap,
+                         uint64_t max_big, uint64_t *d_out_off, uint32_t *d_out_ids, uint32_t *d_out_pos, uint64_t out_cap,
+                         hipStream_t s)
+{
+    int rc;
+    K *regions = reinterpret_cast<K *>(c->d_regions);
+    uint32_t np = 1;
+    while (np < max_cap) np <<= 1;
+    const size_t dlds = (size_t)np * sizeof(K);
+    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
+    hipLaunchKernelGGL((sketch_dedup_kernel<K>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
+                       (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
+                       flags, min_occ, big_min, c->d_status);
+    if (!c->h_big.empty()) {
+        const size_t n_tiles_max = (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
+        const size_t kw = sizeof(K) / 4;  // u32 words per key
+        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, (size_t)max_big * kw + n_tiles_max + 8)) != KSSD_OK) return rc;
+        size_t tmp_bytes = 0;
+        HIPCK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (K *)nullptr, (K *)nullptr, (size_t)max_big, 0u, (unsigned)(8 * sizeof(K)), s));
+        if (tmp_bytes > c->cap_big_tmp) {
+            if (c->d_big_tmp) hipFree(c->d_big_tmp);
+            c->d_big_tmp = nullptr;
+            c->cap_big_tmp = 0;
+            if (hipMalloc(&c->d_big_tmp, tmp_bytes) != hipSuccess) return KSSD_ERR_NOMEM;
+            c->cap_big_tmp = tmp_bytes;
+        }
+        for (uint32_t g : c->h_big) {
+            const uint64_t r0 = c->h_reg_off[g], cap = c->h_reg_off[g + 1] - r0;
+            const uint32_t n_tiles = (uint32_t)((cap + BIG_TILE - 1) / BIG_TILE);
+            K *region = regions + r0, *sorted = reinterpret_cast<K *>(c->d_big_alt);
+            uint32_t *tile_cnt = c->d_big_alt + (size_t)max_big * kw, *accum = tile_cnt + n_tiles_max;
+            const uint32_t *cur = c->d_cursor + g;
+            hipLaunchKernelGGL((big_pad_kernel<K>), dim3(1024), dim3(256), 0, s, region, (unsigned long long)cap, cur, c->d_kept + g, accum,
+                               c->d_status);
+            size_t tb = c->cap_big_tmp;
+            HIPCK(rocprim::radix_sort_keys(c->d_big_tmp, tb, region, sorted, (size_t)cap, 0u, (unsigned)(8 * sizeof(K)), s));
+            hipLaunchKernelGGL((big_runs_kernel<K, false>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const K *)sorted,
+                               (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, (K *)nullptr);
+            hipLaunchKernelGGL(big_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_tiles, (const uint32_t *)accum, c->P.hashlimit,
+                               flags, g, (unsigned long long)cap, cur, c->d_kept + g, c->d_status);
+            hipLaunchKernelGGL((big_runs_kernel<K, true>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const K *)sorted,
+                               (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, region);
+        }
+    }
+    hipLaunchKernelGGL(sketch_offsets_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)c->d_kept, n_genomes,
+                       (unsigned long long *)d_out_off, (unsigned long long)out_cap, c->d_status);
+    hipLaunchKernelGGL((sketch_gather_kernel<K>), dim3(n_genomes), dim3(256), 0, s, (const unsigned long long *)c->d_reg_off,
+                       (const K *)regions, (const uint32_t *)c->d_kept, (const unsigned long long *)d_out_off,
+                       d_out_ids, d_out_pos, (const SketchStatus *)c->d_status);
+    return KSSD_OK;
+}
+
 extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask,
                                       const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
                                       uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap, void *stream)
@@ -877,6 +965,8 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     c->last_launch_rc = KSSD_OK;
     c->last_n_genomes = n_genomes;
     if (min_occ < 1) min_occ = 1;
+    const bool with_pos = (flags & KSSD_SKETCH_FIRST_POS) != 0;
+    if (with_pos && !c->d_out_pos) return KSSD_ERR_PARAM;  // kssd_gpu_sketch_set_pos_output first
     const uint64_t n_chunks = h_chunk_off[n_genomes];
     HIPCK(hipMemsetAsync(c->d_status, 0, sizeof(SketchStatus), s));
     if (n_genomes == 0) {
@@ -888,11 +978,13 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     c->h_reg_off.resize((size_t)n_genomes + 1);
     c->h_big.clear();
     const uint32_t big_min_env = getenv("KSSD_DEV_BIG_MIN") ? (uint32_t)atoi(getenv("KSSD_DEV_BIG_MIN")) : 0u;  // tests only
-    const uint32_t big_min = big_min_env ? big_min_env : DEDUP_MAX_N;
+    uint32_t big_min = big_min_env ? big_min_env : DEDUP_MAX_N;
+    if (with_pos && big_min > DEDUP_MAX_N / 2) big_min = DEDUP_MAX_N / 2;  // 8-byte keys: half as many fit the LDS sort
     uint64_t acc = 0, max_cap = 0, max_big = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
         if (h_chunk_off[g + 1] < h_chunk_off[g]) return KSSD_ERR_PARAM;
         const uint64_t pos = (h_chunk_off[g + 1] - h_chunk_off[g]) * KSSD_CHUNK;
+        if (with_pos && pos >= (1ull << 32)) { c->last_launch_rc = KSSD_ERR_UNSUPPORTED; return KSSD_ERR_UNSUPPORTED; }
         uint64_t cap = (uint64_t)((double)pos * rate * c->region_factor) + 256;
         if (cap > pos) cap = pos;  // a genome cannot emit more tuples than it has positions
         if (cap > big_min) {
@@ -914,7 +1006,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     if ((rc = ensure(&c->d_reg_off, &c->cap_reg_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_cursor, &c->cap_cursor, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_kept, &c->cap_kept, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
-    if ((rc = ensure(&c->d_regions, &c->cap_regions, (size_t)acc + 1)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_regions, &c->cap_regions, ((size_t)acc + 1) * (with_pos ? 2 : 1))) != KSSD_OK) return rc;
     // candidate list between the scan and the exact stage: patterns of S (both strands) + Bloom false positives
     // (one private slice per wave of the scan grid)
     const uint64_t want_blocks = (n_chunks + SCAN_WAVES - 1) / SCAN_WAVES;
@@ -968,50 +1060,22 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         x.n_slices = n_slices;
         x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
         x.status = c->d_status;
-        hipLaunchKernelGGL(sketch_exact_kernel, dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
+        if (with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
+        else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
     }
-    uint32_t np = 1;
-    while (np < max_cap) np <<= 1;
-    const size_t dlds = (size_t)np * 4;
-    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
-    hipLaunchKernelGGL(sketch_dedup_kernel, dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
-                       (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, c->d_regions, c->d_kept,
-                       flags, min_occ, big_min, c->d_status);
-    if (!c->h_big.empty()) {
-        const size_t n_tiles_max = (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
-        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, (size_t)max_big + n_tiles_max + 8)) != KSSD_OK) return rc;
-        size_t tmp_bytes = 0;
-        HIPCK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)max_big, 0u, 32u, s));
-        if (tmp_bytes > c->cap_big_tmp) {
-            if (c->d_big_tmp) hipFree(c->d_big_tmp);
-            c->d_big_tmp = nullptr;
-            c->cap_big_tmp = 0;
-            if (hipMalloc(&c->d_big_tmp, tmp_bytes) != hipSuccess) return KSSD_ERR_NOMEM;
-            c->cap_big_tmp = tmp_bytes;
-        }
-        for (uint32_t g : c->h_big) {
-            const uint64_t r0 = c->h_reg_off[g], cap = c->h_reg_off[g + 1] - r0;
-            const uint32_t n_tiles = (uint32_t)((cap + BIG_TILE - 1) / BIG_TILE);
-            uint32_t *region = c->d_regions + r0, *sorted = c->d_big_alt, *tile_cnt = c->d_big_alt + max_big, *accum = tile_cnt + n_tiles_max;
-            const uint32_t *cur = c->d_cursor + g;
-            hipLaunchKernelGGL(big_pad_kernel, dim3(1024), dim3(256), 0, s, region, (unsigned long long)cap, cur, c->d_kept + g, accum, c->d_status);
-            size_t tb = c->cap_big_tmp;
-            HIPCK(rocprim::radix_sort_keys(c->d_big_tmp, tb, region, sorted, (size_t)cap, 0u, 32u, s));
-            hipLaunchKernelGGL((big_runs_kernel<false>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const uint32_t *)sorted,
-                               (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, (uint32_t *)nullptr);
-            hipLaunchKernelGGL(big_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_tiles, (const uint32_t *)accum, c->P.hashlimit,
-                               flags, g, (unsigned long long)cap, cur, c->d_kept + g, c->d_status);
-            hipLaunchKernelGGL((big_runs_kernel<true>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const uint32_t *)sorted,
-                               (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, region);
-        }
-    }
-    hipLaunchKernelGGL(sketch_offsets_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)c->d_kept, n_genomes,
-                       (unsigned long long *)d_out_off, (unsigned long long)out_cap, c->d_status);
-    hipLaunchKernelGGL(sketch_gather_kernel, dim3(n_genomes), dim3(256), 0, s, (const unsigned long long *)c->d_reg_off,
-                       (const uint32_t *)c->d_regions, (const uint32_t *)c->d_kept, (const unsigned long long *)d_out_off,
-                       d_out_ids, (const SketchStatus *)c->d_status);
+    rc = with_pos ? finish_sketch<unsigned long long>(c, n_genomes, flags, min_occ, big_min, max_cap, max_big, d_out_off, d_out_ids,
+                                                      c->d_out_pos, out_cap, s)
+                  : finish_sketch<uint32_t>(c, n_genomes, flags, min_occ, big_min, max_cap, max_big, d_out_off, d_out_ids, nullptr,
+                                            out_cap, s);
+    if (rc != KSSD_OK) return rc;
     HIPCK(hipGetLastError());
+    return KSSD_OK;
+}
+
+extern "C" int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *c, uint32_t *d_out_pos)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    c->d_out_pos = d_out_pos;
     return KSSD_OK;
 }
 
@@ -1058,25 +1122,28 @@ extern "C" int kssd_gpu_scan_stats(kssd_gpu_ctx *c, uint64_t *stage1, uint64_t *
     return KSSD_OK;
 }
 
-extern "C" int kssd_gpu_sketch_batch(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask,
-                                     const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
-                                     uint64_t **out_off, uint32_t **out_ids, int64_t *bad_genome)
+static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask, const uint64_t *chunk_off,
+                             uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                             uint32_t **out_pos, int64_t *bad_genome)
 {
     if (!c || !chunk_off || !out_off || !out_ids) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     *out_off = nullptr;
     *out_ids = nullptr;
+    if (out_pos) *out_pos = nullptr;
     const uint64_t n_chunks = chunk_off[n_genomes];
     const size_t pw = (size_t)n_chunks * KSSD_CHUNK_WORDS + KSSD_PACK_SLACK_WORDS;
     const size_t mw = (size_t)n_chunks * KSSD_CHUNK_MASKW + KSSD_PACK_SLACK_WORDS;
-    uint32_t *d_p = nullptr, *d_m = nullptr, *d_ids = nullptr;
+    uint32_t *d_p = nullptr, *d_m = nullptr, *d_ids = nullptr, *d_pos = nullptr;
     uint64_t *d_off = nullptr;
     int rc = KSSD_OK;
     auto cleanup = [&]() {
         if (d_p) hipFree(d_p);
         if (d_m) hipFree(d_m);
         if (d_ids) hipFree(d_ids);
+        if (d_pos) hipFree(d_pos);
         if (d_off) hipFree(d_off);
+        c->d_out_pos = nullptr;
     };
 #define BCK(x) do { if ((x) != hipSuccess) { rc = hip_fail(hipGetLastError(), #x, __LINE__); cleanup(); return rc; } } while (0)
     BCK(hipMalloc(&d_p, pw * 4));
@@ -1088,12 +1155,19 @@ extern "C" int kssd_gpu_sketch_batch(kssd_gpu_ctx *c, const uint32_t *packed, co
         BCK(hipMemcpy(d_p, packed, (size_t)n_chunks * KSSD_CHUNK_WORDS * 4, hipMemcpyHostToDevice));
         BCK(hipMemcpy(d_m, mask, (size_t)n_chunks * KSSD_CHUNK_MASKW * 4, hipMemcpyHostToDevice));
     }
+    if (out_pos) flags |= KSSD_SKETCH_FIRST_POS;
+    else flags &= ~KSSD_SKETCH_FIRST_POS;
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     uint64_t out_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * rate * 1.5) + 1024;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 12; attempt++) {
         if (d_ids) { hipFree(d_ids); d_ids = nullptr; }
+        if (d_pos) { hipFree(d_pos); d_pos = nullptr; }
         BCK(hipMalloc(&d_ids, (size_t)out_cap * 4));
+        if (out_pos) {
+            BCK(hipMalloc(&d_pos, (size_t)out_cap * 4));
+            c->d_out_pos = d_pos;
+        }
         rc = kssd_gpu_sketch_device(c, d_p, d_m, chunk_off, n_genomes, flags, min_occ, d_off, d_ids, out_cap, nullptr);
         if (rc != KSSD_OK) break;
         rc = kssd_gpu_sketch_status(c, &total, bad_genome, nullptr);
@@ -1103,15 +1177,33 @@ extern "C" int kssd_gpu_sketch_batch(kssd_gpu_ctx *c, const uint32_t *packed, co
     if (rc == KSSD_OK) {
         uint64_t *h_off = (uint64_t *)malloc(((size_t)n_genomes + 1) * 8);
         uint32_t *h_ids = (uint32_t *)malloc((size_t)(total ? total : 1) * 4);
-        if (!h_off || !h_ids) { free(h_off); free(h_ids); cleanup(); return KSSD_ERR_NOMEM; }
+        uint32_t *h_pos = out_pos ? (uint32_t *)malloc((size_t)(total ? total : 1) * 4) : nullptr;
+        if (!h_off || !h_ids || (out_pos && !h_pos)) { free(h_off); free(h_ids); free(h_pos); cleanup(); return KSSD_ERR_NOMEM; }
         BCK(hipMemcpy(h_off, d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost));
         if (total) BCK(hipMemcpy(h_ids, d_ids, (size_t)total * 4, hipMemcpyDeviceToHost));
+        if (total && out_pos) BCK(hipMemcpy(h_pos, d_pos, (size_t)total * 4, hipMemcpyDeviceToHost));
         *out_off = h_off;
         *out_ids = h_ids;
+        if (out_pos) *out_pos = h_pos;
     }
     cleanup();
     return rc;
 #undef BCK
+}
+
+extern "C" int kssd_gpu_sketch_batch(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask,
+                                     const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
+                                     uint64_t **out_off, uint32_t **out_ids, int64_t *bad_genome)
+{
+    return sketch_batch_impl(c, packed, mask, chunk_off, n_genomes, flags, min_occ, out_off, out_ids, nullptr, bad_genome);
+}
+
+extern "C" int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask,
+                                         const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
+                                         uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome)
+{
+    if (!out_pos) return KSSD_ERR_PARAM;
+    return sketch_batch_impl(c, packed, mask, chunk_off, n_genomes, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
 }
 
 extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float *avg_ms, uint32_t *launches)

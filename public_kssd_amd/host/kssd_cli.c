@@ -215,6 +215,7 @@ typedef struct {
     uint32_t *ids;
     uint64_t n_ids, cap_ids;
     uint32_t n;
+    uint32_t hashsize;
 } csr_acc;
 
 static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *acc, filelist *fl, uint32_t first_file)
@@ -223,13 +224,16 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     if (!n) return;
     uint32_t flags = is_fq ? (KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY) : (o->u ? KSSD_SKETCH_UNIQ : KSSD_SKETCH_FASTA);
     uint64_t *off = NULL;
-    uint32_t *ids = NULL;
+    uint32_t *ids = NULL, *pos = NULL;
     int64_t bad = -1;
-    int rc = kssd_gpu_sketch_batch(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), n, flags,
-                                   is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &bad);
+    int rc = kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), n, flags,
+                                       is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &pos, &bad);
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
+    /* file order inside a genome = the reference's hash-slot order, insertions replayed in sequence order */
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint32_t g = 0; g < n; g++) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], acc->hashsize);
     uint64_t add = off[n];
     if (acc->n_ids + add > acc->cap_ids) {
         acc->cap_ids = (acc->n_ids + add) * 2 + 1024;
@@ -241,6 +245,7 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     acc->n_ids += add;
     kssd_gpu_free(off);
     kssd_gpu_free(ids);
+    kssd_gpu_free(pos);
     kssd_batch_clear(b);
 }
 
@@ -260,6 +265,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     kssd_shuf_release(&shuf);
 
     csr_acc acc = {0};
+    acc.hashsize = d.hashsize;
     acc.off = calloc((size_t)fl->n + 1, sizeof(uint64_t));
     kssd_batch *cur = kssd_batch_create();
     const uint64_t max_chunks = 1ull << 19; /* ~2 Gbases per device batch */
@@ -307,7 +313,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     s.off = acc.off;
     s.ids = acc.ids ? acc.ids : calloc(1, 4);
     s.names = fl->path;
-    int rc = kssd_sketchset_write(&s, outdir, d.hashsize, 1);
+    int rc = kssd_sketchset_write(&s, outdir, d.hashsize, 0); /* already in slot order */
     if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
     free(acc.off);
     free(s.ids);

@@ -67,10 +67,20 @@ static int cmp_slot(const void *a, const void *b)
     return x < y ? -1 : x > y;
 }
 
-void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
+typedef struct {
+    uint32_t pos, id;
+} pos_id;
+
+static int cmp_pos(const void *a, const void *b)
 {
-    if (n < 2) return;
-    /* replay the reference's insertions (ascending id order) into a sparse image of its table */
+    uint32_t x = ((const pos_id *)a)->pos, y = ((const pos_id *)b)->pos;
+    return x < y ? -1 : x > y;
+}
+
+/* replay the reference's insertions, in the order given, into a sparse image of its table; ids come back in
+ * ascending slot order */
+static void slot_order_replay(uint32_t *ids, uint64_t n, uint32_t hashsize)
+{
     uint64_t cap = 16;
     while (cap < 4 * n) cap <<= 1;
     uint32_t *occ = malloc(cap * sizeof(uint32_t)); /* open-addressing set of occupied slots, 0xFFFFFFFF = free */
@@ -101,6 +111,24 @@ void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
     for (uint64_t i = 0; i < n; i++) ids[i] = sl[i].id;
     free(occ);
     free(sl);
+}
+
+void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
+{
+    if (n < 2) return;
+    slot_order_replay(ids, n, hashsize); /* insertions in ascending id order */
+}
+
+void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize)
+{
+    if (n < 2) return;
+    pos_id *pi = malloc(n * sizeof(pos_id));
+    if (!pi) return;
+    for (uint64_t i = 0; i < n; i++) { pi[i].pos = first_pos[i]; pi[i].id = ids[i]; }
+    qsort(pi, n, sizeof(pos_id), cmp_pos); /* first positions are distinct: one k-mer per position */
+    for (uint64_t i = 0; i < n; i++) ids[i] = pi[i].id;
+    free(pi);
+    slot_order_replay(ids, n, hashsize); /* insertions in sequence order, as fasta2co makes them */
 }
 
 /* ---- stat files ---------------------------------------------------------------------------------------- */

@@ -90,6 +90,11 @@ void kssd_sketchset_release(kssd_sketchset *s);
  * the same slot depend on which the reference met first in the sequence; here the smaller id wins, so
  * the result is byte-identical to the reference's file unless two ids of the genome collide. */
 void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize);
+/* The same with every id's first position in the genome (kssd_gpu_sketch_batch_pos): the insertions are replayed
+ * in sequence order like fasta2co makes them (iseq2comem.c:254-268), so colliding ids land where the reference
+ * puts them and the file is byte-identical.  (fastq -n >= 2 and -u also let ids that are dropped later occupy
+ * slots: there the order is exact only in the absence of collisions with such ids.) */
+void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
 
 /* write cofiles.stat + combco.<c> + combco.index.<c> like run_stageI (command_dist.c:314-378).
  * slot_order != 0 applies kssd_slot_order per genome (ids are modified in place). */

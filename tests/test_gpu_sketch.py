@@ -238,3 +238,47 @@ def test_many_tiny_genomes_share_waves_and_chunks(gpu_ctx, shuf_l3k10):
         got = ids[int(off[g]):int(off[g + 1])]
         assert np.array_equal(got, np.sort(sk.fasta(texts[g]))), g
         assert np.isin(got, want_all).all()
+
+
+def test_first_positions_give_the_reference_file_order():
+    """combco byte order: the reference dumps its hash table slot by slot; where two ids of a genome probe the same
+    slot the earlier one in the sequence keeps it.  With the device's first positions the host replays exactly that.
+    A small table (131 071 slots for ~7 800 ids) makes hundreds of such collisions per genome."""
+    shuf = K.Shuf.generate(8, 5, 2, seed=3)
+    hs = K.derive(8, 5, 2).hashsize
+    assert hs == 131071
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        rng = np.random.default_rng(2)
+        texts = [fasta_text(rng.integers(0, 4, n, dtype=np.uint8)) for n in (2_000_000, 700_000, 30_000)]
+        b = K.Batch()
+        for t in texts:
+            b.add_fasta(t)
+        off, ids, pos = ctx.sketch_batch_pos(b)
+        off2, ids2 = ctx.sketch_batch(b)
+        assert np.array_equal(off, off2) and np.array_equal(ids, ids2)  # same sets, ascending, with or without positions
+        sk = ko.Sketcher(shuf.table, 8, 5, 2)
+        differs = 0
+        for g, t in enumerate(texts):
+            dump = sk.fasta(t)  # the reference's file order
+            mine, p = ids[int(off[g]):int(off[g + 1])], pos[int(off[g]):int(off[g + 1])]
+            assert len(np.unique(p)) == len(p)  # one k-mer per position
+            assert np.array_equal(K.slot_order_pos(mine, p, hs), dump), g
+            differs += int(not np.array_equal(K.slot_order(mine, hs), dump))
+        assert differs >= 1  # the ascending-id replay is NOT enough here: the positions matter
+    finally:
+        ctx.close()
+
+
+def test_first_positions_through_the_big_genome_path(shuf_l3k10, force_big_path):
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        rng = np.random.default_rng(6)
+        t = fasta_text(rng.integers(0, 4, 3_000_000, dtype=np.uint8))
+        b = K.Batch()
+        b.add_fasta(t)
+        off, ids, pos = ctx.sketch_batch_pos(b)
+        sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+        assert np.array_equal(K.slot_order_pos(ids, pos, sk.p.hashsize), sk.fasta(t))
+    finally:
+        ctx.close()
