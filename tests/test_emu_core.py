@@ -50,8 +50,8 @@ def texts(rng):
     return [multi, rnd(8000), b">e\nACGT\n", rnd(4096 * 3 - 7), rnd(4096 * 2)]
 
 
-CASES = [(k, s, d, 0) for k, s, d in [(10, 6, 3), (8, 5, 2), (10, 7, 5), (9, 6, 3), (11, 6, 3), (8, 4, 1), (12, 7, 4),
-                                      (9, 3, 1)]]
+# (one subk = 7 case: its 1 GiB .shuf takes most of this module's time; 10/7/5 is covered by the -m gpu tests)
+CASES = [(k, s, d, 0) for k, s, d in [(10, 6, 3), (8, 5, 2), (9, 6, 3), (11, 6, 3), (8, 4, 1), (12, 7, 4), (9, 3, 1)]]
 CASES += [(10, 6, 3, 4)]  # gw = 0: the kernel's KSSD_GW; 4: another instantiation of the same templates
 
 
