@@ -226,14 +226,25 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     uint64_t *off = NULL;
     uint32_t *ids = NULL, *pos = NULL;
     int64_t bad = -1;
-    int rc = kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), n, flags,
-                                       is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &pos, &bad);
+    /* first positions (for the reference's exact file order) need genomes below 2^32 positions */
+    int with_pos = 1;
+    const uint64_t *co = kssd_batch_chunk_off(b);
+    for (uint32_t g = 0; g < n; g++)
+        if (co[g + 1] - co[g] >= (1ull << 20)) with_pos = 0;
+    int rc = with_pos ? kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
+                                                  is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &pos, &bad)
+                      : kssd_gpu_sketch_batch(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
+                                              is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &bad);
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
-    /* file order inside a genome = the reference's hash-slot order, insertions replayed in sequence order */
+    /* file order inside a genome = the reference's hash-slot order, insertions replayed in sequence order (or, for
+     * a genome of 2^32 positions and more, in ascending id order: exact unless two of its ids probe the same slot) */
 #pragma omp parallel for schedule(dynamic, 16)
-    for (uint32_t g = 0; g < n; g++) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], acc->hashsize);
+    for (uint32_t g = 0; g < n; g++) {
+        if (with_pos) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], acc->hashsize);
+        else kssd_slot_order(ids + off[g], off[g + 1] - off[g], acc->hashsize);
+    }
     uint64_t add = off[n];
     if (acc->n_ids + add > acc->cap_ids) {
         acc->cap_ids = (acc->n_ids + add) * 2 + 1024;
