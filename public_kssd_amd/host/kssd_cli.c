@@ -389,6 +389,56 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
     kssd_sketchset_release(&qry);
 }
 
+/* several sketch directories -> one (combine_queries, command_dist.c:1323-1475): the first directory sets the shuffle;
+ * later ones that are not sketch directories, carry another shuf_id or the abundance flag are skipped with the
+ * reference's messages; genomes keep their order, ids keep the order they have in the files */
+static void combine_queries(const dist_opt *o)
+{
+    if (o->abundance) die(EINVAL, "combine_queries(): abundance model not supported yet");
+    kssd_sketchset all;
+    memset(&all, 0, sizeof all);
+    int rc = kssd_sketchset_read(&all, o->args[0]);
+    if (rc) die(EIO, "combine_queries():%s/cofiles.stat: %s", o->args[0], kssd_host_strerror(rc));
+    if (all.koc) die(EINVAL, "combine_queries(): abundance model not supported yet");
+    for (int i = 1; i < o->nargs; i++) {
+        if (!(kssd_probe_dir(o->args[i]) & 1)) {
+            printf("%dth query %s is not a valid query: no cofiles.stat file\n", i, o->args[i]);
+            continue;
+        }
+        kssd_sketchset it;
+        memset(&it, 0, sizeof it);
+        rc = kssd_sketchset_read(&it, o->args[i]);
+        if (rc) {
+            printf("combine_queries(): %dth query can not open %s/cofiles.stat\n", i, o->args[i]);
+            continue;
+        }
+        if (it.shuf_id != all.shuf_id) {
+            printf("combine_queries(): %dth shuf_id: %u not match 0th shuf_id: %u\n", i, it.shuf_id, all.shuf_id);
+            kssd_sketchset_release(&it);
+            continue;
+        }
+        if (it.koc) {
+            printf("combine_queries(): %dth query abundance model not supported yet \n", i);
+            kssd_sketchset_release(&it);
+            continue;
+        }
+        const uint64_t a = all.off[all.n], b = it.off[it.n];
+        all.off = realloc(all.off, ((size_t)all.n + it.n + 1) * sizeof(uint64_t));
+        all.ids = realloc(all.ids, (size_t)(a + b ? a + b : 1) * 4);
+        all.names = realloc(all.names, ((size_t)all.n + it.n) * sizeof *all.names);
+        if (!all.off || !all.ids || !all.names) die(ENOMEM, "out of memory");
+        for (uint32_t g = 0; g < it.n; g++) all.off[all.n + g + 1] = a + it.off[g + 1];
+        memcpy(all.ids + a, it.ids, (size_t)b * 4);
+        memcpy(all.names + all.n, it.names, (size_t)it.n * sizeof *all.names);
+        all.n += it.n;
+        kssd_sketchset_release(&it);
+    }
+    mkdir(o->outdir, 0700);
+    rc = kssd_sketchset_write(&all, o->outdir, 0, 0);
+    if (rc) die(EIO, "%s: %s", o->outdir, kssd_host_strerror(rc));
+    kssd_sketchset_release(&all);
+}
+
 static int cmd_dist(int argc, char **argv)
 {
     dist_opt o;
@@ -477,7 +527,7 @@ static int cmd_dist(int argc, char **argv)
             else die(EINVAL, "please sketch the query sequences first (kssd dist -L <.shuf> -o <qrydir> <seqs>), then search with -r");
         } else if (qprobe & 1) {
             if (o.nargs == 1) build_index_files(o.args[0], o.outdir);
-            else die(ENOTSUP, "combining several sketch directories is outside the GPU hot path of this build (SURVEY.md section 8f)");
+            else combine_queries(&o);
         } else {
             filelist fl = {0};
             collect_inputs(&fl, o.nargs, o.args, o.fpath);

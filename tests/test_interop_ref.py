@@ -91,3 +91,28 @@ def test_config1_test_fna_tutorial_oracle_vs_reference(tmp_path, shuf_l3k10):
         want = (rs if i < len(rs.names) else qs).sets_by_name()[os.path.basename(nm)]
         assert np.array_equal(np.sort(ids[int(off[i]):int(off[i + 1])]), want), nm
     assert 1100 < np.diff(rs.off).min() and np.diff(rs.off).max() < 1600   # ~5.4 Mb / 4096
+
+
+def test_combine_queries_equals_the_reference(work, tmp_path):
+    """`kssd dist -o out dirA dirB dirC`: several sketch directories into one (command_dist.c:1323-1475); host-only,
+    so our command line runs here without a GPU.  A directory with another shuf_id is skipped with the same message."""
+    import subprocess
+    other = K.Shuf.generate(10, 6, 3, seed=999)
+    sp = str(tmp_path / "other.shuf")
+    other.write(sp)
+    ko.run_ref(["dist", "-p", 2, "-L", sp, "-o", str(tmp_path / "alien"), os.path.join(G, "qry_fa")], cwd=str(tmp_path))
+    args = [str(work / "ref"), str(work / "qry"), str(tmp_path / "alien"), str(work / "ref")]
+    r = ko.run_ref(["dist", "-o", str(tmp_path / "comb_ref")] + args, cwd=str(tmp_path))
+    ours = subprocess.run([os.path.join(os.path.dirname(G), "..", "public_kssd_amd", "kssd"), "dist", "-o", str(tmp_path / "comb_ours")] + args,
+                          cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert ours.returncode == 0, ours.stdout.decode()
+    msg = "combine_queries(): 2th shuf_id: %u not match 0th shuf_id: %u" % (other.id & 0xFFFFFFFF, K.SketchSet.read(str(work / "ref")).shuf_id)
+    assert msg in r.stdout.decode() and msg in ours.stdout.decode()
+    for f in ("combco.0", "combco.index.0"):
+        assert filecmp.cmp(str(tmp_path / "comb_ref" / f), str(tmp_path / "comb_ours" / f), shallow=False), f
+    a = bytearray(open(str(tmp_path / "comb_ref" / "cofiles.stat"), "rb").read())
+    b = bytearray(open(str(tmp_path / "comb_ours" / "cofiles.stat"), "rb").read())
+    a[5:8] = b[5:8] = b"\0\0\0"   # struct padding behind `bool koc`: the reference writes whatever its stack held
+    assert a == b
+    s = K.SketchSet.read(str(tmp_path / "comb_ours"))
+    assert len(s.names) == 2 * 6 + 3
