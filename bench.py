@@ -304,7 +304,7 @@ def main():
             res["cpu_baseline_port"] = cb["port"]
             res["cpu_baseline_dist"] = cb["dist_port"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and G == 1000 and L == 5_000_000:  # the PMC passes were collected on the default workload
             try:
                 res["roofline"]["traffic"] = json.load(open(pmc)).get("sketch_scan_bytes_per_launch")
             except Exception:

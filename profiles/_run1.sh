@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 900 python bench.py --genomes 10000 --clades 500 --steps 3 --warmup 1 --cpu-sample 0 2>&1 | tail -2 | cut -c1-1500
