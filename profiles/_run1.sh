@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py --genomes 10000 --clades 500 --steps 3 --warmup 1 --cpu-sample 0 2>&1 | tail -2 | cut -c1-1500
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for i in 1 2; do timeout 600 python bench.py --cpu-sample 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernels']['sketch_scan_ms'])"; done

@@ -295,10 +295,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 // ---------------------------------------------------------------------------------------------------
 // kernel 0: chunk -> genome map
 // ---------------------------------------------------------------------------------------------------
+// (it also zeroes the small per-call state: four separate memsets cost more than this whole kernel)
 __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes, uint64_t n_chunks,
-                                 uint32_t *__restrict__ chunk_gid)
+                                 uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
+                                 uint32_t n_slices, unsigned long long *__restrict__ lane_valid_tail)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_genomes) cursor[c] = 0;
+    if (c < n_slices) cand_count[c] = 0;
+    if (c < 2) lane_valid_tail[c] = 0;  // a k-mer that would end past the batch is not "known valid"
     if (c >= n_chunks) return;
     uint32_t lo = 0, hi = n_genomes;  // last g with chunk_off[g] <= c
     while (hi - lo > 1) {
@@ -1016,16 +1021,18 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
-    HIPCK(hipMemsetAsync(c->d_cand_count, 0, (size_t)n_slices * 4, s));
     if ((rc = ensure(&c->d_lane_valid, &c->cap_lane_valid, (size_t)n_chunks + 2)) != KSSD_OK) return rc;
-    HIPCK(hipMemsetAsync(c->d_lane_valid + n_chunks, 0, 16, s));  // a k-mer that would end past the batch is not "known valid"
 
     HIPCK(hipMemcpyAsync(c->d_chunk_off, h_chunk_off, ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCK(hipMemcpyAsync(c->d_reg_off, c->h_reg_off.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCK(hipMemsetAsync(c->d_cursor, 0, (size_t)n_genomes * 4, s));
+    {
+        uint64_t init_n = n_chunks > n_genomes ? n_chunks : n_genomes;
+        if (init_n < n_slices) init_n = n_slices;
+        hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
+                           (const uint64_t *)c->d_chunk_off, n_genomes, n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
+                           n_slices, c->d_lane_valid + n_chunks);
+    }
     if (n_chunks) {
-        hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s,
-                           (const uint64_t *)c->d_chunk_off, n_genomes, n_chunks, c->d_chunk_gid);
         ScanArgs a;
         a.packed = d_packed; a.mask = d_mask; a.n_chunks = n_chunks; a.tab = c->d_T1;
         a.cand = (unsigned long long *)c->d_cand; a.cand_cap = cand_cap; a.cand_count = c->d_cand_count;
