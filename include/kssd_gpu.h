@@ -163,6 +163,19 @@ int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids,
                   double *jaccard, double *mashd, double *contain, double *aafd);
 
 /*
+ * Set operations on sketches of ONE component (ids below 16^7): replace the 2^28-bit dictionary walks of
+ * `kssd set` (command_set.c).  HOST pointers in, malloc'd HOST arrays out (free with kssd_gpu_free).
+ *   kssd_gpu_set_union   -u (sketch_union, :226-288): the distinct ids of `ids`, ascending; uniq != 0: -q
+ *                        (uniq_sketch_union, :376-443): only the ids that occur exactly once in `ids`
+ *   kssd_gpu_set_filter  -s / -i (sketch_operate, :289-375): every sketch of the CSR without (keep_members = 0) or
+ *                        restricted to (keep_members = 1) the ids of `pan`; the order inside a sketch is kept
+ * A ctx from kssd_gpu_create_for_dist is enough.
+ */
+int kssd_gpu_set_union(kssd_gpu_ctx *ctx, const uint32_t *ids, uint64_t n, int uniq, uint32_t **out_ids, uint64_t *out_n);
+int kssd_gpu_set_filter(kssd_gpu_ctx *ctx, const uint64_t *off, const uint32_t *ids, uint32_t n_genomes,
+                        const uint32_t *pan, uint64_t n_pan, int keep_members, uint64_t **out_off, uint32_t **out_ids);
+
+/*
  * Timing hook for bench.py: every launch of the dominant kernel of a path is bracketed by HIP events on
  * the caller's stream (a ring of the last 128 launches).  which: 0 = sketch scan, 1 = distance rows.
  * Waits for the recorded events, returns their average in milliseconds and how many launches that covers;

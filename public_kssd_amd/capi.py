@@ -34,7 +34,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
     "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
-    "kssd_gpu_sketch_batch_pos",
+    "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter",
 ]
 
 
@@ -105,6 +105,8 @@ def gpu_lib():
         L.kssd_gpu_sketch_batch_pos.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                 C.POINTER(C.c_int64)]
         L.kssd_gpu_sketch_set_pos_output.argtypes = [vp, vp]
+        L.kssd_gpu_set_union.argtypes = [vp, vp, u64, C.c_int, C.POINTER(vp), C.POINTER(u64)]
+        L.kssd_gpu_set_filter.argtypes = [vp, vp, vp, u32, vp, u64, C.c_int, C.POINTER(vp), C.POINTER(vp)]
         L.kssd_gpu_free.argtypes = [vp]
         L.kssd_gpu_free.restype = None
         L.kssd_gpu_index_build_device.argtypes = [vp, vp, vp, u32, u64, vp]
@@ -489,6 +491,36 @@ class GpuCtx:
                     stream=None):
         _gck(gpu_lib().kssd_gpu_dist_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_shared),
                                             _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
+
+    def set_union(self, ids, uniq=False):
+        """ascending distinct ids (uniq: the ids that occur exactly once) -- kssd set -u / -q"""
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        po, n = C.c_void_p(), C.c_uint64(0)
+        _gck(gpu_lib().kssd_gpu_set_union(self.h, a.ctypes.data, len(a), int(uniq), C.byref(po), C.byref(n)))
+        try:
+            return (np.frombuffer((C.c_char * (4 * n.value)).from_address(po.value), dtype=np.uint32).copy()
+                    if n.value else np.zeros(0, np.uint32))
+        finally:
+            gpu_lib().kssd_gpu_free(po)
+
+    def set_filter(self, off, ids, pan, keep_members):
+        """every sketch of the CSR without / restricted to the ids of pan, order kept -- kssd set -s / -i"""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        pan = np.ascontiguousarray(pan, dtype=np.uint32)
+        n = len(off) - 1
+        po, pi = C.c_void_p(), C.c_void_p()
+        _gck(gpu_lib().kssd_gpu_set_filter(self.h, off.ctypes.data, ids.ctypes.data, n, pan.ctypes.data, len(pan),
+                                           int(bool(keep_members)), C.byref(po), C.byref(pi)))
+        try:
+            ooff = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(po.value), dtype=np.uint64).copy()
+            tot = int(ooff[-1])
+            oids = (np.frombuffer((C.c_char * (4 * tot)).from_address(pi.value), dtype=np.uint32).copy()
+                    if tot else np.zeros(0, np.uint32))
+        finally:
+            gpu_lib().kssd_gpu_free(po)
+            gpu_lib().kssd_gpu_free(pi)
+        return ooff, oids
 
     def scan_stats(self, stream=None):
         """(positions that passed the stage-1 filter, positions that also passed the Bloom test) of the last scan"""

@@ -1235,3 +1235,8 @@ extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float
 // distance path (index build + row kernel) lives in kssd_dist.inc
 // ---------------------------------------------------------------------------------------------------
 #include "kssd_dist.inc"
+
+// ---------------------------------------------------------------------------------------------------
+// set operations on sketches (kssd set) live in kssd_set.inc
+// ---------------------------------------------------------------------------------------------------
+#include "kssd_set.inc"

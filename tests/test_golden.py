@@ -122,3 +122,24 @@ def test_hip_shared_counts_equal_reference(gpu_ctx):
         f = ln.split("\t")
         q, r = divmod(i, shared.shape[1])
         assert abs(float(f[3]) - J[q, r]) <= 5.1e-7 and abs(float(f[4]) - MD[q, r]) <= 5.1e-7
+
+
+def test_set_operation_goldens_pin_the_numpy_restatement():
+    """tests/test_gpu_set.py checks the device against numpy's unique / isin; here that restatement is pinned against what
+    the reference binary's `kssd set` wrote for the golden sketches (tests/golden/make_golden_set.py)."""
+    import numpy as np
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sk = np.load(os.path.join(g, "sketches.npz"))
+    gold = np.load(os.path.join(g, "set_ops.npz"))
+    ref_ids = np.concatenate([sk[k] for k in sk.files if k.startswith("ref/")])
+    v, n = np.unique(ref_ids, return_counts=True)
+    assert np.array_equal(v, gold["union"])
+    assert np.array_equal(v[n == 1], gold["uniq"])
+    for tag, pan, keep in (("sub", gold["union"], False), ("int", gold["union"], True), ("intq", gold["uniq"], True)):
+        for j, nm in enumerate(gold[tag + "_names"]):
+            got = gold[tag + "_ids"][int(gold[tag + "_index"][j]):int(gold[tag + "_index"][j + 1])]
+            mine = sk["qry/" + str(nm)]
+            want = mine[np.isin(mine, pan) == keep]
+            assert np.array_equal(np.sort(got), want), (tag, nm)  # the reference keeps its file (hash-slot) order
+            assert gold[tag + "_sizes"][j] == len(want)
