@@ -680,13 +680,42 @@ static int cmd_set(int argc, char **argv)
     return 0;
 }
 
+/* kssd reverse -L <.shuf> -o <outdir> <sketch dir> (command_reverse.c): the k-mers behind the sketches, host only */
+static int cmd_reverse(int argc, char **argv)
+{
+    char shuf_path[4096] = "", outdir[4096] = ".";
+    static struct option lo[] = {{"shufFile", 1, 0, 'L'}, {"outdir", 1, 0, 'o'}, {"threads", 1, 0, 'p'}, {"byreads", 0, 0, 'b'}, {0, 0, 0, 0}};
+    int c;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "L:o:p:b", lo, NULL)) != -1) {
+        switch (c) {
+        case 'L': snprintf(shuf_path, sizeof shuf_path, "%s", optarg); break;
+        case 'o': snprintf(outdir, sizeof outdir, "%s", optarg); break;
+        case 'p': break;
+        case 'b': die(ENOTSUP, "reverse --byreads belongs to the --byread sketches, which are outside this build (SURVEY.md section 8f)");
+        default: die(EINVAL, "reverse: unknown option");
+        }
+    }
+    if (argc - optind < 1) die(EINVAL, "need speficy the query path");
+    if (!(kssd_probe_dir(argv[optind]) & 1)) die(EINVAL, "%s is not a valid query folder", argv[optind]);
+    kssd_shuf sh;
+    int rc = kssd_shuf_read(&sh, shuf_path);
+    if (rc) die(EIO, "read_dim_shuffle_file(): %s: %s", shuf_path, kssd_host_strerror(rc));
+    mkdir(outdir, 0777);
+    rc = kssd_reverse_dir(&sh, argv[optind], outdir);
+    if (rc) die(EIO, "co_reverse2kmer(): %s", kssd_host_strerror(rc));
+    kssd_shuf_release(&sh);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     setvbuf(stdout, NULL, _IOLBF, 0);
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
         printf("%s\n\nUsage: kssd <subcommand> [OPTION...] [arguments ...]\nSupported subcommands are:\n\n"
                "  shuffle\tshuffle/sampling k-mer substring space.\n\n  dist   \tsequences sketching and distance estimation.\n\n"
-               "  set    \tset operations on sketches: union, uniq union, subtract, intersect.\n",
+               "  set    \tset operations on sketches: union, uniq union, subtract, intersect.\n\n"
+               "  reverse\trecover the k-mers behind sketches.\n",
                VERSION);
         return argc < 2;
     }
@@ -694,6 +723,7 @@ int main(int argc, char **argv)
     if (!strcmp(argv[1], "shuffle")) return cmd_shuffle(argc - 1, argv + 1);
     if (!strcmp(argv[1], "dist")) return cmd_dist(argc - 1, argv + 1);
     if (!strcmp(argv[1], "set")) return cmd_set(argc - 1, argv + 1);
-    die(EINVAL, "%s is not a valid subcommand (this build implements: shuffle, dist, set)", argv[1]);
+    if (!strcmp(argv[1], "reverse")) return cmd_reverse(argc - 1, argv + 1);
+    die(EINVAL, "%s is not a valid subcommand (this build implements: shuffle, dist, set, reverse)", argv[1]);
     return 1;
 }

@@ -521,3 +521,54 @@ int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_ske
     free(sb);
     return fclose(f) == 0 ? KSSD_HOST_OK : KSSD_HOST_ERR_IO;
 }
+
+/* ---- kssd reverse ------------------------------------------------------------------------------------- */
+uint64_t kssd_reverse_id(uint32_t full_id, int k, int subk, int drlevel, const uint32_t *accepted)
+{
+    const int inner_ctx_bits = subk * 4, half_outer_ctx_bits = (k - subk) * 2, pf_bits = (subk - drlevel) * 4;
+    const uint64_t drtuple = full_id;
+    const uint64_t ind = accepted[drtuple % 4096u]; /* MIN_SUBCTX_DIM_SMP_SZ, command_reverse.c:313 */
+    const uint64_t tuple = ((drtuple >> pf_bits) << inner_ctx_bits) + ind;
+    const uint64_t half_outer_ctx_mask = ((1ull << half_outer_ctx_bits) - 1ull) << inner_ctx_bits;
+    return (tuple & (half_outer_ctx_mask << half_outer_ctx_bits)) + ((tuple & half_outer_ctx_mask) >> inner_ctx_bits) +
+           ((tuple & ((1ull << inner_ctx_bits) - 1ull)) << half_outer_ctx_bits);
+}
+
+int kssd_shuf_accepted(const kssd_shuf *s, uint32_t *accepted)
+{
+    const uint64_t n = 1ull << (4 * s->subk);
+    uint32_t count = 0;
+    for (uint64_t i = 0; i < n; i++)
+        if (s->table[i] >= 0 && s->table[i] < 4096) { accepted[s->table[i]] = (uint32_t)i; count++; }
+    return count == 4096 ? KSSD_HOST_OK : KSSD_HOST_ERR_FORMAT; /* "count %d not match MIN_SUBCTX_DIM_SMP_SZ", :232 */
+}
+
+int kssd_reverse_dir(const kssd_shuf *sh, const char *sketch_dir, const char *outdir)
+{
+    uint32_t accepted[4096];
+    int rc = kssd_shuf_accepted(sh, accepted);
+    if (rc) return rc;
+    kssd_sketchset s;
+    memset(&s, 0, sizeof s);
+    rc = kssd_sketchset_read(&s, sketch_dir); /* ids come back component after component, file order inside each */
+    if (rc) return rc;
+    const int TL = 2 * sh->k;
+    char path[4096], kstring[64];
+    kstring[TL] = '\0';
+    for (uint32_t g = 0; g < s.n && rc == KSSD_HOST_OK; g++) {
+        if (s.off[g + 1] == s.off[g]) continue; /* the reference writes nothing for an empty sketch (:290) */
+        const char *nm = strrchr(s.names[g], '/');
+        nm = nm ? nm + 1 : s.names[g];
+        snprintf(path, sizeof path, "%s/%s", outdir, nm);
+        FILE *f = fopen(path, "w");
+        if (!f) { rc = KSSD_HOST_ERR_IO; break; }
+        for (uint64_t i = s.off[g]; i < s.off[g + 1]; i++) {
+            uint64_t u = kssd_reverse_id(s.ids[i], sh->k, sh->subk, sh->drlevel, accepted);
+            for (int b = 0; b < TL; b++) { kstring[TL - b - 1] = "ACGT"[u & 3u]; u >>= 2; }
+            fprintf(f, "%s\n", kstring);
+        }
+        if (fclose(f) != 0) rc = KSSD_HOST_ERR_IO;
+    }
+    kssd_sketchset_release(&s);
+    return rc;
+}

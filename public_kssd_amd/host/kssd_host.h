@@ -109,6 +109,17 @@ int kssd_index_read(kssd_sketchset *s, const char *dir);
 /* 1 if dir holds cofiles.stat, 2 if mcofiles.stat, 3 both, 0 none (dist_dispatch probing, command_dist.c:62-63) */
 int kssd_probe_dir(const char *dir);
 
+/* kssd reverse (command_reverse.c:219-321): the canonical 2k-mer behind a sketch id.  accepted[r] = the sub-context
+ * whose permutation rank is r (r < 4096, the inverse of the .shuf table on its first 4096 ranks, :223-231);
+ * full_id = the reduced tuple with the component folded back in.  Returns the 2k-mer, 2 bits per base, first base in
+ * the highest of the 4k bits (core_reverse2unituple, :311-321). */
+uint64_t kssd_reverse_id(uint32_t full_id, int k, int subk, int drlevel, const uint32_t *accepted);
+/* the 4096 sub-contexts with rank < 4096 out of a full .shuf table; 0 on success */
+int kssd_shuf_accepted(const kssd_shuf *s, uint32_t *accepted /*4096*/);
+/* write one text file per genome of a sketch directory (named like the genome's file) with one 2k-mer per line, in the
+ * order of the ids in combco.<c>, component after component -- co_reverse2kmer (command_reverse.c:219-310) */
+int kssd_reverse_dir(const kssd_shuf *s, const char *sketch_dir, const char *outdir);
+
 /* ---- distance report (dist_print_nobin + output_ctrl, command_dist.c:1161-1287) ------------------------- */
 typedef struct kssd_print_opt {
     int metric;        /* -M 0 Jaccard / 1 containment */

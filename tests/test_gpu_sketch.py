@@ -282,3 +282,36 @@ def test_first_positions_through_the_big_genome_path(shuf_l3k10, force_big_path)
         assert np.array_equal(K.slot_order_pos(ids, pos, sk.p.hashsize), sk.fasta(t))
     finally:
         ctx.close()
+
+
+def test_round_trip_sketch_then_reverse(gpu_ctx, shuf_l3k10):
+    """encode -> decode at full size: every id of a 5 Mb genome's sketch, turned back into its canonical 20-mer
+    (kssd_reverse_id = core_reverse2unituple, command_reverse.c:311-321), occurs in the genome on one strand, sits at the
+    first position the device reported, and its sub-context has the rank the id carries."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    codes = rng.integers(0, 4, 5_000_000, dtype=np.uint8)
+    b = K.Batch()
+    b.add_fasta(fasta_text(codes))
+    off, ids, pos = gpu_ctx.sketch_batch_pos(b)
+    assert 1100 < len(ids) < 1350
+    acc = np.zeros(4096, np.uint32)
+    tab = shuf_l3k10.table
+    sel = np.nonzero(tab < 4096)[0]
+    acc[tab[sel]] = sel
+    L = K.host_lib()
+    L.kssd_reverse_id.restype = C.c_uint64
+    L.kssd_reverse_id.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    # all 20-mers of the genome as integers, forward strand, first base in the top bits
+    fw = np.zeros(len(codes) - 19, np.uint64)
+    for i in range(20):
+        fw = (fw << np.uint64(2)) | codes[i:len(codes) - 19 + i].astype(np.uint64)
+    rc = np.zeros_like(fw)
+    for i in range(20):
+        rc |= (np.uint64(3) - ((fw >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (19 - i))
+    canon = np.minimum(fw, rc)
+    for i, p in zip(ids.tolist(), pos.tolist()):
+        u = L.kssd_reverse_id(i, 10, 6, 3, acc.ctypes.data)
+        start = p - 4                       # the device reports the sub-context start; the k-mer starts `out` = 4 bases before
+        assert canon[start] == u, (i, p)
+        assert tab[(u >> 8) & 0xFFFFFF] == (i & 0xFFF)

@@ -116,3 +116,21 @@ def test_combine_queries_equals_the_reference(work, tmp_path):
     assert a == b
     s = K.SketchSet.read(str(tmp_path / "comb_ours"))
     assert len(s.names) == 2 * 6 + 3
+
+
+def test_reverse_equals_the_reference(work, tmp_path, shuf_l3k10):
+    """`kssd reverse -L shuf -o out dir`: one text file of 2k-mers per genome (command_reverse.c:219-321); host-only."""
+    import subprocess
+    sp = str(work / "L3K10.shuf")
+    (tmp_path / "r").mkdir()
+    (tmp_path / "o").mkdir()
+    ko.run_ref(["reverse", "-L", sp, "-o", str(tmp_path / "r"), str(work / "qry")], cwd=str(tmp_path))
+    ours = subprocess.run([os.path.join(os.path.dirname(G), "..", "public_kssd_amd", "kssd"), "reverse", "-L", sp, "-o", str(tmp_path / "o"),
+                           str(work / "qry")], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert ours.returncode == 0, ours.stdout.decode()
+    names = sorted(os.listdir(str(tmp_path / "r")))
+    assert names == sorted(os.listdir(str(tmp_path / "o"))) and len(names) == 3
+    for nm in names:
+        assert filecmp.cmp(str(tmp_path / "r" / nm), str(tmp_path / "o" / nm), shallow=False), nm
+        kmers = open(str(tmp_path / "o" / nm)).read().split()
+        assert all(len(x) == 20 and set(x) <= set("ACGT") for x in kmers)
