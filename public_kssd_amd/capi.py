@@ -8,6 +8,7 @@ built, or no gfx950 device is usable, the calls raise.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -405,9 +406,11 @@ class GpuCtx:
             self.h = None
 
     def __del__(self):
-        import sys
-        if not sys.is_finalizing():  # never call into HIP while the interpreter (and the runtime) shut down
-            self.close()
+        try:
+            if not sys.is_finalizing():  # never call into HIP while the interpreter (and the runtime) shut down
+                self.close()
+        except Exception:
+            pass
 
     # host-level ---------------------------------------------------------------------------------------
     def sketch_batch(self, batch, flags=SKETCH_FASTA, min_occ=1):
