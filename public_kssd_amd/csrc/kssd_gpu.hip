@@ -403,27 +403,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // (chunk offset << 12 | position, pattern)
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
-    for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
-        *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
-    __syncthreads();
-
     // static partition: every wave of the grid owns one contiguous run of chunks
     const unsigned long long total_waves = (unsigned long long)gridDim.x * SCAN_WAVES;
     const unsigned long long wid = (unsigned long long)blockIdx.x * SCAN_WAVES + wave;
     const unsigned long long per = (a.n_chunks + total_waves - 1) / total_waves;
     unsigned long long c0 = wid * per, c1 = c0 + per;
     if (c1 > a.n_chunks) c1 = a.n_chunks;
-    if (c0 >= c1) return;
     const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
     uint32_t n_stage1 = 0, n_bloom = 0;  // telemetry (wave-uniform)
 
-    // prologue: chunk c0 through both alignments, chunks c0+1 and c0+2 requested
+    // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
+    // first reads overlaps the 144 KiB copy instead of following it
     ChunkRegs r0, r1, r2, r3;
     uint32_t raw[Gp::NMAX];
     uint32_t alo, ahi;
-    load_chunk(a, c0, lane, r0);
+    load_chunk(a, c0 < clast ? c0 : clast, lane, r0);
     load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, r1);
     load_chunk(a, c0 + 2 < clast ? c0 + 2 : clast, lane, r2);
+
+    for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
+        *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
+    __syncthreads();
+    if (c0 >= c1) return;
+
+    // prologue: chunk c0 through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
     kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
     kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of chunk c0 in flight
