@@ -98,6 +98,7 @@ struct kssd_gpu_ctx {
     unsigned long long *d_lane_valid;  // per chunk, written by the scan (+1 zero word at the end)
     size_t cap_lane_valid;
     uint64_t last_cand_cap;
+    uint64_t cand_floor;    // per-slice capacity an overflowed attempt asked for (kept for the retries)
     double cand_factor;
     SketchStatus *d_status;
     double region_factor;
@@ -996,7 +997,9 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         uint64_t cap = (uint64_t)((double)pos * rate * c->region_factor) + 256;
         if (cap > pos) cap = pos;  // a genome cannot emit more tuples than it has positions
         if (cap > big_min) {
-            if ((uint64_t)((double)pos * rate * 1.25) + 64 <= big_min) cap = big_min;  // still fits the LDS sort
+            // a genome expected to fit the LDS sort keeps that path -- unless an earlier attempt has shown that this
+            // batch emits far more than the sampling rate predicts (low-complexity sequence): then the factor decides
+            if (c->region_factor <= 2.0 && (uint64_t)((double)pos * rate * 1.25) + 64 <= big_min) cap = big_min;
             else {
                 if (cap >= (1ull << 31)) { c->last_launch_rc = KSSD_ERR_UNSUPPORTED; return KSSD_ERR_UNSUPPORTED; }
                 c->h_big.push_back(g);  // global-memory sort path
@@ -1020,7 +1023,8 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     const uint64_t want_blocks = (n_chunks + SCAN_WAVES - 1) / SCAN_WAVES;
     const int grid = (int)(want_blocks < (uint64_t)c->cu_count ? want_blocks : (uint64_t)c->cu_count);
     const uint32_t n_slices = (uint32_t)(grid > 0 ? grid : 1) * SCAN_WAVES;
-    const uint64_t cand_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * (2.0 * rate + 0.0005) * c->cand_factor / n_slices) + 256;
+    uint64_t cand_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * (2.0 * rate + 0.0005) * c->cand_factor / n_slices) + 256;
+    if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
     if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
@@ -1101,9 +1105,14 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
     HIPCK(hipMemcpyAsync(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     if (total_ids) *total_ids = st.total_ids;
+    if (getenv("KSSD_DEV_TRACE"))
+        fprintf(stderr, "[kssd_gpu] status: ids %llu, stage1 %llu, bloom %llu, cand_overflow %u (need %u of %llu), region_overflow %u "
+                        "(need x%.2f, factor %.2f), out_overflow %u, capacity %u\n",
+                (unsigned long long)st.total_ids, (unsigned long long)st.n_stage1, (unsigned long long)st.n_bloom, st.cand_overflow,
+                st.cand_need, (unsigned long long)c->last_cand_cap, st.region_overflow, st.max_need_q8 / 256.0, c->region_factor,
+                st.out_overflow, st.capacity_genome_p1);
     if (st.cand_overflow) {
-        const double need = (double)st.cand_need / (double)(c->last_cand_cap ? c->last_cand_cap : 1);
-        c->cand_factor *= (need > 1.0 ? need : 1.0) * 1.5;
+        c->cand_floor = (uint64_t)st.cand_need + st.cand_need / 4 + 64;
         return KSSD_ERR_OVERFLOW;
     }
     if (st.region_overflow) {

@@ -315,3 +315,32 @@ def test_round_trip_sketch_then_reverse(gpu_ctx, shuf_l3k10):
         start = p - 4                       # the device reports the sub-context start; the k-mer starts `out` = 4 bases before
         assert canon[start] == u, (i, p)
         assert tab[(u >> 8) & 0xFFFFFF] == (i & 0xFFF)
+
+
+def test_low_complexity_megabases_overflow_and_retry(shuf_l3k10):
+    """12 Mb of a period-4 repeat whose 12-mer IS an accepted pattern: EVERY position passes all filters -- candidate
+    list and staging regions overflow their estimates by three orders of magnitude, the call reports it, the host-level
+    entry point retries with larger buffers (and the global-memory dedup), and the result is still the reference's"""
+    tab = shuf_l3k10.table.copy()
+    code = 0
+    for ch in b"ACGT" * 3:
+        code = (code << 2) | b"ACGT".index(ch)
+    y = int(np.nonzero(tab == 5)[0][0])          # give the repeat's sub-context rank 5: still a permutation
+    tab[y], tab[code] = tab[code], 5
+    shuf = K.Shuf((shuf_l3k10.id, 10, 6, 3), tab)
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        sk = ko.Sketcher(shuf.table, 10, 6, 3)
+        texts = [b">str\n" + b"ACGT" * 3_000_000 + b"\n", b">polyA\n" + b"A" * 2_000_000 + b"\n",
+                 b">dinuc\n" + b"AC" * 1_500_000 + b"\n"]
+        b = K.Batch()
+        for t in texts:
+            b.add_fasta(t)
+        off, ids = ctx.sketch_batch(b)
+        s1, bl = ctx.scan_stats()
+        assert bl > 2_500_000                     # the flood really happened: every 4th position of the 12 Mb repeat
+        for g, t in enumerate(texts):
+            assert np.array_equal(ids[int(off[g]):int(off[g + 1])], np.sort(sk.fasta(t))), g
+        assert len(ids[int(off[0]):int(off[1])]) >= 1
+    finally:
+        ctx.close()
