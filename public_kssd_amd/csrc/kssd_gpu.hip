@@ -55,6 +55,7 @@ extern "C" const char *kssd_gpu_strerror(int code)
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define CBUF 128          // per-wave buffer of stage-1 candidates waiting for the Bloom test (8 B each)
+#define SKETCH_TRACK_FILL 0x80000000u  // internal flag: record the fullest staging region even without an overflow
 #define DEDUP_THREADS 512
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
@@ -673,6 +674,8 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
         }
         return;
     }
+    if ((flags & SKETCH_TRACK_FILL) && tid == 0)  // only while the regions are oversized after an overflow (see sketch_status)
+        atomicMax(&st->max_need_q8, (uint32_t)(((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1)));
     uint32_t np = 1;
     while (np < n) np <<= 1;
     for (uint32_t i = tid; i < np; i += DEDUP_THREADS) a[i] = i < n ? regions[r0 + i] : KeyOps<K>::pad();
@@ -757,6 +760,8 @@ __global__ void big_pad_kernel(K *__restrict__ region, unsigned long long cap, c
             unsigned long long need = (n * 256ull + cap - 1) / (cap ? cap : 1);
             atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
             *kept_g = 0;
+        } else {
+            atomicMax(&st->max_need_q8, (uint32_t)((n * 256ull + cap - 1) / (cap ? cap : 1)));
         }
     }
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * blockDim.x)
@@ -1077,6 +1082,7 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         if (with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
         else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
     }
+    if (c->region_factor > 2.0) flags |= SKETCH_TRACK_FILL;
     rc = with_pos ? finish_sketch<unsigned long long>(c, n_genomes, flags, min_occ, big_min, max_cap, max_big, d_out_off, d_out_ids,
                                                       c->d_out_pos, out_cap, s)
                   : finish_sketch<uint32_t>(c, n_genomes, flags, min_occ, big_min, max_cap, max_big, d_out_off, d_out_ids, nullptr,
@@ -1121,6 +1127,12 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
         return KSSD_ERR_OVERFLOW;
     }
     if (st.out_overflow) return KSSD_ERR_OVERFLOW;
+    if (c->region_factor > 2.0 && st.max_need_q8 < 64) {
+        // the regions were grown for a batch that emitted far more than the sampling rate predicts; this batch filled
+        // its fullest region to less than a quarter: shrink towards the default again
+        const double f = c->region_factor * ((double)st.max_need_q8 / 256.0) * 2.0;
+        c->region_factor = f > 2.0 ? f : 2.0;
+    }
     if (st.capacity_genome_p1) {
         if (bad_genome) *bad_genome = (int64_t)(0xFFFFFFFFu - st.capacity_genome_p1);
         return KSSD_ERR_CAPACITY;

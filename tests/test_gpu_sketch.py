@@ -342,5 +342,15 @@ def test_low_complexity_megabases_overflow_and_retry(shuf_l3k10):
         for g, t in enumerate(texts):
             assert np.array_equal(ids[int(off[g]):int(off[g + 1])], np.sort(sk.fasta(t))), g
         assert len(ids[int(off[0]):int(off[1])]) >= 1
+        # the same context afterwards on ordinary sequence (its oversized buffers shrink back; results unaffected)
+        rng = np.random.default_rng(3)
+        t2 = [fasta_text(rng.integers(0, 4, 400_000, dtype=np.uint8)) for _ in range(5)]
+        for _ in range(2):
+            b2 = K.Batch()
+            for t in t2:
+                b2.add_fasta(t)
+            off2, ids2 = ctx.sketch_batch(b2)
+            for g, t in enumerate(t2):
+                assert np.array_equal(ids2[int(off2[g]):int(off2[g + 1])], np.sort(sk.fasta(t))), g
     finally:
         ctx.close()
