@@ -50,6 +50,9 @@ extern "C" {
 #define KSSD_SKETCH_NO_CAPACITY 4u  /* do not raise KSSD_ERR_CAPACITY (fastq2co never does, :338)      */
 #define KSSD_SKETCH_FIRST_POS 8u    /* also report every id's first position inside its genome: what the */
                                     /*   reference's hash-slot file order depends on (iseq2comem.c:254-268) */
+#define KSSD_SKETCH_COUNTS 16u      /* report every id's number of occurrences, saturating at 65535, in the   */
+                                    /*   second output array instead of positions: the abundance sketches of   */
+                                    /*   -A (mt_shortreads2koc / write_fqkoc2files, iseq2comem.c:435-471,552-615) */
 
 typedef struct kssd_gpu_ctx kssd_gpu_ctx;
 
@@ -128,7 +131,8 @@ int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint3
                           const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
                           uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                           int64_t *bad_genome);
-/* same, plus the first position of every id (KSSD_SKETCH_FIRST_POS is added to flags) */
+/* same, plus the first position of every id (KSSD_SKETCH_FIRST_POS is added to flags) or, with KSSD_SKETCH_COUNTS
+ * in flags, its number of occurrences */
 int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
                               const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
                               uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos,

@@ -335,6 +335,77 @@ long ko_fastq2co(ko_ctx *c, const unsigned char *text, size_t n, int Q, int M, u
 }
 
 /* whole (possibly gzip'ed) file into memory; the reference streams `zcat -fc file` (iseq2comem.c:187) */
+/* ---- FASTQ, abundance sketches (dist -A) -------------------------------------------------- */
+#define KO_KOC_LEN 4096    /* FQ_LEN, iseq2comem.c:553 */
+#define KO_OCCRC_BIT 16    /* iseq2comem.c:357 */
+#define KO_OCCRC_MAX 0xffffULL
+
+/* mt_shortreads2koc with one thread + write_fqkoc2files (iseq2comem.c:554-615, 435-471): every sampled k-mer of the
+ * second line of every four-line record counted in a 16-bit saturating counter beside its key; no quality rule, no -n;
+ * crowding is fatal.  Dump in hash-slot order: ids, component, occurrences. */
+long ko_fastq2koc(ko_ctx *c, const unsigned char *text, size_t n, u32 *ids, uint8_t *comps, uint16_t *counts, size_t cap)
+{
+    const ko_params *p = &c->p;
+    memset(c->co, 0, (size_t)p->hashsize * sizeof(u64));
+    char *seq = calloc(1, KO_KOC_LEN + 10), *tmp = calloc(1, KO_KOC_LEN + 10);
+    mstream ms = {text, n, 0, 0};
+    const u64 S = p->hashsize;
+    u32 keycount = 0;
+    long rc = 0;
+    while (!rc && m_fgets(tmp, KO_KOC_LEN, &ms) && m_fgets(seq, KO_KOC_LEN, &ms) && m_fgets(tmp, KO_KOC_LEN, &ms) &&
+           m_fgets(tmp, KO_KOC_LEN, &ms)) { /* :567 */
+        u64 fwd = 0, rev = 0, run = 1;
+        for (int pos = 0; seq[pos] && seq[pos] != '\n' && !rc; pos++) { /* :574 */
+            int b = base_code((unsigned char)seq[pos]);
+            if (b < 0) { /* :580 */
+                run = 1;
+                continue;
+            }
+            fwd = ((fwd << 2) | (u64)b) & p->tupmask;
+            rev = (rev >> 2) + (((u64)b ^ 3ULL) << p->rc_shift);
+            run++;
+            if (run <= (u64)p->TL)
+                continue;
+            u64 dr;
+            if (!reduce_kmer(c, fwd, rev, &dr))
+                continue;
+            for (u64 t = 0; t < S; t++) { /* :591-607 */
+                u32 s = probe_slot(dr, t, S);
+                u64 v = c->co[s];
+                if (v == 0) {
+                    c->co[s] = (dr << KO_OCCRC_BIT) + 1ULL;
+                    if (++keycount > p->hashlimit)
+                        rc = KO_ERR_CAPACITY;
+                    break;
+                }
+                if ((v >> KO_OCCRC_BIT) == dr) {
+                    if ((v & KO_OCCRC_MAX) < KO_OCCRC_MAX)
+                        c->co[s] = v + 1ULL;
+                    break;
+                }
+            }
+        }
+    }
+    free(seq);
+    free(tmp);
+    if (rc)
+        return rc;
+    size_t w = 0;
+    for (u32 s = 0; s < p->hashsize; s++) { /* :452-463 */
+        u64 v = c->co[s];
+        if (v > 0) {
+            if (w >= cap)
+                return KO_ERR_BUFSZ;
+            ids[w] = (u32)(v >> (p->comp_bits + KO_OCCRC_BIT));
+            if (comps)
+                comps[w] = (uint8_t)((v >> KO_OCCRC_BIT) % (u64)p->comp_num);
+            counts[w] = (uint16_t)(v & KO_OCCRC_MAX);
+            w++;
+        }
+    }
+    return (long)w;
+}
+
 static unsigned char *slurp_gz(const char *path, size_t *len)
 {
     gzFile g = gzopen(path, "rb");

@@ -68,6 +68,11 @@ long ko_fasta2co(ko_ctx *c, const unsigned char *text, size_t n, int uniq,
 long ko_fastq2co(ko_ctx *c, const unsigned char *text, size_t n, int Q, int M,
                  uint32_t *ids, uint8_t *comps, size_t cap);
 
+/* FASTQ with occurrence counts (dist -A): mt_shortreads2koc on one thread + write_fqkoc2files
+ * (iseq2comem.c:554-615,435-471); counts[i] = occurrences of ids[i], saturated at 65535 */
+long ko_fastq2koc(ko_ctx *c, const unsigned char *text, size_t n, uint32_t *ids, uint8_t *comps,
+                  uint16_t *counts, size_t cap);
+
 /* same, reading a (possibly gzip'ed) file through zlib; is_fastq selects the scanner */
 long ko_sketch_file(ko_ctx *c, const char *path, int is_fastq, int uniq, int Q, int M,
                     uint32_t *ids, uint8_t *comps, size_t cap);

@@ -55,6 +55,8 @@ def lib():
         L.ko_params_init.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int]
         L.ko_fasta2co.restype = C.c_long
         L.ko_fasta2co.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ko_fastq2koc.restype = C.c_long
+        L.ko_fastq2koc.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.ko_fastq2co.restype = C.c_long
         L.ko_fastq2co.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_size_t]
@@ -129,6 +131,16 @@ class Sketcher:
         text = bytes(text)
         n = lib().ko_fastq2co(self.h, text, len(text), Q, M, self._ids.ctypes.data, self._comps.ctypes.data, self._cap)
         return self._ret(n, with_comps)
+
+    def fastq_koc(self, text):
+        """dist -A: (ids, counts) in the reference's file order"""
+        text = bytes(text)
+        counts = np.zeros(self._cap, np.uint16)
+        n = lib().ko_fastq2koc(self.h, text, len(text), self._ids.ctypes.data, self._comps.ctypes.data,
+                               counts.ctypes.data, self._cap)
+        if n < 0:
+            raise OracleError(n)
+        return self._ids[:n].copy(), counts[:n].copy()
 
     def file(self, path, is_fastq=False, uniq=False, Q=0, M=1):
         n = lib().ko_sketch_file(self.h, os.fsencode(path), int(is_fastq), int(uniq), Q, M, self._ids.ctypes.data,

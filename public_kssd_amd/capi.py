@@ -26,6 +26,7 @@ SKETCH_KEEP_ZERO = 1
 SKETCH_UNIQ = 2
 SKETCH_NO_CAPACITY = 4
 SKETCH_FIRST_POS = 8
+SKETCH_COUNTS = 16
 
 OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -59,7 +60,7 @@ class GpuInfo(C.Structure):
 class _SketchSet(C.Structure):
     _fields_ = [("shuf_id", C.c_uint32), ("koc", C.c_int), ("kmerlen", C.c_int), ("dim_rd_len", C.c_int),
                 ("comp_num", C.c_int), ("n", C.c_uint32), ("off", C.c_void_p), ("ids", C.c_void_p),
-                ("names", C.c_void_p)]
+                ("names", C.c_void_p), ("counts", C.c_void_p)]
 
 
 class _PrintOpt(C.Structure):
@@ -140,6 +141,7 @@ def host_lib():
         L.kssd_batch_clear.restype = None
         L.kssd_batch_add_fasta.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.kssd_batch_add_fastq.argtypes = [vp, C.c_char_p, C.c_size_t, i32, C.POINTER(u64)]
+        L.kssd_batch_add_reads.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(u64)]
         L.kssd_batch_add_file.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(u64)]
         for f in ("packed", "mask", "chunk_off"):
             getattr(L, "kssd_batch_" + f).restype = vp
@@ -229,19 +231,25 @@ def derive(k, subk, drlevel):
 class SketchSet:
     """Sketches of n genomes: CSR of full reduced tuples + the header fields of cofiles.stat."""
 
-    def __init__(self, shuf_id, kmerlen, dim_rd_len, comp_num, names, off, ids):
+    def __init__(self, shuf_id, kmerlen, dim_rd_len, comp_num, names, off, ids, counts=None):
         self.shuf_id, self.kmerlen, self.dim_rd_len, self.comp_num = shuf_id, kmerlen, dim_rd_len, comp_num
         self.names = list(names)
         self.off = np.ascontiguousarray(off, dtype=np.uint64)
         self.ids = np.ascontiguousarray(ids, dtype=np.uint32).copy()
+        # abundance sketches (dist -A): occurrences of ids[i], u16; None for plain sketches
+        self.counts = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint16).copy()
         assert len(self.off) == len(self.names) + 1
+        assert self.counts is None or len(self.counts) == len(self.ids)
 
     def _c(self):
         self._nm = b"".join(os.fsencode(n).ljust(256, b"\0")[:256] for n in self.names) or b"\0"
         self._nmbuf = C.create_string_buffer(self._nm, len(self._nm))
         self._ids = self.ids if len(self.ids) else np.zeros(1, np.uint32)
-        return _SketchSet(self.shuf_id, 0, self.kmerlen, self.dim_rd_len, self.comp_num, len(self.names),
-                          self.off.ctypes.data, self._ids.ctypes.data, C.addressof(self._nmbuf))
+        koc = self.counts is not None
+        self._cnt = (self.counts if len(self.counts) else np.zeros(1, np.uint16)) if koc else None
+        return _SketchSet(self.shuf_id, int(koc), self.kmerlen, self.dim_rd_len, self.comp_num, len(self.names),
+                          self.off.ctypes.data, self._ids.ctypes.data, C.addressof(self._nmbuf),
+                          self._cnt.ctypes.data if koc else None)
 
     @classmethod
     def _from_c(cls, s):
@@ -252,7 +260,11 @@ class SketchSet:
                else np.zeros(0, np.uint32))
         raw = (C.c_char * (256 * n)).from_address(s.names).raw if n else b""
         names = [raw[256 * i:256 * (i + 1)].split(b"\0")[0].decode() for i in range(n)]
-        return cls(s.shuf_id, s.kmerlen, s.dim_rd_len, s.comp_num, names, off, ids)
+        counts = None
+        if s.koc and s.counts:
+            counts = (np.frombuffer((C.c_char * (2 * tot)).from_address(s.counts), dtype=np.uint16).copy() if tot
+                      else np.zeros(0, np.uint16))
+        return cls(s.shuf_id, s.kmerlen, s.dim_rd_len, s.comp_num, names, off, ids, counts)
 
     def write(self, d, hashsize, slot_order=True):
         """cofiles.stat + combco.<c> + combco.index.<c>"""
@@ -337,6 +349,13 @@ class Batch:
         text = bytes(text)
         n = C.c_uint64(0)
         _hck(host_lib().kssd_batch_add_fastq(self.h, text, len(text), Q, C.byref(n)))
+        return n.value
+
+    def add_reads(self, text):
+        """reads framed like dist -A frames them; returns the number of reads"""
+        text = bytes(text)
+        n = C.c_uint64(0)
+        _hck(host_lib().kssd_batch_add_reads(self.h, text, len(text), C.byref(n)))
         return n.value
 
     def add_file(self, path, is_fastq=False, Q=0):

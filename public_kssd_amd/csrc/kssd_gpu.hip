@@ -713,6 +713,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
                     else hi = mid;
                 }
                 const uint32_t len = lo - i;
+                if (flags & KSSD_SKETCH_COUNTS) kv = KeyOps<K>::make(v, len < 65535u ? len : 65535u);  // OCCRC_MAX, global_basic.h
                 keep = len >= min_occ;
                 if ((flags & KSSD_SKETCH_UNIQ) && len > 1) keep = false;
                 if (v == 0 && !(flags & KSSD_SKETCH_KEEP_ZERO)) {
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const K *__restri
                     else hi = mid;
                 }
                 const unsigned long long len = lo - i;
+                if (flags & KSSD_SKETCH_COUNTS) kv = KeyOps<K>::make(v, len < 65535ull ? (uint32_t)len : 65535u);
                 keep = len >= min_occ;
                 if ((flags & KSSD_SKETCH_UNIQ) && len > 1) keep = false;
                 if (v == 0 && !(flags & KSSD_SKETCH_KEEP_ZERO)) {
@@ -979,7 +981,8 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     c->last_launch_rc = KSSD_OK;
     c->last_n_genomes = n_genomes;
     if (min_occ < 1) min_occ = 1;
-    const bool with_pos = (flags & KSSD_SKETCH_FIRST_POS) != 0;
+    const bool with_pos = (flags & (KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS)) != 0;  // 64-bit keys, second output array
+    if ((flags & KSSD_SKETCH_FIRST_POS) && (flags & KSSD_SKETCH_COUNTS)) return KSSD_ERR_PARAM;  // one or the other per call
     if (with_pos && !c->d_out_pos) return KSSD_ERR_PARAM;  // kssd_gpu_sketch_set_pos_output first
     const uint64_t n_chunks = h_chunk_off[n_genomes];
     HIPCK(hipMemsetAsync(c->d_status, 0, sizeof(SketchStatus), s));
@@ -1186,8 +1189,8 @@ static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint
         BCK(hipMemcpy(d_p, packed, (size_t)n_chunks * KSSD_CHUNK_WORDS * 4, hipMemcpyHostToDevice));
         BCK(hipMemcpy(d_m, mask, (size_t)n_chunks * KSSD_CHUNK_MASKW * 4, hipMemcpyHostToDevice));
     }
-    if (out_pos) flags |= KSSD_SKETCH_FIRST_POS;
-    else flags &= ~KSSD_SKETCH_FIRST_POS;
+    if (out_pos && !(flags & KSSD_SKETCH_COUNTS)) flags |= KSSD_SKETCH_FIRST_POS;
+    if (!out_pos) flags &= ~(KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS);
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     uint64_t out_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * rate * 1.5) + 1024;
     uint64_t total = 0;

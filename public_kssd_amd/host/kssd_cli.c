@@ -213,6 +213,7 @@ static void load_shuf(const dist_opt *o, kssd_shuf *s)
 typedef struct {
     uint64_t *off;
     uint32_t *ids;
+    uint16_t *counts; /* -A: occurrences of every id */
     uint64_t n_ids, cap_ids;
     uint32_t n;
     uint32_t hashsize;
@@ -223,6 +224,11 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     uint32_t n = kssd_batch_n_genomes(b);
     if (!n) return;
     uint32_t flags = is_fq ? (KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY) : (o->u ? KSSD_SKETCH_UNIQ : KSSD_SKETCH_FASTA);
+    uint32_t min_occ = is_fq ? (uint32_t)o->kmerocrs : 1u;
+    if (o->abundance) { /* mt_shortreads2koc (iseq2comem.c:554-615): every k-mer kept, -n not looked at, crowding is fatal */
+        flags = KSSD_SKETCH_KEEP_ZERO;
+        min_occ = 1;
+    }
     uint64_t *off = NULL;
     uint32_t *ids = NULL, *pos = NULL;
     int64_t bad = -1;
@@ -232,12 +238,23 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     for (uint32_t g = 0; g < n; g++)
         if (co[g + 1] - co[g] >= (1ull << 20)) with_pos = 0;
     int rc = with_pos ? kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
-                                                  is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &pos, &bad)
+                                                  min_occ, &off, &ids, &pos, &bad)
                       : kssd_gpu_sketch_batch(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
-                                              is_fq ? (uint32_t)o->kmerocrs : 1u, &off, &ids, &bad);
+                                              min_occ, &off, &ids, &bad);
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
+    /* -A: a second pass over the same batch returns the occurrences of every id (ids ascending inside a genome,
+     * the same set as above) */
+    uint64_t *aoff = NULL;
+    uint32_t *aids = NULL, *acnt = NULL;
+    if (o->abundance) {
+        gck(kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n,
+                                      KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &aoff, &aids,
+                                      &acnt, &bad),
+            "sketch (abundances)");
+        if (aoff[n] != off[n]) die(EIO, "sketch (abundances): %llu ids against %llu", (unsigned long long)aoff[n], (unsigned long long)off[n]);
+    }
     /* file order inside a genome = the reference's hash-slot order, insertions replayed in sequence order (or, for
      * a genome of 2^32 positions and more, in ascending id order: exact unless two of its ids probe the same slot) */
 #pragma omp parallel for schedule(dynamic, 16)
@@ -249,8 +266,25 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     if (acc->n_ids + add > acc->cap_ids) {
         acc->cap_ids = (acc->n_ids + add) * 2 + 1024;
         acc->ids = realloc(acc->ids, acc->cap_ids * 4);
+        if (o->abundance) acc->counts = realloc(acc->counts, acc->cap_ids * 2);
     }
     memcpy(acc->ids + acc->n_ids, ids, add * 4);
+    if (o->abundance) {
+        int bad_follow = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad_follow)
+        for (uint32_t g = 0; g < n; g++) {
+            const uint64_t m = off[g + 1] - off[g];
+            if (aoff[g + 1] - aoff[g] != m) { bad_follow |= 1; continue; }
+            uint16_t *c16 = malloc((m ? m : 1) * 2);
+            for (uint64_t i = 0; i < m; i++) c16[i] = (uint16_t)acnt[aoff[g] + i]; /* saturated at 65535 on the device */
+            bad_follow |= kssd_counts_follow(aids + aoff[g], c16, ids + off[g], acc->counts + acc->n_ids + off[g], m) != 0;
+            free(c16);
+        }
+        if (bad_follow) die(EIO, "sketch (abundances): the two passes disagree");
+        kssd_gpu_free(aoff);
+        kssd_gpu_free(aids);
+        kssd_gpu_free(acnt);
+    }
     for (uint32_t g = 0; g < n; g++) acc->off[acc->n + g + 1] = acc->n_ids + off[g + 1];
     acc->n += n;
     acc->n_ids += add;
@@ -263,8 +297,20 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
 static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
 {
     if (fl->n == 0) die(EINVAL, "no valid input .fas/.fq file");
-    if (o->abundance || o->byread || o->pipecmd[0])
-        die(ENOTSUP, "-A / --byread / --pipecmd are outside the GPU hot path of this build (SURVEY.md section 8f)");
+    if (o->byread || o->pipecmd[0])
+        die(ENOTSUP, "--byread / --pipecmd are outside the GPU hot path of this build (SURVEY.md section 8f)");
+    int abundance = o->abundance;
+    if (abundance) /* command_dist.c:297-301: one non-FASTQ input closes the mode (here: for the whole run, up front) */
+        for (int i = 0; i < fl->n; i++)
+            if (!has_fmt(fl->path[i], fq_fmt)) {
+                printf("Warning: close abundance mode (-A) since non-fastq file input.\n");
+                abundance = 0;
+                break;
+            }
+    dist_opt oa = *o;
+    oa.abundance = abundance;
+    o = &oa;
+    if (abundance) printf("running mt_shortreads2koc()\n");
     kssd_shuf shuf;
     load_shuf(o, &shuf);
     kssd_derived d;
@@ -293,8 +339,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             tb[i - i0] = kssd_batch_create();
             uint64_t lines = 0;
             int fq = has_fmt(fl->path[i], fq_fmt);
-            trc[i - i0] = kssd_batch_add_file(tb[i - i0], fl->path[i], fq, o->kmerqlty, &lines);
-            if (fq && trc[i - i0] == 0) printf("%llu reads detected\n", (unsigned long long)lines);
+            /* -A reads the bases only: no quality filter (iseq2comem.c:566-573) */
+            trc[i - i0] = kssd_batch_add_file(tb[i - i0], fl->path[i], fq && o->abundance ? 2 : fq, o->kmerqlty, &lines);
+            if (fq && trc[i - i0] == 0 && !o->abundance) printf("%llu reads detected\n", (unsigned long long)lines);
         }
         for (int i = i0; i < i1; i++) {
             if (trc[i - i0]) die(EIO, "%s: %s", fl->path[i], kssd_host_strerror(trc[i - i0]));
@@ -324,10 +371,13 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     s.off = acc.off;
     s.ids = acc.ids ? acc.ids : calloc(1, 4);
     s.names = fl->path;
+    s.koc = o->abundance;
+    s.counts = o->abundance ? (acc.counts ? acc.counts : calloc(1, 2)) : NULL;
     int rc = kssd_sketchset_write(&s, outdir, d.hashsize, 0); /* already in slot order */
     if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
     free(acc.off);
     free(s.ids);
+    free(s.counts);
     kssd_gpu_destroy(g_ctx);
     g_ctx = NULL;
 }

@@ -53,6 +53,7 @@ void kssd_sketchset_release(kssd_sketchset *s)
     free(s->off);
     free(s->ids);
     free(s->names);
+    free(s->counts);
     memset(s, 0, sizeof *s);
 }
 
@@ -129,6 +130,44 @@ void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, u
     for (uint64_t i = 0; i < n; i++) ids[i] = pi[i].id;
     free(pi);
     slot_order_replay(ids, n, hashsize); /* insertions in sequence order, as fasta2co makes them */
+}
+
+typedef struct {
+    uint32_t id;
+    uint16_t cnt;
+} id_cnt;
+
+static int cmp_id_cnt(const void *a, const void *b)
+{
+    uint32_t x = ((const id_cnt *)a)->id, y = ((const id_cnt *)b)->id;
+    return x < y ? -1 : x > y;
+}
+
+int kssd_counts_follow(const uint32_t *ids_before, const uint16_t *counts_before, const uint32_t *ids_after,
+                       uint16_t *counts_after, uint64_t n)
+{
+    if (!n) return KSSD_HOST_OK;
+    id_cnt *t = malloc(n * sizeof(id_cnt));
+    if (!t) return KSSD_HOST_ERR_NOMEM;
+    int sorted = 1;
+    for (uint64_t i = 0; i < n; i++) {
+        t[i].id = ids_before[i];
+        t[i].cnt = counts_before[i];
+        if (i && ids_before[i] < ids_before[i - 1]) sorted = 0;
+    }
+    if (!sorted) qsort(t, n, sizeof(id_cnt), cmp_id_cnt);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (t[mid].id < ids_after[i]) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo >= n || t[lo].id != ids_after[i]) { free(t); return KSSD_HOST_ERR_PARAM; }
+        counts_after[i] = t[lo].cnt;
+    }
+    free(t);
+    return KSSD_HOST_OK;
 }
 
 /* ---- stat files ---------------------------------------------------------------------------------------- */
@@ -215,7 +254,22 @@ int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hash
 {
     mkdir(dir, 0777);
     if (slot_order)
-        for (uint32_t g = 0; g < s->n; g++) kssd_slot_order(s->ids + s->off[g], s->off[g + 1] - s->off[g], hashsize);
+        for (uint32_t g = 0; g < s->n; g++) {
+            const uint64_t n = s->off[g + 1] - s->off[g];
+            uint32_t *before = NULL;
+            uint16_t *cb4 = NULL;
+            if (s->koc && s->counts && n) { /* the abundances travel with their ids */
+                before = malloc(n * 4);
+                cb4 = malloc(n * 2);
+                if (!before || !cb4) { free(before); free(cb4); return KSSD_HOST_ERR_NOMEM; }
+                memcpy(before, s->ids + s->off[g], n * 4);
+                memcpy(cb4, s->counts + s->off[g], n * 2);
+            }
+            kssd_slot_order(s->ids + s->off[g], n, hashsize);
+            if (before) kssd_counts_follow(before, cb4, s->ids + s->off[g], s->counts + s->off[g], n);
+            free(before);
+            free(cb4);
+        }
     const int cb = comp_bits_of(s->comp_num);
     const uint32_t cmask = (uint32_t)s->comp_num - 1u;
     char path[4096];
@@ -225,23 +279,31 @@ int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hash
         snprintf(path, sizeof path, "%s/combco.%d", dir, c);
         FILE *f = fopen(path, "wb");
         if (!f) { free(idx); return KSSD_HOST_ERR_IO; }
+        FILE *fa = NULL; /* abundances beside the ids, same order (command_dist.c:323-351) */
+        if (s->koc && s->counts) {
+            snprintf(path, sizeof path, "%s/combco.%d.a", dir, c);
+            if (!(fa = fopen(path, "wb"))) { fclose(f); free(idx); return KSSD_HOST_ERR_IO; }
+        }
         uint64_t run = 0;
         idx[0] = 0;
         for (uint32_t g = 0; g < s->n; g++) {
             if (s->comp_num == 1) {
                 uint64_t cnt = s->off[g + 1] - s->off[g];
                 fwrite(s->ids + s->off[g], 4, cnt, f);
+                if (fa) fwrite(s->counts + s->off[g], 2, cnt, fa);
                 run += cnt;
             } else {
                 for (uint64_t i = s->off[g]; i < s->off[g + 1]; i++)
                     if ((s->ids[i] & cmask) == (uint32_t)c) { /* drtuple % component_num, iseq2comem.c:543 */
                         uint32_t id = s->ids[i] >> cb;
                         fwrite(&id, 4, 1, f);
+                        if (fa) fwrite(s->counts + i, 2, 1, fa);
                         run++;
                     }
             }
             idx[g + 1] = run;
         }
+        if (fa && fclose(fa) != 0) { fclose(f); free(idx); return KSSD_HOST_ERR_IO; }
         if (fclose(f) != 0) { free(idx); return KSSD_HOST_ERR_IO; }
         snprintf(path, sizeof path, "%s/combco.index.%d", dir, c);
         f = fopen(path, "wb");
@@ -280,6 +342,10 @@ int kssd_sketchset_read(kssd_sketchset *s, const char *dir)
     s->ids = malloc((size_t)(s->off[s->n] ? s->off[s->n] : 1) * 4);
     uint64_t *fill = calloc((size_t)s->n + 1, sizeof(uint64_t));
     if (!s->ids || !fill) { free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_NOMEM; }
+    if (s->koc) { /* abundances, if their files are around (the searches never need them, command_dist.c:880) */
+        s->counts = calloc((size_t)(s->off[s->n] ? s->off[s->n] : 1), 2);
+        if (!s->counts) { free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_NOMEM; }
+    }
     const int cb = comp_bits_of(s->comp_num);
     char path[4096];
     for (int c = 0; c < s->comp_num; c++) {
@@ -292,14 +358,24 @@ int kssd_sketchset_read(kssd_sketchset *s, const char *dir)
             free(idx); free(co); free(fill); kssd_sketchset_release(s);
             return KSSD_HOST_ERR_FORMAT;
         }
+        uint16_t *ab = NULL;
+        if (s->koc) {
+            size_t la = 0;
+            snprintf(path, sizeof path, "%s/combco.%d.a", dir, c);
+            ab = slurp_file(path, &la);
+            if (ab && la != (size_t)idx[s->n] * 2) { free(ab); ab = NULL; }
+            if (!ab) { free(s->counts); s->counts = NULL; }
+        }
         for (uint32_t g = 0; g < s->n; g++)
             for (uint64_t i = idx[g]; i < idx[g + 1]; i++) {
                 uint64_t w = s->off[g] + fill[g]++;
-                if (w >= s->off[g + 1]) { free(idx); free(co); free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_FORMAT; }
+                if (w >= s->off[g + 1]) { free(idx); free(co); free(ab); free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_FORMAT; }
                 s->ids[w] = (co[i] << cb) | (uint32_t)c;
+                if (ab && s->counts) s->counts[w] = ab[i];
             }
         free(idx);
         free(co);
+        free(ab);
     }
     free(fill);
     return KSSD_HOST_OK;

@@ -396,6 +396,42 @@ int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int
     return KSSD_HOST_OK;
 }
 
+#define KOC_LINE 4096 /* FQ_LEN of the abundance scanner, iseq2comem.c:553 */
+
+/* the reads as dist -A scans them (mt_shortreads2koc, iseq2comem.c:554-615): records of four fgets() lines of at
+ * most KOC_LINE-1 bytes, the second one scanned up to its newline, no quality filter; a read restarts the k-mer and
+ * so does every byte that is not ACGT/acgt.  (A line without newline inside KOC_LINE-1 bytes makes the reference
+ * run off its buffer; here the scan stops at the end of what fgets() returned.) */
+int kssd_batch_add_reads(kssd_batch *b, const unsigned char *text, size_t n, uint64_t *n_reads)
+{
+    if (!fa_class_ready) fa_class_init();
+    int rc = batch_begin(b);
+    if (rc) return rc;
+    char *seq = calloc(1, KOC_LINE + 10), *tmp = calloc(1, KOC_LINE + 10);
+    if (!seq || !tmp) { free(seq); free(tmp); return KSSD_HOST_ERR_NOMEM; }
+    gwriter w;
+    gw_start(&w, b);
+    mstream ms = {text, n, 0, 0};
+    uint64_t reads = 0;
+    while (ms_gets(tmp, KOC_LINE, &ms) && ms_gets(seq, KOC_LINE, &ms) && ms_gets(tmp, KOC_LINE, &ms) && ms_gets(tmp, KOC_LINE, &ms)) {
+        w.pending_break = 1;
+        for (int pos = 0; seq[pos] && seq[pos] != '\n'; pos++) {
+            unsigned cls = fa_class[(unsigned char)seq[pos]];
+            if (cls < 4) {
+                if ((rc = gw_base(&w, cls)) != 0) { gw_abort(&w); free(seq); free(tmp); return rc; }
+            } else {
+                w.pending_break = 1;
+            }
+        }
+        reads++;
+    }
+    free(seq);
+    free(tmp);
+    gw_finish(&w);
+    if (n_reads) *n_reads = reads;
+    return KSSD_HOST_OK;
+}
+
 int kssd_slurp(const char *path, unsigned char **buf, size_t *len)
 {
     gzFile g = gzopen(path, "rb");
@@ -429,7 +465,8 @@ int kssd_batch_add_file(kssd_batch *b, const char *path, int is_fastq, int Q, ui
     size_t n = 0;
     int rc = kssd_slurp(path, &txt, &n);
     if (rc) return rc;
-    rc = is_fastq ? kssd_batch_add_fastq(b, txt, n, Q, n_lines) : kssd_batch_add_fasta(b, txt, n);
+    rc = is_fastq == 2 ? kssd_batch_add_reads(b, txt, n, n_lines)
+         : is_fastq ? kssd_batch_add_fastq(b, txt, n, Q, n_lines) : kssd_batch_add_fasta(b, txt, n);
     free(txt);
     return rc;
 }

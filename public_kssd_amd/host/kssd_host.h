@@ -49,7 +49,11 @@ int kssd_batch_add_fasta(kssd_batch *b, const unsigned char *text, size_t n);
 /* append one read set; framing and quality rule of fastq2co (iseq2comem.c:289-321);
  * *n_lines receives the reference's "reads detected" figure (4 x records) */
 int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int Q, uint64_t *n_lines);
-/* read a file (gzip or plain, like `zcat -fc`, iseq2comem.c:187) and append it */
+/* append one read set the way the abundance scanner of dist -A frames it (mt_shortreads2koc, iseq2comem.c:554-581):
+ * four lines per read, no quality rule; *n_reads receives the number of reads */
+int kssd_batch_add_reads(kssd_batch *b, const unsigned char *text, size_t n, uint64_t *n_reads);
+/* read a file (gzip or plain, like `zcat -fc`, iseq2comem.c:187) and append it; is_fastq: 0 FASTA, 1 FASTQ,
+ * 2 FASTQ for abundance sketches (kssd_batch_add_reads) */
 int kssd_batch_add_file(kssd_batch *b, const char *path, int is_fastq, int Q, uint64_t *n_lines);
 const uint32_t *kssd_batch_packed(const kssd_batch *b);
 const uint32_t *kssd_batch_mask(const kssd_batch *b);
@@ -75,13 +79,14 @@ int kssd_derive(kssd_derived *d, int k, int subk, int drlevel);
 /* ---- on-disk sketch / index formats -------------------------------------------- */
 typedef struct kssd_sketchset {
     uint32_t shuf_id;
-    int koc;                 /* abundance flag of co_dstat_t, always 0 here */
+    int koc;                 /* abundance flag of co_dstat_t (dist -A): counts below go to / come from combco.<c>.a */
     int kmerlen, dim_rd_len; /* 2k, 2*drlevel */
     int comp_num;
     uint32_t n;              /* genomes */
     uint64_t *off;           /* n+1, exclusive prefix */
     uint32_t *ids;           /* FULL reduced tuples (component folded back in), genome after genome */
     char (*names)[KSSD_PATHLEN];
+    uint16_t *counts;        /* koc != 0: occurrences of ids[i], saturated at 65535 (write_fqkoc2files, iseq2comem.c:435-471); else NULL */
 } kssd_sketchset;
 void kssd_sketchset_release(kssd_sketchset *s);
 
@@ -96,7 +101,12 @@ void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize);
  * slots: there the order is exact only in the absence of collisions with such ids.) */
 void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
 
-/* write cofiles.stat + combco.<c> + combco.index.<c> like run_stageI (command_dist.c:314-378).
+/* abundances follow a reordering of one genome's (distinct) ids: counts_after[i] = the count ids_after[i] had in
+ * (ids_before, counts_before); KSSD_HOST_ERR_PARAM if an id of ids_after is not among ids_before */
+int kssd_counts_follow(const uint32_t *ids_before, const uint16_t *counts_before, const uint32_t *ids_after,
+                       uint16_t *counts_after, uint64_t n);
+
+/* write cofiles.stat + combco.<c> + combco.index.<c> (+ combco.<c>.a when koc) like run_stageI (command_dist.c:314-378).
  * slot_order != 0 applies kssd_slot_order per genome (ids are modified in place). */
 int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hashsize, int slot_order);
 /* read them back (all components folded into full tuples) */

@@ -56,6 +56,33 @@ def test_oracle_sketches_equal_reference(shuf):
     assert len(SK["qry/edge.fa"]) > 20
 
 
+def test_oracle_abundance_sketch_equals_reference(shuf, tmp_path):
+    """dist -A (mt_shortreads2koc + write_fqkoc2files): ids in file order and their u16 occurrences; the host reader
+    and writer carry combco.<c>.a and the koc flag of cofiles.stat"""
+    A = np.load(os.path.join(G, "abund.npz"))
+    sk = ko.Sketcher(shuf.table, 10, 6, 3)
+    fq = read_any(os.path.join(G, "reads.fq.gz"))
+    ids, counts = sk.fastq_koc(fq)
+    assert np.array_equal(ids, A["ids"]) and np.array_equal(counts, A["counts"]) and int(A["koc"]) == 1
+    assert counts.max() > 1
+    # the same set as the plain FASTQ sketch with -n 1
+    assert np.array_equal(np.sort(ids), SK["fq1/reads.fq.gz"])
+    b = K.Batch()
+    assert b.add_reads(fq) == 3000 and b.n_genomes == 1
+    # writer / reader: slot order restored from sorted ids, abundances follow their ids
+    o = np.argsort(ids)
+    s = K.SketchSet(shuf.id, 20, 6, 1, ["reads.fq.gz"], [0, len(ids)], ids[o], counts[o])
+    s.write(str(tmp_path / "koc"), sk.p.hashsize, slot_order=True)
+    assert np.array_equal(np.fromfile(str(tmp_path / "koc" / "combco.0"), np.uint32), A["ids"])
+    assert np.array_equal(np.fromfile(str(tmp_path / "koc" / "combco.0.a"), np.uint16), A["counts"])
+    assert np.array_equal(np.fromfile(str(tmp_path / "koc" / "combco.index.0"), np.uint64), A["index"])
+    head = np.fromfile(str(tmp_path / "koc" / "cofiles.stat"), np.uint8)[:32]
+    keep = np.r_[0:5, 8:32]  # bytes 5..7 pad the reference's bool
+    assert np.array_equal(head[keep], A["stat_head"][keep])
+    back = K.SketchSet.read(str(tmp_path / "koc"))
+    assert np.array_equal(back.ids, A["ids"]) and np.array_equal(back.counts, A["counts"])
+
+
 def golden_sets():
     rn, qn = [str(x) for x in SH["ref_names"]], [str(x) for x in SH["qry_names"]]
     roff = np.cumsum([0] + [len(SK["ref/" + n]) for n in rn]).astype(np.uint64)

@@ -82,6 +82,35 @@ def test_fastq_and_auto_shuf(tmp_path):
         assert np.array_equal(ids, np.sort(sk.file(os.path.join(G, "ref_fa", nm))))
 
 
+def test_abundance_sketch_files_are_the_references(tmp_path):
+    """dist -A on reads: combco.0, combco.0.a, combco.index.0 byte for byte what the reference wrote with one thread,
+    koc set in cofiles.stat; a search with such a query ignores the abundances like the reference does
+    (command_dist.c:880)"""
+    d = str(tmp_path)
+    A = np.load(os.path.join(G, "abund.npz"))
+    run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
+    out = run(["dist", "-A", "-L", "L3K10.shuf", "-o", "koc", os.path.join(G, "reads.fq.gz")], d)
+    assert "running mt_shortreads2koc()" in out
+    assert np.array_equal(np.fromfile(os.path.join(d, "koc", "combco.0"), np.uint32), A["ids"])
+    assert np.array_equal(np.fromfile(os.path.join(d, "koc", "combco.0.a"), np.uint16), A["counts"])
+    assert np.array_equal(np.fromfile(os.path.join(d, "koc", "combco.index.0"), np.uint64), A["index"])
+    head = np.fromfile(os.path.join(d, "koc", "cofiles.stat"), np.uint8)[:32]
+    keep = np.r_[0:5, 8:32]
+    assert np.array_equal(head[keep], A["stat_head"][keep])
+    # -A with a FASTA among the inputs closes the mode with the reference's warning
+    out = run(["dist", "-A", "-L", "L3K10.shuf", "-o", "mixed", os.path.join(G, "reads.fq.gz"),
+               os.path.join(G, "qry_fa", "edge.fa")], d)
+    assert "Warning: close abundance mode (-A) since non-fastq file input." in out
+    assert not os.path.exists(os.path.join(d, "mixed", "combco.0.a"))
+    assert np.fromfile(os.path.join(d, "mixed", "cofiles.stat"), np.uint8)[4] == 0
+    # search: reads against the references, same numbers with and without abundances
+    run(["dist", "-L", "L3K10.shuf", "-o", "ref", os.path.join(G, "ref_fa")], d)
+    run(["dist", "-L", "L3K10.shuf", "-o", "plain", os.path.join(G, "reads.fq.gz")], d)
+    run(["dist", "-r", "ref", "-o", "d_koc", "koc"], d)
+    run(["dist", "-r", "ref", "-o", "d_plain", "plain"], d)
+    assert open(os.path.join(d, "d_koc", "distance.out")).read() == open(os.path.join(d, "d_plain", "distance.out")).read()
+
+
 def test_errors_match_the_reference(tmp_path):
     d = str(tmp_path)
     r = subprocess.run([BIN, "shuffle", "-k", "10", "-s", "8", "-l", "5", "-o", "x"], cwd=d, stderr=subprocess.PIPE)

@@ -103,6 +103,44 @@ def test_fastq_min_occ(gpu_ctx, shuf_l3k10):
     assert len(ids) == 0 and len(sk.fastq(fq2, Q=ord("5"), M=1)) == 0
 
 
+def test_occurrence_counts_of_the_abundance_sketches(gpu_ctx, shuf_l3k10, monkeypatch):
+    """KSSD_SKETCH_COUNTS: every id with its number of occurrences (dist -A, iseq2comem.c:554-615), saturating at
+    65535 like the reference's 16-bit counter; through the LDS sort and through the big-genome path"""
+    rng = np.random.default_rng(11)
+    genome = rng.integers(0, 4, 200000, dtype=np.uint8)
+    reads = []
+    for _ in range(9000):
+        s = int(rng.integers(0, len(genome) - 150))
+        r = genome[s:s + 150].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(r)
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    # one read that holds a sampled k-mer, 70 000 times: its k-mers saturate the counter
+    hot = next(r for r in reads if len(sk.fastq_koc(fastq_text([r]))[0]) > 0)
+    fq_a = fastq_text(reads)
+    fq_b = fastq_text(reads[:2000] + [hot] * 70000)
+    for big in (False, True):
+        if big:
+            monkeypatch.setenv("KSSD_DEV_BIG_MIN", "64")  # read per call
+        ctx = gpu_ctx
+        b = K.Batch()
+        assert b.add_reads(fq_a) == len(reads)
+        assert b.add_reads(fq_b) == 72000
+        off, ids, cnt = ctx.sketch_batch_pos(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY | K.SKETCH_COUNTS)
+        for g, fq in enumerate((fq_a, fq_b)):
+            wi, wc = sk.fastq_koc(fq)
+            o = np.argsort(wi)
+            lo, hi = int(off[g]), int(off[g + 1])
+            assert np.array_equal(ids[lo:hi], wi[o]), (big, g)
+            assert np.array_equal(cnt[lo:hi], wc[o].astype(np.uint32)), (big, g)
+        assert cnt[int(off[1]):].max() == 65535 and cnt[:int(off[1])].max() < 100
+        # positions and counts are one or the other per call
+        with pytest.raises(K.KssdError):
+            ctx.sketch_batch_pos(b, K.SKETCH_KEEP_ZERO | K.SKETCH_FIRST_POS | K.SKETCH_COUNTS)
+    monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
+
+
 @pytest.mark.parametrize("k,subk,dr", [(8, 5, 2), (10, 7, 5), (9, 6, 3), (11, 6, 3), (12, 7, 4)])
 def test_other_shuffles(k, subk, dr):
     shuf = K.Shuf.generate(k, subk, dr, seed=77 + k)

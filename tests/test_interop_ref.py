@@ -134,3 +134,27 @@ def test_reverse_equals_the_reference(work, tmp_path, shuf_l3k10):
         assert filecmp.cmp(str(tmp_path / "r" / nm), str(tmp_path / "o" / nm), shallow=False), nm
         kmers = open(str(tmp_path / "o" / nm)).read().split()
         assert all(len(x) == 20 and set(x) <= set("ACGT") for x in kmers)
+
+
+def test_abundance_sketch_oracle_vs_reference_on_deep_reads(tmp_path, shuf_l3k10):
+    """dist -A -p 1 of the real reference on 30x reads of a 40 kb sequence (occurrences up to dozens) against the
+    oracle restatement: ids in file order and occurrences"""
+    from synth import fastq_text
+    rng = np.random.default_rng(5)
+    genome = rng.integers(0, 4, 40000, dtype=np.uint8)
+    reads = []
+    for _ in range(8000):
+        s = int(rng.integers(0, len(genome) - 150))
+        r = genome[s:s + 150].copy()
+        reads.append((3 - r)[::-1] if rng.random() < 0.5 else r)
+    fq = fastq_text(reads)
+    (tmp_path / "deep.fq").write_bytes(fq)
+    sp = str(tmp_path / "L3K10.shuf")
+    shuf_l3k10.write(sp)
+    ko.run_ref(["dist", "-p", 1, "-A", "-L", sp, "-o", "koc", str(tmp_path / "deep.fq")], cwd=str(tmp_path))
+    ids = np.fromfile(str(tmp_path / "koc" / "combco.0"), np.uint32)
+    cnt = np.fromfile(str(tmp_path / "koc" / "combco.0.a"), np.uint16)
+    wi, wc = ko.Sketcher(shuf_l3k10.table, 10, 6, 3).fastq_koc(fq)
+    assert np.array_equal(ids, wi) and np.array_equal(cnt, wc) and cnt.max() >= 20
+    s = K.SketchSet.read(str(tmp_path / "koc"))
+    assert np.array_equal(s.ids, ids) and np.array_equal(s.counts, cnt)
