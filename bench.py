@@ -12,6 +12,10 @@ its own genomes on the indexed side (all gathered sketches are the query rows): 
 that would otherwise be repeated on every rank, and every metric of the path is symmetric in (query, reference),
 so the R x G block a rank writes is the transpose of its G x R query block.
 
+Steps are pipelined: --inflight batches (default 3) are in flight at a time, each on its own HIP stream with its own
+context and outputs, so that the latency-bound kernels of one step (exact stage, index build) run underneath the scan
+of the next one; --inflight 1 runs the steps back to back on one stream.
+
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -153,6 +157,8 @@ def main():
     ap.add_argument("--clades", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "3")),
+                    help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,8 +183,8 @@ def main():
             dist.init_process_group(backend)
 
     G, L = a.genomes, a.length
+    NF = max(1, a.inflight)
     shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
-    ctx = K.GpuCtx(shuf, local)
     t0 = time.time()
     n_keep = a.cpu_sample if (rank == 0 and world == 1) else 0
     packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * rank, dev, keep_codes=min(n_keep, G))
@@ -186,70 +192,144 @@ def main():
     if rank == 0:
         log("[bench] batch of %d x %.1f Mb packed on device in %.1f s" % (G, L / 1e6, time.time() - t0))
 
-    # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
+    # Software pipeline over steps.  Every step is the whole hot path over one batch; NF = 3 batches are in flight,
+    # each with its own context (workspaces, index), outputs and HIP stream.  The scan fills every CU's LDS, so it
+    # runs alone among the LDS users.  Events between the phases (kssd_gpu_sketch_phase) arrange the rest around it:
+    #     under scan n            exact stage of step n-1, index build of step n-2, per-call setup of step n+1
+    #                             (no LDS; bound by random HBM reads / atomics, a few waves per SIMD)
+    #     between scan n and n+1  per-genome sort of step n-1 and all-pairs rows of step n-2 (LDS users), side by side
+    # Nothing is skipped or reused between steps; --inflight 1 runs the same phases back to back on one stream.
     exp_ids = int(G * L / 4096)
     cap = int(exp_ids * 1.25) + 4096                      # ids per rank (padded all-gather unit)
-    off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
-    ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
     R = G * world
     if world > 1:
-        from public_kssd_amd.shard import SketchGather, query_block
-        gather = SketchGather(world, G, cap, dev)
-        qb, qe = query_block(rank, G)
-    shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
-    planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
-    stream = torch.cuda.current_stream().cuda_stream
+        from public_kssd_amd.shard import SketchGather
 
-    # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
-    # status read-back has told the host how many ids this batch really has
-    idx_bound = [cap]
+    class Slot:
+        pass
+    slots = []
+    for j in range(NF):
+        sl = Slot()
+        sl.ctx = K.GpuCtx(shuf, local)
+        # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
+        sl.off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        sl.ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
+        sl.shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
+        sl.planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
+        sl.tstream = torch.cuda.Stream(device=dev) if NF > 1 else torch.cuda.current_stream()
+        sl.stream = sl.tstream.cuda_stream
+        sl.scanned, sl.sorted = torch.cuda.Event(), torch.cuda.Event()
+        sl.gather = SketchGather(world, G, cap, dev) if world > 1 else None
+        # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
+        # status read-back has told the host how many ids this batch really has
+        sl.idx_bound = cap
+        slots.append(sl)
 
-    def step():
-        ctx.sketch_device(packed, mask, chunk_off, off_l, ids_l, cap, K.SKETCH_FASTA, 1, stream)
+    def plan_prep(sl):
+        sl.ctx.sketch_plan(packed, mask, chunk_off, sl.off_l, sl.ids_l, cap, K.SKETCH_FASTA, 1)
+        sl.ctx.sketch_phase(K.PHASE_PREP, sl.stream)
+
+    def index_build(sl):
         if world == 1:
-            ctx.index_build_device(off_l, ids_l, G, idx_bound[0], stream)
-            ctx.dist_device(off_l, ids_l, G, 0, G, shared, *planes, stream=stream)
+            sl.q = (sl.off_l, sl.ids_l)
         else:
             # the one exchange step of the path: all-gather of every rank's packed sketches (RCCL over xGMI),
             # fixed-size padded units compacted on the device, so that no size has to visit the host
-            roff, rids = gather(off_l, ids_l)
-            # index this rank's own sketches only (constant work per rank), query with everybody's: the R x G block
-            # [all genomes] x [this rank's genomes] = transpose of rows [rank*G, (rank+1)*G) of the global matrix
-            ctx.index_build_device(off_l, ids_l, G, idx_bound[0], stream)
-            ctx.dist_device(roff, rids, R, 0, R, shared, *planes, stream=stream)
+            with torch.cuda.stream(sl.tstream):
+                sl.q = sl.gather(sl.off_l, sl.ids_l)
+        # index this rank's own sketches only (constant work per rank), query with everybody's: the R x G block
+        # [all genomes] x [this rank's genomes] = transpose of rows [rank*G, (rank+1)*G) of the global matrix
+        sl.ctx.index_build_device(sl.off_l, sl.ids_l, G, sl.idx_bound, sl.stream)
+
+    def rows(sl):
+        sl.ctx.dist_device(sl.q[0], sl.q[1], R, 0, R, sl.shared, *sl.planes, stream=sl.stream)
+
+    def run_steps(n_steps):
+        """n_steps whole steps, pipelined over the NF slots; everything is enqueued, nothing synchronised"""
+        if NF < 3:
+            for n in range(n_steps):                      # back to back (NF = 2: two independent chains)
+                sl = slots[n % NF]
+                plan_prep(sl)
+                for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                    sl.ctx.sketch_phase(ph, sl.stream)
+                index_build(sl)
+                rows(sl)
+            return
+        if n_steps > 0:
+            plan_prep(slots[0])
+        for n in range(n_steps + 2):                      # two more rounds drain the pipeline
+            cur, prev, old = slots[n % NF], slots[(n - 1) % NF], slots[(n - 2) % NF]
+            if n < n_steps:
+                if n >= 2:
+                    cur.tstream.wait_event(old.sorted)    # the gap's LDS users are through (the rows of step n-3
+                cur.ctx.sketch_phase(K.PHASE_SCAN, cur.stream)   # precede this scan on its own stream)
+                cur.scanned.record(cur.tstream)
+            if 1 <= n <= n_steps:                         # step n-1: exact stage under scan n, sort after it
+                prev.ctx.sketch_phase(K.PHASE_EXACT, prev.stream)
+                if n < n_steps:
+                    prev.tstream.wait_event(cur.scanned)
+                prev.ctx.sketch_phase(K.PHASE_FINISH, prev.stream)
+                prev.sorted.record(prev.tstream)
+                index_build(prev)                         # runs under scan n+1
+            if n + 1 < n_steps:                           # setup of step n+1 ahead of the rows that share its stream
+                plan_prep(slots[(n + 1) % NF])
+            if 2 <= n:                                    # step n-2: all-pairs rows after scan n
+                if n < n_steps:
+                    old.tstream.wait_event(cur.scanned)
+                rows(old)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # first call sizes the workspaces; retry if a staging region was too small
-    for attempt in range(6):
-        step()
-        rc, total, bad = ctx.sketch_status(stream)
-        if rc == 0:
-            idx_bound[0] = min(cap, int(total) + 1024)
-            break
-        if rc != K.capi.ERR_OVERFLOW:
-            raise SystemExit("sketch failed: rc=%d" % rc)
-    else:
-        raise SystemExit("sketch kept overflowing")
-    for _ in range(a.warmup):
-        step()
+    # first calls size the workspaces of every context; retry if a staging region was too small
+    for sl in slots:
+        for attempt in range(6):
+            plan_prep(sl)
+            for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                sl.ctx.sketch_phase(ph, sl.stream)
+            index_build(sl)
+            rows(sl)
+            rc, total, bad = sl.ctx.sketch_status(sl.stream)
+            if rc == 0:
+                sl.idx_bound = min(cap, int(total) + 1024)
+                break
+            if rc != K.capi.ERR_OVERFLOW:
+                raise SystemExit("sketch failed: rc=%d" % rc)
+        else:
+            raise SystemExit("sketch kept overflowing")
     sync()
-    ctx.kernel_time(0, reset=True)
-    ctx.kernel_time(1, reset=True)
+    run_steps(a.warmup)
+    sync()
+    for sl in slots:
+        sl.ctx.kernel_time(0, reset=True)
+        sl.ctx.kernel_time(1, reset=True)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run_steps(a.steps)
     sync()
     dt = time.perf_counter() - t0
-    rc, total, bad = ctx.sketch_status(stream)
-    if rc != 0:
-        raise SystemExit("sketch status rc=%d after the timed loop" % rc)
-    scan_ms, scan_n = ctx.kernel_time(0)
-    dist_ms, dist_n = ctx.kernel_time(1)
+    scan_ms = dist_ms = 0.0
+    scan_n = dist_n = 0
+    used = slots
+    for sl in used:
+        rc, total, bad = sl.ctx.sketch_status(sl.stream)
+        if rc != 0:
+            raise SystemExit("sketch status rc=%d after the timed loop" % rc)
+        ms, n = sl.ctx.kernel_time(0)
+        scan_ms += ms * n
+        scan_n += n
+        ms, n = sl.ctx.kernel_time(1)
+        dist_ms += ms * n
+        dist_n += n
+    scan_ms = scan_ms / scan_n if scan_n else 0.0       # average launch duration over every timed launch
+    dist_ms = dist_ms / dist_n if dist_n else 0.0
+    ctx, stream = slots[0].ctx, slots[0].stream
+    off_l, ids_l, shared = slots[0].off_l, slots[0].ids_l, slots[0].shared
     n_stage1, n_bloom = ctx.scan_stats(stream)
+    for sl in used[1:]:                                   # every slot worked on the same batch: same results
+        assert torch.equal(sl.off_l, off_l) and torch.equal(sl.shared, shared), "slots disagree"
+        assert torch.equal(sl.ids_l[:int(total)], ids_l[:int(total)]), "slots disagree"
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -280,7 +360,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
                                    "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
-                       "pairs_per_step": world * pairs, "parallelism": "genomes and matrix blocks sharded x%d (own genomes "
+                       "pairs_per_step": world * pairs, "batches_in_flight": NF, "parallelism": "genomes and matrix blocks sharded x%d (own genomes "
                        "indexed, all gathered sketches as query rows), all-gather of sketches" % world if world > 1
                        else "single GPU"},
             "pairs_per_s": world * pairs * a.steps / dt,
@@ -310,7 +390,8 @@ def main():
             except Exception:
                 pass
         print(json.dumps(res), flush=True)
-    ctx.close()
+    for sl in slots:
+        sl.ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -104,6 +104,23 @@ int kssd_gpu_sketch_device(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const ui
                            uint32_t min_occ, uint64_t *d_out_off, uint32_t *d_out_ids,
                            uint64_t out_cap, void *stream);
 /*
+ * The same call, split for callers that stream batches through several contexts (one per batch in flight, each on
+ * its own stream): kssd_gpu_sketch_plan does the host part (validation, workspace sizing; no stream work),
+ * kssd_gpu_sketch_phase enqueues one phase.  Phases of one plan go on one stream, in order PREP, SCAN, EXACT, FINISH;
+ * the caller may put event waits between them so that the phases without LDS use (PREP, EXACT) run underneath another
+ * context's SCAN, and the LDS users (FINISH) between two scans (bench.py).  kssd_gpu_sketch_device = the plan and
+ * the four phases back to back.
+ */
+#define KSSD_PHASE_PREP 0   /* per-call state, chunk -> genome map                         */
+#define KSSD_PHASE_SCAN 1   /* the scan kernel: every CU's LDS                             */
+#define KSSD_PHASE_EXACT 2  /* exact evaluation of the candidates: no LDS, random HBM reads */
+#define KSSD_PHASE_FINISH 3 /* per-genome dedup (LDS sort), CSR offsets, gather            */
+int kssd_gpu_sketch_plan(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
+                         const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
+                         uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap);
+int kssd_gpu_sketch_phase(kssd_gpu_ctx *ctx, int phase, void *stream);
+
+/*
  * Synchronises `stream` and reports on the last kssd_gpu_sketch_device call:
  *   *total_ids  = ids the batch produced (valid even on KSSD_ERR_OVERFLOW: size to retry with)
  *   *bad_genome = first genome that raised KSSD_ERR_CAPACITY, else -1

@@ -27,6 +27,7 @@ SKETCH_UNIQ = 2
 SKETCH_NO_CAPACITY = 4
 SKETCH_FIRST_POS = 8
 SKETCH_COUNTS = 16
+PHASE_PREP, PHASE_SCAN, PHASE_EXACT, PHASE_FINISH = 0, 1, 2, 3
 
 OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -36,7 +37,8 @@ GPU_SYMBOLS = [
     "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
     "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
-    "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter",
+    "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
+    "kssd_gpu_sketch_phase",
 ]
 
 
@@ -101,6 +103,8 @@ def gpu_lib():
         L.kssd_gpu_destroy.restype = None
         L.kssd_gpu_get_info.argtypes = [vp, C.POINTER(GpuInfo)]
         L.kssd_gpu_sketch_device.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, u64, vp]
+        L.kssd_gpu_sketch_plan.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, u64]
+        L.kssd_gpu_sketch_phase.argtypes = [vp, i32, vp]
         L.kssd_gpu_sketch_status.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_int64), vp]
         L.kssd_gpu_sketch_batch.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp),
                                             C.POINTER(C.c_int64)]
@@ -499,6 +503,15 @@ class GpuCtx:
         _gck(gpu_lib().kssd_gpu_sketch_device(self.h, _ptr(d_packed), _ptr(d_mask), chunk_off.ctypes.data,
                                               len(chunk_off) - 1, flags, min_occ, _ptr(d_out_off), _ptr(d_out_ids),
                                               out_cap, stream))
+
+    def sketch_plan(self, d_packed, d_mask, chunk_off, d_out_off, d_out_ids, out_cap, flags=SKETCH_FASTA, min_occ=1):
+        """host part of sketch_device; the phases follow with sketch_phase (PHASE_PREP .. PHASE_FINISH, one stream)"""
+        chunk_off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        _gck(gpu_lib().kssd_gpu_sketch_plan(self.h, _ptr(d_packed), _ptr(d_mask), chunk_off.ctypes.data,
+                                            len(chunk_off) - 1, flags, min_occ, _ptr(d_out_off), _ptr(d_out_ids), out_cap))
+
+    def sketch_phase(self, phase, stream=None):
+        _gck(gpu_lib().kssd_gpu_sketch_phase(self.h, phase, stream))
 
     def sketch_status(self, stream=None):
         """(rc, total_ids, bad_genome) after synchronising the stream"""

@@ -107,6 +107,19 @@ struct kssd_gpu_ctx {
     int last_launch_rc;
     std::vector<uint64_t> h_reg_off;
     std::vector<uint32_t> h_big;  // genomes of the last batch that take the global-memory dedup path
+    // the planned call (kssd_gpu_sketch_plan), executed phase by phase (kssd_gpu_sketch_phase)
+    struct {
+        bool valid;
+        const uint32_t *d_packed, *d_mask;
+        uint32_t n_genomes, flags, min_occ, big_min, n_slices;
+        bool with_pos;
+        uint64_t n_chunks, max_cap, max_big, cand_cap, out_cap;
+        int grid;
+        uint64_t *d_out_off;
+        uint32_t *d_out_ids;
+    } plan;
+    std::vector<uint64_t> h_chunk_off;      // the planned batch's chunk offsets
+    std::vector<uint64_t> dev_chunk_off, dev_reg_off;  // what d_chunk_off / d_reg_off hold (copies are skipped when unchanged)
     uint32_t *d_big_alt;          // sort output | tile counts | 2 accumulators
     size_t cap_big_alt;
     void *d_big_tmp;              // rocPRIM temporary storage
@@ -300,9 +313,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 // (it also zeroes the small per-call state: four separate memsets cost more than this whole kernel)
 __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes, uint64_t n_chunks,
                                  uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                 uint32_t n_slices, unsigned long long *__restrict__ lane_valid_tail)
+                                 uint32_t n_slices, unsigned long long *__restrict__ lane_valid_tail,
+                                 uint32_t *__restrict__ status_words)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < sizeof(SketchStatus) / 4) status_words[c] = 0;
     if (c < n_genomes) cursor[c] = 0;
     if (c < n_slices) cand_count[c] = 0;
     if (c < 2) lane_valid_tail[c] = 0;  // a k-mer that would end past the batch is not "known valid"
@@ -971,12 +986,21 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     return KSSD_OK;
 }
 
-extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask,
-                                      const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
-                                      uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap, void *stream)
+// A sketch call = a plan (host: validation, workspace sizes, staging layout) and four phases on a stream:
+//   PREP    per-call state, chunk -> genome map          (no LDS, small)
+//   SCAN    the scan kernel                              (every CU's LDS)
+//   EXACT   stage 2 on the candidates                    (no LDS, bound by random HBM reads)
+//   FINISH  per-genome dedup, CSR offsets, gather        (LDS sort)
+// kssd_gpu_sketch_device runs them back to back.  A caller that streams batches through several contexts puts its
+// own event waits between the phases, so that the LDS-free phases of one batch run underneath the scan of another
+// (bench.py); the results do not depend on how the phases are interleaved with other contexts' work.
+extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask,
+                                    const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
+                                    uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap)
 {
-    if (!c || c->dist_only || !h_chunk_off || !d_out_off || (!d_out_ids && out_cap)) return KSSD_ERR_PARAM;
-    hipStream_t s = (hipStream_t)stream;
+    if (!c) return KSSD_ERR_PARAM;
+    c->plan.valid = false;
+    if (c->dist_only || !h_chunk_off || !d_out_off || (!d_out_ids && out_cap)) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     c->last_launch_rc = KSSD_OK;
     c->last_n_genomes = n_genomes;
@@ -985,9 +1009,11 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     if ((flags & KSSD_SKETCH_FIRST_POS) && (flags & KSSD_SKETCH_COUNTS)) return KSSD_ERR_PARAM;  // one or the other per call
     if (with_pos && !c->d_out_pos) return KSSD_ERR_PARAM;  // kssd_gpu_sketch_set_pos_output first
     const uint64_t n_chunks = h_chunk_off[n_genomes];
-    HIPCK(hipMemsetAsync(c->d_status, 0, sizeof(SketchStatus), s));
+    auto &pl = c->plan;
+    pl.d_packed = d_packed; pl.d_mask = d_mask; pl.n_genomes = n_genomes; pl.flags = flags; pl.min_occ = min_occ;
+    pl.with_pos = with_pos; pl.n_chunks = n_chunks; pl.d_out_off = d_out_off; pl.d_out_ids = d_out_ids; pl.out_cap = out_cap;
     if (n_genomes == 0) {
-        HIPCK(hipMemsetAsync(d_out_off, 0, sizeof(uint64_t), s));
+        pl.valid = true;
         return KSSD_OK;
     }
     // staging regions: expected emissions = positions * dim_end / 16^subk, times a safety factor
@@ -1019,10 +1045,17 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
         if (cap > big_min && cap > max_big) max_big = cap;
     }
     c->h_reg_off[n_genomes] = acc;
+    c->h_chunk_off.assign(h_chunk_off, h_chunk_off + n_genomes + 1);
     int rc;
     if ((rc = ensure(&c->d_chunk_gid, &c->cap_chunks, (size_t)n_chunks + 1)) != KSSD_OK) return rc;
-    if ((rc = ensure(&c->d_chunk_off, &c->cap_chunk_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
-    if ((rc = ensure(&c->d_reg_off, &c->cap_reg_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
+    {
+        const size_t before = c->cap_chunk_off;
+        if ((rc = ensure(&c->d_chunk_off, &c->cap_chunk_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
+        if (c->cap_chunk_off != before) c->dev_chunk_off.clear();
+        const size_t before2 = c->cap_reg_off;
+        if ((rc = ensure(&c->d_reg_off, &c->cap_reg_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
+        if (c->cap_reg_off != before2) c->dev_reg_off.clear();
+    }
     if ((rc = ensure(&c->d_cursor, &c->cap_cursor, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_kept, &c->cap_kept, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_regions, &c->cap_regions, ((size_t)acc + 1) * (with_pos ? 2 : 1))) != KSSD_OK) return rc;
@@ -1037,62 +1070,130 @@ extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed,
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
     if ((rc = ensure(&c->d_lane_valid, &c->cap_lane_valid, (size_t)n_chunks + 2)) != KSSD_OK) return rc;
+    pl.big_min = big_min; pl.max_cap = max_cap; pl.max_big = max_big; pl.cand_cap = cand_cap; pl.n_slices = n_slices; pl.grid = grid;
+    pl.valid = true;
+    return KSSD_OK;
+}
 
-    HIPCK(hipMemcpyAsync(c->d_chunk_off, h_chunk_off, ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCK(hipMemcpyAsync(c->d_reg_off, c->h_reg_off.data(), ((size_t)n_genomes + 1) * 8, hipMemcpyHostToDevice, s));
-    {
-        uint64_t init_n = n_chunks > n_genomes ? n_chunks : n_genomes;
-        if (init_n < n_slices) init_n = n_slices;
-        hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
-                           (const uint64_t *)c->d_chunk_off, n_genomes, n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
-                           n_slices, c->d_lane_valid + n_chunks);
+static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
+{
+    const auto &pl = c->plan;
+    if (pl.n_genomes == 0) {
+        HIPCK(hipMemsetAsync(c->d_status, 0, sizeof(SketchStatus), s));
+        HIPCK(hipMemsetAsync(pl.d_out_off, 0, sizeof(uint64_t), s));
+        return KSSD_OK;
     }
-    if (n_chunks) {
-        ScanArgs a;
-        a.packed = d_packed; a.mask = d_mask; a.n_chunks = n_chunks; a.tab = c->d_T1;
-        a.cand = (unsigned long long *)c->d_cand; a.cand_cap = cand_cap; a.cand_count = c->d_cand_count;
-        a.lane_valid = c->d_lane_valid;
-        a.status = c->d_status;
-        const unsigned evi = c->ev_n[0] % EV_RING;
-        HIPCK(hipEventRecord(c->ev_a[0][evi], s));
-        switch (c->P.subk) {
-        case 2: rc = launch_scan<2>(c, a, grid, s); break;
-        case 3: rc = launch_scan<3>(c, a, grid, s); break;
-        case 4: rc = launch_scan<4>(c, a, grid, s); break;
-        case 5: rc = launch_scan<5>(c, a, grid, s); break;
-        case 6: {
-            static const int abl = getenv("KSSD_DEV_ABLATE") ? atoi(getenv("KSSD_DEV_ABLATE")) : 0;  // profiling only
-            if (abl == 1) rc = launch_scan<6, 1>(c, a, grid, s);
-            else if (abl == 2) rc = launch_scan<6, 2>(c, a, grid, s);
-            else if (abl == 3) rc = launch_scan<6, 3>(c, a, grid, s);
-            else rc = launch_scan<6>(c, a, grid, s);
-            break;
-        }
-        case 7: rc = launch_scan<7>(c, a, grid, s); break;
-        default: rc = KSSD_ERR_UNSUPPORTED;
-        }
-        if (rc != KSSD_OK) return rc;
-        HIPCK(hipEventRecord(c->ev_b[0][evi], s));
-        c->ev_n[0]++;
-        ExactArgs x;
-        x.packed = d_packed; x.mask = d_mask; x.chunk_gid = c->d_chunk_gid;
-        x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;
-        x.cand = (const unsigned long long *)c->d_cand; x.cand_cap = cand_cap; x.cand_count = c->d_cand_count;
-        x.lane_valid = c->d_lane_valid;
-        x.n_slices = n_slices;
-        x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
-        x.status = c->d_status;
-        if (with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
-        else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), dim3((unsigned)((cand_cap + 255) / 256), n_slices), dim3(256), 0, s, c->P, x);
+    const size_t nb = ((size_t)pl.n_genomes + 1) * 8;
+    // the layout tables travel only when they differ from what the device holds (a stream of equally shaped batches
+    // pays for them once)
+    if (c->dev_chunk_off != c->h_chunk_off) {
+        HIPCK(hipMemcpyAsync(c->d_chunk_off, c->h_chunk_off.data(), nb, hipMemcpyHostToDevice, s));
+        c->dev_chunk_off = c->h_chunk_off;
     }
+    if (c->dev_reg_off != c->h_reg_off) {
+        HIPCK(hipMemcpyAsync(c->d_reg_off, c->h_reg_off.data(), nb, hipMemcpyHostToDevice, s));
+        c->dev_reg_off = c->h_reg_off;
+    }
+    uint64_t init_n = pl.n_chunks > pl.n_genomes ? pl.n_chunks : pl.n_genomes;
+    if (init_n < pl.n_slices) init_n = pl.n_slices;
+    if (init_n < sizeof(SketchStatus) / 4) init_n = sizeof(SketchStatus) / 4;
+    hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
+                       (const uint64_t *)c->d_chunk_off, pl.n_genomes, pl.n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
+                       pl.n_slices, c->d_lane_valid + pl.n_chunks, reinterpret_cast<uint32_t *>(c->d_status));
+    HIPCK(hipGetLastError());
+    return KSSD_OK;
+}
+
+static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
+{
+    const auto &pl = c->plan;
+    if (pl.n_genomes == 0 || pl.n_chunks == 0) return KSSD_OK;
+    int rc;
+    ScanArgs a;
+    a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
+    a.cand = (unsigned long long *)c->d_cand; a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
+    a.lane_valid = c->d_lane_valid;
+    a.status = c->d_status;
+    const int grid = pl.grid;
+    const unsigned evi = c->ev_n[0] % EV_RING;
+    HIPCK(hipEventRecord(c->ev_a[0][evi], s));
+    switch (c->P.subk) {
+    case 2: rc = launch_scan<2>(c, a, grid, s); break;
+    case 3: rc = launch_scan<3>(c, a, grid, s); break;
+    case 4: rc = launch_scan<4>(c, a, grid, s); break;
+    case 5: rc = launch_scan<5>(c, a, grid, s); break;
+    case 6: {
+        static const int abl = getenv("KSSD_DEV_ABLATE") ? atoi(getenv("KSSD_DEV_ABLATE")) : 0;  // profiling only
+        if (abl == 1) rc = launch_scan<6, 1>(c, a, grid, s);
+        else if (abl == 2) rc = launch_scan<6, 2>(c, a, grid, s);
+        else if (abl == 3) rc = launch_scan<6, 3>(c, a, grid, s);
+        else rc = launch_scan<6>(c, a, grid, s);
+        break;
+    }
+    case 7: rc = launch_scan<7>(c, a, grid, s); break;
+    default: rc = KSSD_ERR_UNSUPPORTED;
+    }
+    if (rc != KSSD_OK) return rc;
+    HIPCK(hipEventRecord(c->ev_b[0][evi], s));
+    c->ev_n[0]++;
+    return KSSD_OK;
+}
+
+static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
+{
+    const auto &pl = c->plan;
+    if (pl.n_genomes == 0 || pl.n_chunks == 0) return KSSD_OK;
+    ExactArgs x;
+    x.packed = pl.d_packed; x.mask = pl.d_mask; x.chunk_gid = c->d_chunk_gid;
+    x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;
+    x.cand = (const unsigned long long *)c->d_cand; x.cand_cap = pl.cand_cap; x.cand_count = c->d_cand_count;
+    x.lane_valid = c->d_lane_valid;
+    x.n_slices = pl.n_slices;
+    x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
+    x.status = c->d_status;
+    const dim3 grid((unsigned)((pl.cand_cap + 255) / 256), pl.n_slices);
+    if (pl.with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), grid, dim3(256), 0, s, c->P, x);
+    else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), grid, dim3(256), 0, s, c->P, x);
+    HIPCK(hipGetLastError());
+    return KSSD_OK;
+}
+
+static int phase_finish(kssd_gpu_ctx *c, hipStream_t s)
+{
+    const auto &pl = c->plan;
+    if (pl.n_genomes == 0) return KSSD_OK;
+    uint32_t flags = pl.flags;
     if (c->region_factor > 2.0) flags |= SKETCH_TRACK_FILL;
-    rc = with_pos ? finish_sketch<unsigned long long>(c, n_genomes, flags, min_occ, big_min, max_cap, max_big, d_out_off, d_out_ids,
-                                                      c->d_out_pos, out_cap, s)
-                  : finish_sketch<uint32_t>(c, n_genomes, flags, min_occ, big_min, max_cap, max_big, d_out_off, d_out_ids, nullptr,
-                                            out_cap, s);
+    int rc = pl.with_pos ? finish_sketch<unsigned long long>(c, pl.n_genomes, flags, pl.min_occ, pl.big_min, pl.max_cap, pl.max_big,
+                                                             pl.d_out_off, pl.d_out_ids, c->d_out_pos, pl.out_cap, s)
+                         : finish_sketch<uint32_t>(c, pl.n_genomes, flags, pl.min_occ, pl.big_min, pl.max_cap, pl.max_big, pl.d_out_off,
+                                                   pl.d_out_ids, nullptr, pl.out_cap, s);
     if (rc != KSSD_OK) return rc;
     HIPCK(hipGetLastError());
     return KSSD_OK;
+}
+
+extern "C" int kssd_gpu_sketch_phase(kssd_gpu_ctx *c, int phase, void *stream)
+{
+    if (!c || !c->plan.valid) return KSSD_ERR_PARAM;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(hipSetDevice(c->device));
+    switch (phase) {
+    case KSSD_PHASE_PREP: return phase_prep(c, s);
+    case KSSD_PHASE_SCAN: return phase_scan(c, s);
+    case KSSD_PHASE_EXACT: return phase_exact(c, s);
+    case KSSD_PHASE_FINISH: return phase_finish(c, s);
+    default: return KSSD_ERR_PARAM;
+    }
+}
+
+extern "C" int kssd_gpu_sketch_device(kssd_gpu_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask,
+                                      const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
+                                      uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap, void *stream)
+{
+    int rc = kssd_gpu_sketch_plan(c, d_packed, d_mask, h_chunk_off, n_genomes, flags, min_occ, d_out_off, d_out_ids, out_cap);
+    for (int ph = KSSD_PHASE_PREP; rc == KSSD_OK && ph <= KSSD_PHASE_FINISH; ph++) rc = kssd_gpu_sketch_phase(c, ph, stream);
+    return rc;
 }
 
 extern "C" int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *c, uint32_t *d_out_pos)
