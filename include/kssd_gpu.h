@@ -54,6 +54,11 @@ extern "C" {
                                     /*   second output array instead of positions: the abundance sketches of   */
                                     /*   -A (mt_shortreads2koc / write_fqkoc2files, iseq2comem.c:435-471,552-615) */
 
+#define KSSD_SKETCH_BY_POS 32u      /* no dedup at all: EVERY sampled k-mer of a genome, in sequence order, repeats  */
+                                    /*   and id 0 included; the second output array holds its position.  The stream  */
+                                    /*   reads2mco writes for dist --byread (iseq2comem.c:156-176); the caller cuts it  */
+                                    /*   into reads at the positions its tokeniser recorded for the '>' lines          */
+
 typedef struct kssd_gpu_ctx kssd_gpu_ctx;
 
 /* mirrors dim_shuffle_stat_t (command_shuffle.h:17-23) */
@@ -137,9 +142,10 @@ int kssd_gpu_sketch_status(kssd_gpu_ctx *ctx, uint64_t *total_ids, int64_t *bad_
 int kssd_gpu_scan_stats(kssd_gpu_ctx *ctx, uint64_t *stage1, uint64_t *bloom, void *stream);
 
 /*
- * Where kssd_gpu_sketch_device writes the first positions when called with KSSD_SKETCH_FIRST_POS: DEVICE
- * u32[out_cap], parallel to d_out_ids (position of the id's first occurrence, counted from the genome's first
- * chunk).  Genomes must be shorter than 2^32 positions in that mode.
+ * Where kssd_gpu_sketch_device writes the first positions when called with KSSD_SKETCH_FIRST_POS (the counts with
+ * KSSD_SKETCH_COUNTS, the positions of the stream with KSSD_SKETCH_BY_POS): DEVICE u32[out_cap], parallel to
+ * d_out_ids (position of the id's first occurrence, counted from the genome's first chunk).  Genomes must be
+ * shorter than 2^32 positions in these modes.
  */
 int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *ctx, uint32_t *d_out_pos);
 
@@ -149,7 +155,7 @@ int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint3
                           uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                           int64_t *bad_genome);
 /* same, plus the first position of every id (KSSD_SKETCH_FIRST_POS is added to flags) or, with KSSD_SKETCH_COUNTS
- * in flags, its number of occurrences */
+ * in flags, its number of occurrences or, with KSSD_SKETCH_BY_POS, the position of every entry of the k-mer stream */
 int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
                               const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
                               uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos,

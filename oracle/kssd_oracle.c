@@ -226,6 +226,60 @@ long ko_fasta2co(ko_ctx *c, const unsigned char *text, size_t n, int uniq, u32 *
     return dump_plain(c, ids, comps, cap);
 }
 
+/* ---- sketch by read (dist --byread) --------------------------------------------------------- */
+/* reads2mco (iseq2comem.c:78-186): the FASTA scanner of fasta2co without the per-genome table -- every k-mer that
+ * passes the .shuf filter is written, in stream order and as often as it occurs; a '>' anywhere starts the next read
+ * (:126-150).  ids/comps = the stream of (drtuple >> comp_bits, drtuple % comp_num) (:173-175);
+ * read_of[i] = the read entry i belongs to (0 = before the first '>'), from which the caller derives the per-component
+ * index files: cumulative counts over reads 0..n_reads, WITHOUT a leading zero (:177-183).
+ * *n_reads = number of '>' met.  Returns the number of entries or a negative KO_ERR_*. */
+long ko_reads2mco(ko_ctx *c, const unsigned char *text, size_t n, u32 *ids, uint8_t *comps, u32 *read_of, size_t cap,
+                  uint64_t *n_reads)
+{
+    const ko_params *p = &c->p;
+    if (n == 0)
+        return KO_ERR_EMPTY; /* :104 */
+    u64 fwd = 0, rev = 0, run = 1, readn = 0;
+    size_t w = 0;
+    for (size_t i = 0; i < n; i++) {
+        unsigned char ch = text[i];
+        int b = base_code(ch);
+        if (b >= 0) { /* :117-122 */
+            fwd = ((fwd << 2) | (u64)b) & p->tupmask;
+            rev = (rev >> 2) + (((u64)b ^ 3ULL) << p->rc_shift);
+            run++;
+        } else if (ch == '\n' || ch == '\r') { /* :123 */
+            continue;
+        } else if (ch == '>') { /* :125-151: next read, skip the header line */
+            readn++;
+            while (i < n && text[i] != '\n')
+                i++;
+            if (i >= n)
+                return KO_ERR_HEADER; /* :146 */
+            run = 1;
+            continue;
+        } else { /* :124,:152-155 */
+            run = 1;
+            continue;
+        }
+        if (run <= (u64)p->TL) /* :156 */
+            continue;
+        u64 dr;
+        if (!reduce_kmer(c, fwd, rev, &dr)) /* :158-170 */
+            continue;
+        if (w >= cap)
+            return KO_ERR_BUFSZ;
+        ids[w] = (u32)(dr >> p->comp_bits); /* :173 */
+        if (comps)
+            comps[w] = (uint8_t)(dr % (u64)p->comp_num);
+        read_of[w] = (u32)readn; /* :172 */
+        w++;
+    }
+    if (n_reads)
+        *n_reads = readn;
+    return (long)w;
+}
+
 /* ---- FASTQ ------------------------------------------------------------------------------- */
 #define KO_FQ_LEN 20000 /* iseq2comem.c:274 */
 

@@ -73,6 +73,11 @@ long ko_fastq2co(ko_ctx *c, const unsigned char *text, size_t n, int Q, int M,
 long ko_fastq2koc(ko_ctx *c, const unsigned char *text, size_t n, uint32_t *ids, uint8_t *comps,
                   uint16_t *counts, size_t cap);
 
+/* FASTA by read (dist --byread): reads2mco (iseq2comem.c:78-186).  The stream of sampled k-mers in sequence order,
+ * repeats included; read_of[i] = number of '>' met before entry i; *n_reads = number of '>' in the text */
+long ko_reads2mco(ko_ctx *c, const unsigned char *text, size_t n, uint32_t *ids, uint8_t *comps,
+                  uint32_t *read_of, size_t cap, uint64_t *n_reads);
+
 /* same, reading a (possibly gzip'ed) file through zlib; is_fastq selects the scanner */
 long ko_sketch_file(ko_ctx *c, const char *path, int is_fastq, int uniq, int Q, int M,
                     uint32_t *ids, uint8_t *comps, size_t cap);

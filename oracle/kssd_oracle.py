@@ -57,6 +57,9 @@ def lib():
         L.ko_fasta2co.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.ko_fastq2koc.restype = C.c_long
         L.ko_fastq2koc.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ko_reads2mco.restype = C.c_long
+        L.ko_reads2mco.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_uint64)]
         L.ko_fastq2co.restype = C.c_long
         L.ko_fastq2co.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_size_t]
@@ -141,6 +144,27 @@ class Sketcher:
         if n < 0:
             raise OracleError(n)
         return self._ids[:n].copy(), counts[:n].copy()
+
+    def byread(self, text):
+        """dist --byread: (ids, comps, read_of, n_reads) -- the sampled k-mers in sequence order, repeats included"""
+        text = bytes(text)
+        read_of = np.zeros(self._cap, np.uint32)
+        nr = C.c_uint64(0)
+        n = lib().ko_reads2mco(self.h, text, len(text), self._ids.ctypes.data, self._comps.ctypes.data,
+                               read_of.ctypes.data, self._cap, C.byref(nr))
+        if n < 0:
+            raise OracleError(n)
+        return self._ids[:n].copy(), self._comps[:n].copy(), read_of[:n].copy(), int(nr.value)
+
+    def byread_files(self, text):
+        """what reads2mco leaves on disk: {component: (combco bytes as u32[], combco.index as i64[])}"""
+        ids, comps, read_of, nr = self.byread(text)
+        out = {}
+        for c in range(self.p.comp_num):
+            sel = comps == c
+            cnt = np.bincount(read_of[sel], minlength=nr + 1).astype(np.int64)
+            out[c] = (ids[sel].copy(), np.cumsum(cnt))
+        return out
 
     def file(self, path, is_fastq=False, uniq=False, Q=0, M=1):
         n = lib().ko_sketch_file(self.h, os.fsencode(path), int(is_fastq), int(uniq), Q, M, self._ids.ctypes.data,

@@ -27,6 +27,7 @@ SKETCH_UNIQ = 2
 SKETCH_NO_CAPACITY = 4
 SKETCH_FIRST_POS = 8
 SKETCH_COUNTS = 16
+SKETCH_BY_POS = 32
 PHASE_PREP, PHASE_SCAN, PHASE_EXACT, PHASE_FINISH = 0, 1, 2, 3
 
 OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -147,6 +148,10 @@ def host_lib():
         L.kssd_batch_add_fastq.argtypes = [vp, C.c_char_p, C.c_size_t, i32, C.POINTER(u64)]
         L.kssd_batch_add_reads.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(u64)]
         L.kssd_batch_add_file.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(u64)]
+        L.kssd_batch_add_fasta_reads.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(u64)]
+        L.kssd_byread_write.argtypes = [C.c_char_p, u32, i32, i32, C.c_char_p, u32, vp, vp, u64, vp, u64]
+        L.kssd_host_free.argtypes = [vp]
+        L.kssd_host_free.restype = None
         for f in ("packed", "mask", "chunk_off"):
             getattr(L, "kssd_batch_" + f).restype = vp
             getattr(L, "kssd_batch_" + f).argtypes = [vp]
@@ -301,6 +306,16 @@ class SketchSet:
                 for i, n in enumerate(self.names)}
 
 
+def byread_write(d, shuf, fname, ids, pos, read_start):
+    """combco.<c> / combco.index.<c> / cofiles.stat of `kssd dist --byread` for one file (reads2mco)"""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    rs = np.ascontiguousarray(read_start, dtype=np.uint64)
+    name = os.fsencode(fname)[:255].ljust(256, b"\0")
+    _hck(host_lib().kssd_byread_write(os.fsencode(d), shuf.id & 0xFFFFFFFF, shuf.k, shuf.drlevel, name, 1,
+                                      ids.ctypes.data, pos.ctypes.data, len(ids), rs.ctypes.data, len(rs)))
+
+
 def slot_order_pos(ids, first_pos, hashsize):
     """ids of one genome in the reference's file order, insertions replayed in sequence order"""
     a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
@@ -361,6 +376,17 @@ class Batch:
         n = C.c_uint64(0)
         _hck(host_lib().kssd_batch_add_reads(self.h, text, len(text), C.byref(n)))
         return n.value
+
+    def add_fasta_reads(self, text):
+        """one FASTA file as ONE genome for dist --byread; returns the cut points of its reads (uint64[number of '>'])"""
+        text = bytes(text)
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _hck(host_lib().kssd_batch_add_fasta_reads(self.h, text, len(text), C.byref(p), C.byref(n)))
+        try:
+            return (np.frombuffer((C.c_char * (8 * n.value)).from_address(p.value), dtype=np.uint64).copy()
+                    if n.value else np.zeros(0, np.uint64))
+        finally:
+            host_lib().kssd_host_free(p)
 
     def add_file(self, path, is_fastq=False, Q=0):
         n = C.c_uint64(0)

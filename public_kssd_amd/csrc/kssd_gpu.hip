@@ -576,6 +576,7 @@ struct ExactArgs {
     const unsigned long long *reg_off;
     uint32_t *cursor;
     void *regions;  // uint32_t[] or, in first-position mode, unsigned long long[]
+    uint32_t by_pos;  // KSSD_SKETCH_BY_POS: the 64-bit key is position << 32 | tuple, so that the sort leaves sequence order
     SketchStatus *status;
 };
 
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         if (mine) {
             const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
             const unsigned long long pos = (unsigned long long)at + rank_in(grp);
-            if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = KeyOps<K>::make(dr, gpos);
+            if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = x.by_pos ? KeyOps<K>::make(gpos, dr) : KeyOps<K>::make(dr, gpos);
         }
         todo &= ~grp;
     }
@@ -1005,8 +1006,18 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     c->last_launch_rc = KSSD_OK;
     c->last_n_genomes = n_genomes;
     if (min_occ < 1) min_occ = 1;
-    const bool with_pos = (flags & (KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS)) != 0;  // 64-bit keys, second output array
-    if ((flags & KSSD_SKETCH_FIRST_POS) && (flags & KSSD_SKETCH_COUNTS)) return KSSD_ERR_PARAM;  // one or the other per call
+    const bool with_pos = (flags & (KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS)) != 0;  // 64-bit keys, second output array
+    {
+        const uint32_t m = flags & (KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS);
+        if (m & (m - 1)) return KSSD_ERR_PARAM;  // one of them per call
+    }
+    if (flags & KSSD_SKETCH_BY_POS) {
+        // the keys are (position, tuple): every key is its own run, so the dedup kernels keep everything -- as long as no
+        // keep rule interferes (reads2mco has none: no table, no capacity limit, id 0 written like any other)
+        if (flags & KSSD_SKETCH_UNIQ) return KSSD_ERR_PARAM;
+        flags |= KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY;
+        min_occ = 1;
+    }
     if (with_pos && !c->d_out_pos) return KSSD_ERR_PARAM;  // kssd_gpu_sketch_set_pos_output first
     const uint64_t n_chunks = h_chunk_off[n_genomes];
     auto &pl = c->plan;
@@ -1150,6 +1161,7 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     x.lane_valid = c->d_lane_valid;
     x.n_slices = pl.n_slices;
     x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
+    x.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
     x.status = c->d_status;
     const dim3 grid((unsigned)((pl.cand_cap + 255) / 256), pl.n_slices);
     if (pl.with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), grid, dim3(256), 0, s, c->P, x);
@@ -1164,8 +1176,11 @@ static int phase_finish(kssd_gpu_ctx *c, hipStream_t s)
     if (pl.n_genomes == 0) return KSSD_OK;
     uint32_t flags = pl.flags;
     if (c->region_factor > 2.0) flags |= SKETCH_TRACK_FILL;
+    // by-position keys carry the position in the upper half: the gather's "id" is the position, its "position" the tuple
+    uint32_t *ids_to = (flags & KSSD_SKETCH_BY_POS) ? c->d_out_pos : pl.d_out_ids;
+    uint32_t *pos_to = (flags & KSSD_SKETCH_BY_POS) ? pl.d_out_ids : c->d_out_pos;
     int rc = pl.with_pos ? finish_sketch<unsigned long long>(c, pl.n_genomes, flags, pl.min_occ, pl.big_min, pl.max_cap, pl.max_big,
-                                                             pl.d_out_off, pl.d_out_ids, c->d_out_pos, pl.out_cap, s)
+                                                             pl.d_out_off, ids_to, pos_to, pl.out_cap, s)
                          : finish_sketch<uint32_t>(c, pl.n_genomes, flags, pl.min_occ, pl.big_min, pl.max_cap, pl.max_big, pl.d_out_off,
                                                    pl.d_out_ids, nullptr, pl.out_cap, s);
     if (rc != KSSD_OK) return rc;
@@ -1290,8 +1305,8 @@ static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint
         BCK(hipMemcpy(d_p, packed, (size_t)n_chunks * KSSD_CHUNK_WORDS * 4, hipMemcpyHostToDevice));
         BCK(hipMemcpy(d_m, mask, (size_t)n_chunks * KSSD_CHUNK_MASKW * 4, hipMemcpyHostToDevice));
     }
-    if (out_pos && !(flags & KSSD_SKETCH_COUNTS)) flags |= KSSD_SKETCH_FIRST_POS;
-    if (!out_pos) flags &= ~(KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS);
+    if (out_pos && !(flags & (KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS))) flags |= KSSD_SKETCH_FIRST_POS;
+    if (!out_pos) flags &= ~(KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS);
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     uint64_t out_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * rate * 1.5) + 1024;
     uint64_t total = 0;

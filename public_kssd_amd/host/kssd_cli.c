@@ -294,11 +294,63 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     kssd_batch_clear(b);
 }
 
+/* dist --byread (run_stageI command_dist.c:267-273 + reads2mco iseq2comem.c:78-186): every input file is one genome on
+ * the device; KSSD_SKETCH_BY_POS returns its whole k-mer stream with positions, the tokeniser's cut points turn the
+ * positions into reads.  Like the reference, every file overwrites combco.* of the one before.  (One deviation: a
+ * gzip'ed input is unpacked; the reference opens --byread inputs without zcat and scans the compressed bytes.) */
+static void sketch_files_byread(const dist_opt *o, filelist *fl, const char *outdir)
+{
+    kssd_shuf shuf;
+    load_shuf(o, &shuf);
+    kssd_derived d;
+    if (kssd_derive(&d, shuf.k, shuf.subk, shuf.drlevel))
+        die(EINVAL, "get_hashsz(): primer_ind out of range(0 ~ 24): this might caused by too small or too large k (k=%d, level=%d)", shuf.k, shuf.drlevel);
+    printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
+    kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
+    gck(kssd_gpu_create(&g_ctx, &hdr, shuf.table, o->device), "kssd_gpu_create");
+    kssd_shuf_release(&shuf);
+    kssd_batch *b = kssd_batch_create();
+    for (int i = 0; i < fl->n; i++) {
+        printf("decomposing %s by reads\n", fl->path[i]);
+        unsigned char *txt = NULL;
+        size_t len = 0;
+        int rc = kssd_slurp(fl->path[i], &txt, &len);
+        if (rc) die(EIO, "reads2mco():%s: %s", fl->path[i], kssd_host_strerror(rc));
+        uint64_t *cuts = NULL, n_reads = 0;
+        rc = kssd_batch_add_fasta_reads(b, txt, len, &cuts, &n_reads);
+        free(txt);
+        if (rc == KSSD_HOST_ERR_EMPTY) die(EIO, "reads2mco():eof or fread error file=%s", fl->path[i]);
+        if (rc == KSSD_HOST_ERR_HEADER) die(EIO, "fasta2co(): can not find seqences head start from '>' 0");
+        if (rc) die(EIO, "%s: %s", fl->path[i], kssd_host_strerror(rc));
+        uint64_t *off = NULL;
+        uint32_t *ids = NULL, *pos = NULL;
+        int64_t bad = -1;
+        gck(kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), 1, KSSD_SKETCH_BY_POS,
+                                      1u, &off, &ids, &pos, &bad),
+            "sketch (by read)");
+        rc = kssd_byread_write(outdir, (uint32_t)hdr.id, hdr.k, hdr.drlevel, (const char (*)[KSSD_PATHLEN])fl->path, (uint32_t)fl->n, ids,
+                               pos, off[1], cuts, n_reads);
+        if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
+        kssd_gpu_free(off);
+        kssd_gpu_free(ids);
+        kssd_gpu_free(pos);
+        kssd_host_free(cuts);
+        kssd_batch_clear(b);
+        printf("decomposing %s by reads is complete!\n", fl->path[i]);
+    }
+    kssd_batch_destroy(b);
+    kssd_gpu_destroy(g_ctx);
+    g_ctx = NULL;
+}
+
 static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
 {
     if (fl->n == 0) die(EINVAL, "no valid input .fas/.fq file");
-    if (o->byread || o->pipecmd[0])
-        die(ENOTSUP, "--byread / --pipecmd are outside the GPU hot path of this build (SURVEY.md section 8f)");
+    if (o->pipecmd[0]) die(ENOTSUP, "--pipecmd is outside the GPU hot path of this build (SURVEY.md section 8f)");
+    if (o->byread) {
+        sketch_files_byread(o, fl, outdir);
+        return;
+    }
     int abundance = o->abundance;
     if (abundance) /* command_dist.c:297-301: one non-FASTQ input closes the mode (here: for the whole run, up front) */
         for (int i = 0; i < fl->n; i++)
@@ -735,14 +787,14 @@ static int cmd_reverse(int argc, char **argv)
 {
     char shuf_path[4096] = "", outdir[4096] = ".";
     static struct option lo[] = {{"shufFile", 1, 0, 'L'}, {"outdir", 1, 0, 'o'}, {"threads", 1, 0, 'p'}, {"byreads", 0, 0, 'b'}, {0, 0, 0, 0}};
-    int c;
+    int c, byreads = 0;
     optind = 1;
     while ((c = getopt_long(argc, argv, "L:o:p:b", lo, NULL)) != -1) {
         switch (c) {
         case 'L': snprintf(shuf_path, sizeof shuf_path, "%s", optarg); break;
         case 'o': snprintf(outdir, sizeof outdir, "%s", optarg); break;
         case 'p': break;
-        case 'b': die(ENOTSUP, "reverse --byreads belongs to the --byread sketches, which are outside this build (SURVEY.md section 8f)");
+        case 'b': byreads = 1; break;
         default: die(EINVAL, "reverse: unknown option");
         }
     }
@@ -751,6 +803,12 @@ static int cmd_reverse(int argc, char **argv)
     kssd_shuf sh;
     int rc = kssd_shuf_read(&sh, shuf_path);
     if (rc) die(EIO, "read_dim_shuffle_file(): %s: %s", shuf_path, kssd_host_strerror(rc));
+    if (byreads) { /* co_rvs2kmer_byreads prints to stdout (command_reverse.c:201-212) */
+        rc = kssd_reverse_byreads(&sh, argv[optind], stdout);
+        if (rc) die(EIO, "co_rvs2kmer_btreads(): %s", kssd_host_strerror(rc));
+        kssd_shuf_release(&sh);
+        return 0;
+    }
     mkdir(outdir, 0777);
     rc = kssd_reverse_dir(&sh, argv[optind], outdir);
     if (rc) die(EIO, "co_reverse2kmer(): %s", kssd_host_strerror(rc));

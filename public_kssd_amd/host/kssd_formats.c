@@ -315,6 +315,53 @@ int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hash
     return write_stat(s, dir, 0);
 }
 
+int kssd_byread_write(const char *dir, uint32_t shuf_id, int k, int drlevel, const char (*names)[KSSD_PATHLEN], uint32_t n_files,
+                      const uint32_t *ids, const uint32_t *pos, uint64_t n, const uint64_t *read_start, uint64_t n_reads)
+{
+    mkdir(dir, 0777);
+    const int extra = k - drlevel - 7; /* COMPONENT_SZ, iseq2comem.c:63-64,80 */
+    const int cb = extra > 0 ? 4 * extra : 0;
+    const int comp_num = extra > 0 ? 1 << cb : 1;
+    const uint32_t cmask = (uint32_t)comp_num - 1u;
+    /* read of every entry: number of cut points <= its position (both sequences ascend) */
+    int64_t *cum = malloc(((size_t)n_reads + 1) * sizeof(int64_t));
+    if (!cum) return KSSD_HOST_ERR_NOMEM;
+    char path[4096];
+    for (int c = 0; c < comp_num; c++) {
+        snprintf(path, sizeof path, "%s/combco.%d", dir, c);
+        FILE *f = fopen(path, "wb");
+        if (!f) { free(cum); return KSSD_HOST_ERR_IO; }
+        memset(cum, 0, ((size_t)n_reads + 1) * sizeof(int64_t));
+        uint64_t r = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            while (r < n_reads && read_start[r] <= pos[i]) r++;
+            if ((ids[i] & cmask) != (uint32_t)c) continue; /* drtuple % component_num, iseq2comem.c:172-175 */
+            const uint32_t id = ids[i] >> cb;
+            fwrite(&id, 4, 1, f);
+            cum[r]++;
+        }
+        if (fclose(f) != 0) { free(cum); return KSSD_HOST_ERR_IO; }
+        for (uint64_t j = 1; j <= n_reads; j++) cum[j] += cum[j - 1]; /* iseq2comem.c:177-183: no leading zero */
+        snprintf(path, sizeof path, "%s/combco.index.%d", dir, c);
+        f = fopen(path, "wb");
+        if (!f) { free(cum); return KSSD_HOST_ERR_IO; }
+        fwrite(cum, sizeof(int64_t), (size_t)n_reads + 1, f);
+        if (fclose(f) != 0) { free(cum); return KSSD_HOST_ERR_IO; }
+    }
+    free(cum);
+    /* cofiles.stat as run_stageI writes it behind reads2mco: every input file listed, nothing counted
+     * (command_dist.c:360-378) */
+    kssd_sketchset s;
+    memset(&s, 0, sizeof s);
+    uint64_t *off = calloc((size_t)n_files + 1, sizeof(uint64_t));
+    if (!off) return KSSD_HOST_ERR_NOMEM;
+    s.shuf_id = shuf_id; s.kmerlen = 2 * k; s.dim_rd_len = 2 * drlevel; s.comp_num = comp_num; s.n = n_files;
+    s.off = off; s.names = (char (*)[KSSD_PATHLEN])names;
+    const int rc = write_stat(&s, dir, 0);
+    free(off);
+    return rc;
+}
+
 static void *slurp_file(const char *path, size_t *len)
 {
     FILE *f = fopen(path, "rb");
@@ -646,5 +693,63 @@ int kssd_reverse_dir(const kssd_shuf *sh, const char *sketch_dir, const char *ou
         if (fclose(f) != 0) rc = KSSD_HOST_ERR_IO;
     }
     kssd_sketchset_release(&s);
+    return rc;
+}
+
+/* co_rvs2kmer_byreads (command_reverse.c:147-218): the reads of a --byread sketch directory as text on `out`.
+ * ">read n" for n = 1..readn (readn = entries of combco.index.0 minus one), under each the k-mers of component 0, 1, ...
+ * The reference takes the COUNT of read n from index[n] - index[n-1] but reads the ids sequentially from the start of
+ * combco.<c>: k-mers in front of the first header (index[0] of them) shift every read's list by that many entries.
+ * Restated as it behaves. */
+int kssd_reverse_byreads(const kssd_shuf *sh, const char *sketch_dir, FILE *out)
+{
+    uint32_t accepted[4096];
+    int rc = kssd_shuf_accepted(sh, accepted);
+    if (rc) return rc;
+    const int extra = sh->k - sh->drlevel - 7;
+    const int cb = extra > 0 ? 4 * extra : 0;
+    char path[4096];
+    snprintf(path, sizeof path, "%s/cofiles.stat", sketch_dir);
+    size_t hl = 0;
+    unsigned char *hdr = slurp_file(path, &hl);
+    if (!hdr || hl < 32) { free(hdr); return KSSD_HOST_ERR_IO; }
+    int32_t comp_num;
+    memcpy(&comp_num, hdr + 16, 4);
+    free(hdr);
+    if (comp_num < 1 || comp_num > 65536) return KSSD_HOST_ERR_FORMAT;
+    uint64_t **idx = calloc((size_t)comp_num, sizeof *idx);
+    uint32_t **ids = calloc((size_t)comp_num, sizeof *ids);
+    size_t *n_ids = calloc((size_t)comp_num, sizeof *n_ids), *cursor = calloc((size_t)comp_num, sizeof *cursor);
+    uint64_t readn = 0;
+    rc = KSSD_HOST_OK;
+    for (int j = 0; j < comp_num && rc == KSSD_HOST_OK; j++) {
+        size_t il = 0, xl = 0;
+        snprintf(path, sizeof path, "%s/combco.index.%d", sketch_dir, j);
+        idx[j] = slurp_file(path, &xl);
+        snprintf(path, sizeof path, "%s/combco.%d", sketch_dir, j);
+        ids[j] = slurp_file(path, &il);
+        if (!idx[j] || !ids[j] || xl < 8) { rc = KSSD_HOST_ERR_IO; break; }
+        if (j == 0) readn = xl / 8 - 1; /* :184-185 */
+        else if (xl / 8 - 1 < readn) rc = KSSD_HOST_ERR_FORMAT;
+        n_ids[j] = il / 4;
+    }
+    const int TL = 2 * sh->k;
+    char kstring[64];
+    kstring[TL] = '\0';
+    for (uint64_t n = 0; n < readn && rc == KSSD_HOST_OK; n++) {
+        fprintf(out, ">read %llu\n", (unsigned long long)(n + 1));
+        for (int j = 0; j < comp_num; j++) {
+            const uint64_t cnt = idx[j][n + 1] - idx[j][n];
+            for (uint64_t t = 0; t < cnt; t++) {
+                if (cursor[j] >= n_ids[j]) break; /* the reference's fread fails silently there and repeats the last id */
+                const uint32_t full = (ids[j][cursor[j]++] << cb) | (uint32_t)j;
+                uint64_t u = kssd_reverse_id(full, sh->k, sh->subk, sh->drlevel, accepted);
+                for (int b = 0; b < TL; b++) { kstring[TL - b - 1] = "ACGT"[u & 3u]; u >>= 2; }
+                fprintf(out, "%s\n", kstring);
+            }
+        }
+    }
+    for (int j = 0; j < comp_num; j++) { free(idx[j]); free(ids[j]); }
+    free(idx); free(ids); free(n_ids); free(cursor);
     return rc;
 }

@@ -15,6 +15,8 @@
 #define CHUNK_MASKW 128u
 #define SLACK_WORDS 8u
 
+void kssd_host_free(void *p) { free(p); }
+
 const char *kssd_host_strerror(int code)
 {
     switch (code) {
@@ -330,6 +332,51 @@ int kssd_batch_add_fasta(kssd_batch *b, const unsigned char *text, size_t n)
         }
     }
     gw_finish(&w);
+    return KSSD_HOST_OK;
+}
+
+/* The same scanner for dist --byread (reads2mco, iseq2comem.c:110-156): one genome per file, and for every '>' the
+ * position (inside the genome) the next base will be written at.  A k-mer belongs to read r (0 = before the first
+ * '>') iff starts[r-1] <= its position < starts[r]: every k-mer met after a header lies entirely behind the break
+ * position the header leaves, every earlier one entirely before it. */
+int kssd_batch_add_fasta_reads(kssd_batch *b, const unsigned char *text, size_t n, uint64_t **read_start, uint64_t *n_reads)
+{
+    if (!fa_class_ready) fa_class_init();
+    if (!read_start || !n_reads) return KSSD_HOST_ERR_PARAM;
+    *read_start = NULL;
+    *n_reads = 0;
+    if (n == 0) return KSSD_HOST_ERR_EMPTY;
+    int rc = batch_begin(b);
+    if (rc) return rc;
+    size_t cap = 1024, nr = 0;
+    uint64_t *st = malloc(cap * sizeof *st);
+    if (!st) return KSSD_HOST_ERR_NOMEM;
+    gwriter w;
+    gw_start(&w, b);
+    for (size_t i = 0; i < n; i++) {
+        unsigned cls = fa_class[text[i]];
+        if (cls < 4) {
+            if ((rc = gw_base(&w, cls)) != 0) { gw_abort(&w); free(st); return rc; }
+        } else if (cls == C_SKIP) {
+        } else if (cls == C_HEADER) {
+            const unsigned char *nl = memchr(text + i, '\n', n - i);
+            if (!nl) { gw_abort(&w); free(st); return KSSD_HOST_ERR_HEADER; }
+            i = (size_t)(nl - text);
+            w.pending_break = 1;
+            if (nr == cap) {
+                cap *= 2;
+                uint64_t *q = realloc(st, cap * sizeof *st);
+                if (!q) { gw_abort(&w); free(st); return KSSD_HOST_ERR_NOMEM; }
+                st = q;
+            }
+            st[nr++] = w.p + (w.p ? 1 : 0); /* gw_base puts one invalid position in front of the next base */
+        } else {
+            w.pending_break = 1;
+        }
+    }
+    gw_finish(&w);
+    *read_start = st;
+    *n_reads = nr;
     return KSSD_HOST_OK;
 }
 

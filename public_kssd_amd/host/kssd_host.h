@@ -25,6 +25,7 @@ extern "C" {
 #define KSSD_PATHLEN 256 /* PATHLEN, global_basic.h:40: name records in cofiles.stat */
 
 const char *kssd_host_strerror(int code);
+void kssd_host_free(void *p); /* for the arrays this library mallocs for its caller */
 
 /* ---- .shuf (command_shuffle.c:131-207) ------------------------------------------------------------ */
 typedef struct kssd_shuf {
@@ -46,6 +47,10 @@ void kssd_batch_destroy(kssd_batch *b);
 void kssd_batch_clear(kssd_batch *b);
 /* append one genome; tokenisation rules of fasta2co (iseq2comem.c:213-242) */
 int kssd_batch_add_fasta(kssd_batch *b, const unsigned char *text, size_t n);
+/* append one FASTA file as ONE genome for dist --byread (reads2mco, iseq2comem.c:78-186): same tokenisation, and
+ * *read_start (malloc'd, n_reads entries, caller frees) receives for every '>' the position inside the genome at which
+ * the bases behind that header begin -- the cut points of the k-mer stream KSSD_SKETCH_BY_POS returns */
+int kssd_batch_add_fasta_reads(kssd_batch *b, const unsigned char *text, size_t n, uint64_t **read_start, uint64_t *n_reads);
 /* append one read set; framing and quality rule of fastq2co (iseq2comem.c:289-321);
  * *n_lines receives the reference's "reads detected" figure (4 x records) */
 int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int Q, uint64_t *n_lines);
@@ -109,6 +114,15 @@ int kssd_counts_follow(const uint32_t *ids_before, const uint16_t *counts_before
 /* write cofiles.stat + combco.<c> + combco.index.<c> (+ combco.<c>.a when koc) like run_stageI (command_dist.c:314-378).
  * slot_order != 0 applies kssd_slot_order per genome (ids are modified in place). */
 int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hashsize, int slot_order);
+/* what reads2mco leaves in a sketch directory (iseq2comem.c:78-186, run_stageI command_dist.c:267-273,360-378) for ONE
+ * input file (with several, every file overwrites the one before): combco.<c> = the k-mer stream of component c
+ * (ids[i] % comp_num == c, stored as ids[i] >> comp_bits), combco.index.<c> = cumulative counts over the reads
+ * 0..n_reads as int64 WITHOUT a leading zero, cofiles.stat naming all n_files inputs with all_ctx_ct = 0 and zero
+ * counts (the reference writes uninitialised memory there).
+ * ids/pos = the stream KSSD_SKETCH_BY_POS returned for the file's genome (FULL tuples, positions ascending),
+ * read_start = the cut points from kssd_batch_add_fasta_reads. */
+int kssd_byread_write(const char *dir, uint32_t shuf_id, int k, int drlevel, const char (*names)[KSSD_PATHLEN], uint32_t n_files,
+                      const uint32_t *ids, const uint32_t *pos, uint64_t n, const uint64_t *read_start, uint64_t n_reads);
 /* read them back (all components folded into full tuples) */
 int kssd_sketchset_read(kssd_sketchset *s, const char *dir);
 /* mcofiles.stat + mco.index.<c> + mco.<c> from a sketch set: combco2mco + run_stageII
@@ -129,6 +143,10 @@ int kssd_shuf_accepted(const kssd_shuf *s, uint32_t *accepted /*4096*/);
 /* write one text file per genome of a sketch directory (named like the genome's file) with one 2k-mer per line, in the
  * order of the ids in combco.<c>, component after component -- co_reverse2kmer (command_reverse.c:219-310) */
 int kssd_reverse_dir(const kssd_shuf *s, const char *sketch_dir, const char *outdir);
+
+/* kssd reverse --byreads (co_rvs2kmer_byreads, command_reverse.c:147-218): a --byread sketch directory as text,
+ * ">read n" followed by the 2k-mers of the read, on `out` */
+int kssd_reverse_byreads(const kssd_shuf *s, const char *sketch_dir, FILE *out);
 
 /* ---- distance report (dist_print_nobin + output_ctrl, command_dist.c:1161-1287) ------------------------- */
 typedef struct kssd_print_opt {

@@ -10,7 +10,8 @@
 
 template <int SUBK, int GW>
 static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mask, uint64_t n_chunks, const uint32_t *gid,
-                const uint8_t *T1, const uint32_t *bloom, const KssdG *G, std::vector<uint64_t> &out, uint64_t *n_cand)
+                const uint8_t *T1, const uint32_t *bloom, const KssdG *G, std::vector<uint64_t> &out, uint64_t *n_cand,
+                std::vector<uint64_t> *where = nullptr)
 {
     const int64_t total = (int64_t)n_chunks * KSSD_CHUNK;
     for (uint64_t c = 0; c < n_chunks; c++) {
@@ -35,7 +36,10 @@ static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mas
                 if ((bloom[kssd_bloom_word(h)] & bits) != bits) continue;
                 n_cand[1]++;
                 uint32_t dr;
-                if (kssd_stage2(P, cbeg + lane * 64 + b, lo, hi, packed, mask, G, dr)) out.push_back(((uint64_t)gid[c] << 32) | dr);
+                if (kssd_stage2(P, cbeg + lane * 64 + b, lo, hi, packed, mask, G, dr)) {
+                    out.push_back(((uint64_t)gid[c] << 32) | dr);
+                    if (where) where->push_back((uint64_t)(cbeg + lane * 64 + b));  // position of the sub-context start
+                }
             }
         }
     }
@@ -59,10 +63,31 @@ static void run_all(const KssdParams &P, const uint32_t *packed, const uint32_t 
     }
 }
 
+static long emu_impl(int k, int subk, int drlevel, const int32_t *table, const uint32_t *packed, const uint32_t *mask,
+                     uint64_t n_chunks, const uint32_t *chunk_gid, int brute, uint64_t *out, uint64_t cap,
+                     uint64_t *n_cand, int gw, uint64_t *where_out);
+
 extern "C" long emu_sketch(int k, int subk, int drlevel, const int32_t *table, const uint32_t *packed, const uint32_t *mask,
                            uint64_t n_chunks, const uint32_t *chunk_gid, int brute, uint64_t *out, uint64_t cap,
                            uint64_t *n_cand, int gw)
 {
+    return emu_impl(k, subk, drlevel, table, packed, mask, n_chunks, chunk_gid, brute, out, cap, n_cand, gw, nullptr);
+}
+
+// the same, and where[i] = batch position (of the sub-context start) entry i was sampled at; entries come in position order
+extern "C" long emu_sketch_where(int k, int subk, int drlevel, const int32_t *table, const uint32_t *packed, const uint32_t *mask,
+                                 uint64_t n_chunks, const uint32_t *chunk_gid, uint64_t *out, uint64_t *where, uint64_t cap)
+{
+    uint64_t n_cand[2];
+    return emu_impl(k, subk, drlevel, table, packed, mask, n_chunks, chunk_gid, 0, out, cap, n_cand, 0, where);
+}
+
+static long emu_impl(int k, int subk, int drlevel, const int32_t *table, const uint32_t *packed, const uint32_t *mask,
+                     uint64_t n_chunks, const uint32_t *chunk_gid, int brute, uint64_t *out, uint64_t cap,
+                     uint64_t *n_cand, int gw, uint64_t *where_out)
+{
+    std::vector<uint64_t> where;
+    std::vector<uint64_t> *wp = where_out ? &where : nullptr;
     KssdParams P;
     if (kssd_params_init(&P, k, subk, drlevel) != 0) return -1;
     std::vector<uint32_t> acc;
@@ -78,8 +103,8 @@ extern "C" long emu_sketch(int k, int subk, int drlevel, const int32_t *table, c
     else {
 #define RUN(S)                                                                                           \
     case S:                                                                                              \
-        if (gw == 4) run<S, 4>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand); \
-        else if (gw == 5) run<S, 5>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand); \
+        if (gw == 4) run<S, 4>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand, wp); \
+        else if (gw == 5) run<S, 5>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand, wp); \
         else return -5;                                                                                  \
         break;
         switch (subk) {
@@ -90,5 +115,6 @@ extern "C" long emu_sketch(int k, int subk, int drlevel, const int32_t *table, c
     }
     if (res.size() > cap) return -4;
     memcpy(out, res.data(), res.size() * 8);
+    if (where_out) memcpy(where_out, where.data(), where.size() * 8);
     return (long)res.size();
 }

@@ -29,6 +29,8 @@ def emu():
     L.emu_sketch.restype = C.c_long
     L.emu_sketch.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
                                                                   C.c_uint64, C.c_void_p, C.c_int]
+    L.emu_sketch_where.restype = C.c_long
+    L.emu_sketch_where.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     return L
 
 
@@ -81,3 +83,42 @@ def test_stage1_stage2_match_oracle(emu, k, subk, dr, gw):
         # of the exact pattern leaves the ~0.05 % that are in S plus ~2 % of the rest
         assert 0.006 < ncand[0] / npos < 0.010
         assert 0.0004 < ncand[1] / npos < 0.0009
+
+
+def test_byread_host_side_against_the_reference_goldens(emu, tmp_path):
+    """dist --byread without a GPU: the tokeniser's cut points (kssd_batch_add_fasta_reads) and the file writer
+    (kssd_byread_write), fed with the k-mer stream the CPU emulation of the device arithmetic samples in position order,
+    leave the files the reference binary wrote (tests/golden/byread.npz), 1 and 16 components"""
+    import gzip
+    import json
+    G = os.path.join(HERE, "golden")
+    B = np.load(os.path.join(G, "byread.npz"))
+    seed = json.load(open(os.path.join(G, "golden.json")))["seed"]
+    inputs = {"byread.fa": gzip.open(os.path.join(G, "byread.fa.gz"), "rb").read(),
+              "edge.fa": open(os.path.join(G, "qry_fa", "edge.fa"), "rb").read()}
+    for tag, (k, s, l) in {"L3K10": (10, 6, 3), "L3K11": (11, 6, 3)}.items():
+        shuf = K.Shuf.generate(k, s, l, seed=seed)
+        for name, text in inputs.items():
+            b = K.Batch()
+            cuts = b.add_fasta_reads(text)
+            assert len(cuts) == text.count(b">") and np.all(np.diff(cuts.astype(np.int64)) >= 0)
+            p, m = b.packed(), b.mask()
+            gid = np.zeros(b.n_chunks, np.uint32)
+            out = np.zeros(b.n_chunks * 4096 + 16, np.uint64)
+            where = np.zeros_like(out)
+            n = emu.emu_sketch_where(k, s, l, shuf.table.ctypes.data, p.ctypes.data, m.ctypes.data, b.n_chunks,
+                                     gid.ctypes.data, out.ctypes.data, where.ctypes.data, len(out))
+            assert n >= 0
+            ids, pos = (out[:n] & np.uint64(0xFFFFFFFF)).astype(np.uint32), where[:n].astype(np.uint32)
+            assert np.all(np.diff(pos.astype(np.int64)) > 0)
+            d = str(tmp_path / (tag + name))
+            K.byread_write(d, shuf, name, ids, pos, cuts)
+            ncomp = 16 if k == 11 else 1
+            for c in range(ncomp):
+                assert np.array_equal(np.fromfile(os.path.join(d, "combco.%d" % c), np.uint32), B["%s/%s/co.%d" % (tag, name, c)])
+                assert np.array_equal(np.fromfile(os.path.join(d, "combco.index.%d" % c), np.int64), B["%s/%s/idx.%d" % (tag, name, c)])
+            assert not os.path.exists(os.path.join(d, "combco.%d" % ncomp))
+            stat = np.fromfile(os.path.join(d, "cofiles.stat"), np.uint8)
+            keep = np.r_[4:5, 8:32]  # shuf id aside (the goldens' shuffle carries the reference's own random id)
+            assert np.array_equal(stat[:32][keep], B["%s/%s/stat" % (tag, name)][keep])
+            assert len(stat) == 32 + 4 + 256 and bytes(stat[36:36 + len(name)]) == name.encode()

@@ -94,6 +94,29 @@ def golden_sets():
     return ref, qry
 
 
+BYREAD_SHUFS = {"L3K10": (10, 6, 3), "L3K11": (11, 6, 3)}
+
+
+def byread_inputs():
+    return {"byread.fa": read_any(os.path.join(G, "byread.fa.gz")), "edge.fa": read_any(os.path.join(G, "qry_fa", "edge.fa"))}
+
+
+def test_oracle_byread_stream_equals_reference():
+    """dist --byread (reads2mco, iseq2comem.c:78-186): the k-mer stream per component and the cumulative per-read index,
+    as the reference binary wrote them (tests/golden/make_golden_byread.py), 1 and 16 components"""
+    B = np.load(os.path.join(G, "byread.npz"))
+    for tag, (k, s, l) in BYREAD_SHUFS.items():
+        sh = K.Shuf.generate(k, s, l, seed=META["seed"])
+        sk = ko.Sketcher(sh.table, k, s, l)
+        for name, text in byread_inputs().items():
+            files = sk.byread_files(text)
+            assert len(files) == (16 if k == 11 else 1)
+            for c, (ids, idx) in files.items():
+                assert np.array_equal(ids, B["%s/%s/co.%d" % (tag, name, c)]), (tag, name, c)
+                assert np.array_equal(idx, B["%s/%s/idx.%d" % (tag, name, c)]), (tag, name, c)
+    assert len(B["L3K10/byread.fa/co.0"]) > 80 and len(B["L3K10/byread.fa/idx.0"]) == 98
+
+
 def test_oracle_shared_counts_equal_reference():
     ref, qry = golden_sets()
     assert np.array_equal(ref.off[1:] - ref.off[:-1], SH["ref_sz"]) and np.array_equal(qry.off[1:] - qry.off[:-1], SH["qry_sz"])

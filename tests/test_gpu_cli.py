@@ -111,6 +111,33 @@ def test_abundance_sketch_files_are_the_references(tmp_path):
     assert open(os.path.join(d, "d_koc", "distance.out")).read() == open(os.path.join(d, "d_plain", "distance.out")).read()
 
 
+def test_byread_sketch_files_are_the_references(tmp_path):
+    """dist --byread: combco.<c> and combco.index.<c> byte for byte what the reference binary wrote (tests/golden/
+    byread.npz), 1 and 16 components; with two inputs the second overwrites the first, as in the reference"""
+    import gzip
+    d = str(tmp_path)
+    B = np.load(os.path.join(G, "byread.npz"))
+    open(os.path.join(d, "byread.fa"), "wb").write(gzip.open(os.path.join(G, "byread.fa.gz"), "rb").read())
+    edge = os.path.join(G, "qry_fa", "edge.fa")
+    for tag, k in (("L3K10", 10), ("L3K11", 11)):
+        run(["shuffle", "-k", k, "-s", 6, "-l", 3, "-o", tag, "--seed", META["seed"]], d)
+        for name, path in (("byread.fa", "byread.fa"), ("edge.fa", edge)):
+            out = run(["dist", "--byread", "-L", tag + ".shuf", "-o", "o_" + tag + name, path], d)
+            assert "decomposing %s by reads is complete!" % path in out
+            o = os.path.join(d, "o_" + tag + name)
+            ncomp = 16 if k == 11 else 1
+            for c in range(ncomp):
+                assert np.array_equal(np.fromfile(os.path.join(o, "combco.%d" % c), np.uint32), B["%s/%s/co.%d" % (tag, name, c)])
+                assert np.array_equal(np.fromfile(os.path.join(o, "combco.index.%d" % c), np.int64), B["%s/%s/idx.%d" % (tag, name, c)])
+            stat = np.fromfile(os.path.join(o, "cofiles.stat"), np.uint8)
+            keep = np.r_[0:5, 8:32]
+            assert np.array_equal(stat[:32][keep], B["%s/%s/stat" % (tag, name)][keep])
+    # gzip'ed input is unpacked (documented deviation); two inputs: the last one's stream stays, both are named
+    run(["dist", "--byread", "-L", "L3K10.shuf", "-o", "two", edge, os.path.join(G, "byread.fa.gz")], d)
+    assert np.array_equal(np.fromfile(os.path.join(d, "two", "combco.0"), np.uint32), B["L3K10/byread.fa/co.0"])
+    assert os.path.getsize(os.path.join(d, "two", "cofiles.stat")) == 32 + 2 * 4 + 2 * 256
+
+
 def test_errors_match_the_reference(tmp_path):
     d = str(tmp_path)
     r = subprocess.run([BIN, "shuffle", "-k", "10", "-s", "8", "-l", "5", "-o", "x"], cwd=d, stderr=subprocess.PIPE)

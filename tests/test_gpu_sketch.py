@@ -141,6 +141,59 @@ def test_occurrence_counts_of_the_abundance_sketches(gpu_ctx, shuf_l3k10, monkey
     monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
 
 
+def _byread_text(rng, n_reads, max_len, repeat_every=0):
+    out = [fasta_text(rng.integers(0, 4, 900, dtype=np.uint8))[len(b">seq\n"):]]  # bases in front of the first header: read 0
+    keep = []
+    for i in range(n_reads):
+        r = rng.integers(0, 4, int(rng.integers(5, max_len)), dtype=np.uint8)
+        if repeat_every and i % repeat_every == repeat_every - 1:
+            r = keep[int(rng.integers(0, len(keep)))]  # a repeated read: its k-mers come again
+        keep.append(r)
+        out.append(fasta_text(r, name=b"read%d" % i, n_mask=(rng.random(len(r)) < 2e-4)))
+        if i % 17 == 3:
+            out.append(b">no bases\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("k,subk,dr", [(10, 6, 3), (11, 6, 3), (8, 5, 2)])
+def test_by_position_stream_of_the_byread_sketches(k, subk, dr, monkeypatch):
+    """KSSD_SKETCH_BY_POS: every sampled k-mer in sequence order, repeats and id 0 included, with its position; cut at the
+    tokeniser's read starts it is the stream reads2mco writes (dist --byread, iseq2comem.c:78-186), per component file
+    and per-read index -- through the LDS sort and through the big-genome path; several genomes per call"""
+    shuf = K.Shuf.generate(k, subk, dr, seed=77)
+    sk = ko.Sketcher(shuf.table, k, subk, dr)
+    rng = np.random.default_rng(5 + k)
+    texts = [_byread_text(rng, 60, 40000, repeat_every=7), _byread_text(rng, 400, 300), b">only a header\n", b"ACGTNNNN\n>x\nAC\n"]
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        for big in (False, True):
+            if big:
+                monkeypatch.setenv("KSSD_DEV_BIG_MIN", "16")  # read per call
+            b = K.Batch()
+            cuts = [b.add_fasta_reads(t) for t in texts]
+            off, ids, pos = ctx.sketch_batch_pos(b, K.SKETCH_BY_POS)
+            n_total = 0
+            for g, t in enumerate(texts):
+                wi, wc, wr, nr = sk.byread(t)
+                lo, hi = int(off[g]), int(off[g + 1])
+                gi, gp = ids[lo:hi], pos[lo:hi]
+                assert nr == len(cuts[g]) == t.count(b">")
+                assert np.all(np.diff(gp.astype(np.int64)) > 0), "positions ascend strictly: one k-mer per position"
+                full = (wi.astype(np.uint64) << np.uint64(sk.p.comp_bits)) | wc.astype(np.uint64)
+                assert np.array_equal(gi.astype(np.uint64), full), (big, g, len(gi), len(full))
+                assert np.array_equal(np.searchsorted(cuts[g], gp, side="right"), wr), (big, g)
+                n_total += len(wi)
+            assert n_total > 150
+            assert len(np.unique(ids[:int(off[1])])) < int(off[1]), "the repeated reads must show up as repeated ids"
+        with pytest.raises(K.KssdError):  # one kind of second output per call
+            ctx.sketch_batch_pos(b, K.SKETCH_BY_POS | K.SKETCH_COUNTS)
+        with pytest.raises(K.KssdError):  # no keep rule may interfere
+            ctx.sketch_batch_pos(b, K.SKETCH_BY_POS | K.SKETCH_UNIQ)
+    finally:
+        monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
+        ctx.close()
+
+
 @pytest.mark.parametrize("k,subk,dr", [(8, 5, 2), (10, 7, 5), (9, 6, 3), (11, 6, 3), (12, 7, 4)])
 def test_other_shuffles(k, subk, dr):
     shuf = K.Shuf.generate(k, subk, dr, seed=77 + k)

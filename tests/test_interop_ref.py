@@ -136,6 +136,40 @@ def test_reverse_equals_the_reference(work, tmp_path, shuf_l3k10):
         assert all(len(x) == 20 and set(x) <= set("ACGT") for x in kmers)
 
 
+def test_byread_sketch_and_reverse_byreads_equal_the_reference(tmp_path):
+    """dist --byread (reads2mco) of the real reference against the oracle restatement on fresh input, 1 and 16 components,
+    and `kssd reverse --byreads` (co_rvs2kmer_byreads, host-only) on the reference's directory: same text on stdout"""
+    import subprocess
+    rng = np.random.default_rng(99)
+
+    def seq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    parts = [seq(40000) + "\n"]  # k-mers in front of the first header: they shift the reference's per-read lists
+    for i in range(50):
+        parts.append(">r%d\n%s\n" % (i, seq(int(rng.integers(30, 20000)))))
+        if i % 6 == 2:
+            parts.append(">empty\n")
+    text = "".join(parts).encode()
+    (tmp_path / "in.fa").write_bytes(text)
+    for k in (10, 11):
+        sh = K.Shuf.generate(k, 6, 3, seed=4242)
+        sp = str(tmp_path / ("s%d.shuf" % k))
+        sh.write(sp)
+        out = "ref%d" % k
+        ko.run_ref(["dist", "--byread", "-L", sp, "-o", out, "in.fa"], cwd=str(tmp_path))
+        files = ko.Sketcher(sh.table, k, 6, 3).byread_files(text)
+        assert len(files) == (16 if k == 11 else 1)
+        for c, (ids, idx) in files.items():
+            assert np.array_equal(np.fromfile(str(tmp_path / out / ("combco.%d" % c)), np.uint32), ids)
+            assert np.array_equal(np.fromfile(str(tmp_path / out / ("combco.index.%d" % c)), np.int64), idx)
+        assert sum(len(v[0]) for v in files.values()) > 100 and sum(int(v[1][0]) for v in files.values()) > 0
+        want = ko.run_ref(["reverse", "--byreads", "-L", sp, out], cwd=str(tmp_path)).stdout
+        ours = subprocess.run([os.path.join(os.path.dirname(G), "..", "public_kssd_amd", "kssd"), "reverse", "--byreads", "-L", sp, out],
+                              cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert ours.returncode == 0, ours.stderr.decode()
+        assert ours.stdout == want and want.count(b">read ") == text.count(b">")
+
+
 def test_abundance_sketch_oracle_vs_reference_on_deep_reads(tmp_path, shuf_l3k10):
     """dist -A -p 1 of the real reference on 30x reads of a 40 kb sequence (occurrences up to dozens) against the
     oracle restatement: ids in file order and occurrences"""
