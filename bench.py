@@ -12,9 +12,11 @@ its own genomes on the indexed side (all gathered sketches are the query rows): 
 that would otherwise be repeated on every rank, and every metric of the path is symmetric in (query, reference),
 so the R x G block a rank writes is the transpose of its G x R query block.
 
-Steps are pipelined: --inflight batches (default 3) are in flight at a time, each on its own HIP stream with its own
-context and outputs, so that the latency-bound kernels of one step (exact stage, index build) run underneath the scan
-of the next one; --inflight 1 runs the steps back to back on one stream.
+By default the steps run back to back on one stream (--inflight 1): the roofline figure of the scan is then the kernel's
+own.  --inflight 3 pipelines the steps over three contexts and streams, so that the latency-bound kernels of one step
+(exact stage, index build) run underneath the scan of the next one: +8 % genomes/s on one MI355X, at the price of a scan
+that shares the machine (its launch takes 0.60-0.64 ms instead of 0.56); DESIGN.md section 5 has both sets of numbers and
+the other schedules that were measured.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -157,8 +159,8 @@ def main():
     ap.add_argument("--clades", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "3")),
-                    help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
+                    help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial, the default; 3 = pipelined)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,13 +194,13 @@ def main():
     if rank == 0:
         log("[bench] batch of %d x %.1f Mb packed on device in %.1f s" % (G, L / 1e6, time.time() - t0))
 
-    # Software pipeline over steps.  Every step is the whole hot path over one batch; NF = 3 batches are in flight,
-    # each with its own context (workspaces, index), outputs and HIP stream.  The scan fills every CU's LDS, so it
-    # runs alone among the LDS users.  Events between the phases (kssd_gpu_sketch_phase) arrange the rest around it:
-    #     under scan n            exact stage of step n-1, index build of step n-2, per-call setup of step n+1
-    #                             (no LDS; bound by random HBM reads / atomics, a few waves per SIMD)
-    #     between scan n and n+1  per-genome sort of step n-1 and all-pairs rows of step n-2 (LDS users), side by side
-    # Nothing is skipped or reused between steps; --inflight 1 runs the same phases back to back on one stream.
+    # Optional software pipeline over steps (--inflight 3).  Every step is the whole hot path over one batch; NF batches
+    # are in flight, each with its own context (workspaces, index), outputs and HIP stream.  The scan holds every CU's
+    # LDS, so no other LDS user starts while it runs; events between the phases (kssd_gpu_sketch_phase) let the
+    # kernels without LDS of the neighbouring steps (exact stage, index insert) run underneath it and the LDS users
+    # (per-genome sort, all-pairs rows, posting allocation) side by side between two scans.
+    # Nothing is skipped or reused between steps; --inflight 1 (the default) runs the same phases back to back on one
+    # stream.
     exp_ids = int(G * L / 4096)
     cap = int(exp_ids * 1.25) + 4096                      # ids per rank (padded all-gather unit)
     R = G * world
@@ -336,6 +338,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # outside the timed region: the scan with nothing else on the device (sketch call alone, one stream), for the
+    # kernel's own roofline figure next to the one measured under the pipeline's contention
+    scan_alone_ms = None
+    if NF > 1 and world == 1:
+        sl = slots[0]
+        sl.ctx.kernel_time(0, reset=True)
+        for _ in range(5):
+            plan_prep(sl)
+            for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                sl.ctx.sketch_phase(ph, sl.stream)
+        torch.cuda.synchronize()
+        scan_alone_ms, _ = sl.ctx.kernel_time(0)
+
     if rank == 0:
         # size-independent sanity on the full matrix of this rank
         sh = shared.view(R, G)  # [all genomes (query rows)] x [this rank's genomes]; world 1: the full G x G matrix
@@ -374,6 +389,9 @@ def main():
                          "traffic": None,
                          "algorithmic_bytes_per_launch": scan_bytes},
         }
+        if scan_alone_ms:
+            res["kernels"]["sketch_scan_ms_alone"] = scan_alone_ms
+            res["roofline"]["frac_alone"] = scan_bytes / (scan_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if a.cpu_sample and world == 1 and kept:
             ol = off_l.cpu().numpy()
             il = ids_l.cpu().numpy().view(np.uint32)

@@ -7,6 +7,11 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 ( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${tag}_pytest.log
 timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+timeout 300 python bench.py --inflight 3 --steps 30 --warmup 3 --cpu-sample 0 > gpurun_out/${tag}_bench_inflight3.json 2> gpurun_out/${tag}_bench_inflight3.err
+# the N = 2 flow on this one GPU (both ranks on cuda:0, gloo instead of RCCL): checks the pipelined multi-rank path
+KSSD_BENCH_ONE_DEVICE=1 KSSD_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --genomes 400 --cpu-sample 0 --inflight 3 \
+  > gpurun_out/${tag}_bench_n2_onegpu.json 2> gpurun_out/${tag}_bench_n2_onegpu.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/${tag}_prof.log 2>&1
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_kernel_stats.csv
@@ -20,4 +25,4 @@ echo "--- FETCH_SIZE calibration: every calib_read* launch reads exactly 2^30 by
 SB_ARGS=calib profiles/pmc_sb.sh ${tag}_calib FETCH_SIZE
 } > gpurun_out/${tag}_pmc_scan.txt 2>&1
 rm -rf gpurun_out/${tag}_prof gpurun_out/pmc_${tag}_*/
-tail -3 gpurun_out/${tag}_pytest.log; cut -c1-700 gpurun_out/${tag}_bench.json; cat gpurun_out/${tag}_pmc_scan.txt
+tail -3 gpurun_out/${tag}_pytest.log; cut -c1-700 gpurun_out/${tag}_bench.json; cut -c1-300 gpurun_out/${tag}_bench_inflight3.json; cut -c1-300 gpurun_out/${tag}_bench_n2_onegpu.json; tail -3 gpurun_out/${tag}_bench_n2_onegpu.err; cat gpurun_out/${tag}_pmc_scan.txt
