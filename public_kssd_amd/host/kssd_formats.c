@@ -638,7 +638,8 @@ int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_ske
                 }
             }
         }
-        for (uint32_t q = q0; q < q1; q++) fwrite(sb[q - q0].p, 1, sb[q - q0].n, f);
+        for (uint32_t q = q0; q < q1; q++)
+            if (sb[q - q0].n) fwrite(sb[q - q0].p, 1, sb[q - q0].n, f);
     }
     for (uint32_t i = 0; i < QB; i++) free(sb[i].p);
     free(sb);
