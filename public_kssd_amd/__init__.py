@@ -7,5 +7,7 @@ from .capi import (Batch, GpuCtx, KssdError, Shuf, SketchSet, derive, distance_p
                    SLACK_WORDS, SKETCH_FASTA, SKETCH_KEEP_ZERO, SKETCH_NO_CAPACITY, SKETCH_FIRST_POS, SKETCH_COUNTS, SKETCH_BY_POS, SKETCH_UNIQ, byread_write,
                    PHASE_PREP, PHASE_SCAN, PHASE_EXACT, PHASE_FINISH)
 
-__all__ = ["Batch", "GpuCtx", "KssdError", "Shuf", "SketchSet", "derive", "distance_print", "slot_order", "slot_order_pos", "gpu_lib", "host_lib", "CHUNK_BASES", "CHUNK_MASKW",
-           "CHUNK_WORDS", "SLACK_WORDS", "SKETCH_FASTA", "SKETCH_KEEP_ZERO", "SKETCH_NO_CAPACITY", "SKETCH_UNIQ"]
+__all__ = ["Batch", "GpuCtx", "KssdError", "Shuf", "SketchSet", "derive", "distance_print", "slot_order", "slot_order_pos", "byread_write",
+           "gpu_lib", "host_lib", "CHUNK_BASES", "CHUNK_MASKW", "CHUNK_WORDS", "SLACK_WORDS", "SKETCH_FASTA", "SKETCH_KEEP_ZERO",
+           "SKETCH_NO_CAPACITY", "SKETCH_FIRST_POS", "SKETCH_COUNTS", "SKETCH_BY_POS", "SKETCH_UNIQ", "PHASE_PREP", "PHASE_SCAN",
+           "PHASE_EXACT", "PHASE_FINISH"]
