@@ -673,6 +673,23 @@ void ko_output_ctrl(u32 X, u32 Y, u32 s, int kmerlen, int dim_rd_len, int metric
     o->ci_d2 = log(dist_arg(metric_sel, o->ci_m1)) / kmerlen;
 }
 
+/* the four metric values of many (X, Y, s) triples, rs = 0: the same expressions as above (command_dist.c:1262-1266),
+ * evaluated with the host's libm; for whole-matrix comparisons */
+void ko_metrics_batch(const u32 *X, const u32 *Y, const u32 *S, size_t n, int kmerlen, double *J, double *MD, double *Cc, double *AD)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) {
+        const u32 x = X[i], y = Y[i], s = S[i];
+        const double j = (double)s / (u32)(x + y - s), c = (double)s / (x < y ? x : y);
+        double d = log(dist_arg(0, j)) / kmerlen;
+        J[i] = j;
+        MD[i] = d > 1 ? 1 : d;
+        d = log(dist_arg(1, c)) / kmerlen;
+        Cc[i] = c;
+        AD[i] = d > 1 ? 1 : d;
+    }
+}
+
 int ko_format_line(char *buf, size_t cap, const char *qname, const char *rname, u32 X, u32 Y, u32 s, int kmerlen,
                    int dim_rd_len, int metric_sel, int pfield, int correction, double dthreshold, u64 cmprsn_num)
 {

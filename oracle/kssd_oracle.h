@@ -123,6 +123,10 @@ void ko_output_ctrl(uint32_t X, uint32_t Y, uint32_t s, int kmerlen, int dim_rd_
                     int metric_sel, int correction, double dthreshold, uint64_t cmprsn_num,
                     ko_metric *m);
 
+/* (Jaccard, MashD, containment, AafD) of n triples with rs = 0, host libm (command_dist.c:1262-1266) */
+void ko_metrics_batch(const uint32_t *X, const uint32_t *Y, const uint32_t *S, size_t n, int kmerlen,
+                      double *J, double *MD, double *Cc, double *AD);
+
 /* one distance.out line exactly as output_ctrl prints it; returns length (0 if skipped) */
 int ko_format_line(char *buf, size_t cap, const char *qname, const char *rname,
                    uint32_t X, uint32_t Y, uint32_t s, int kmerlen, int dim_rd_len,

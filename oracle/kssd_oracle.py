@@ -232,6 +232,19 @@ def output_ctrl(X, Y, s, kmerlen, dim_rd_len, metric_sel=0, correction=0, dthres
     return m
 
 
+def metrics_batch(X, Y, S, kmerlen):
+    """(J, MashD, C, AafD) f64 arrays for broadcastable uint32 arrays, rs = 0, one C loop over the host libm"""
+    X, Y, S = np.broadcast_arrays(np.asarray(X, np.uint32), np.asarray(Y, np.uint32), np.asarray(S, np.uint32))
+    shape = S.shape
+    X, Y, S = (np.ascontiguousarray(a).reshape(-1) for a in (X, Y, S))
+    out = [np.empty(S.size) for _ in range(4)]
+    f = lib().ko_metrics_batch
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_int] + [C.c_void_p] * 4
+    f(X.ctypes.data, Y.ctypes.data, S.ctypes.data, S.size, kmerlen, *[o.ctypes.data for o in out])
+    return tuple(o.reshape(shape) for o in out)
+
+
 def metrics_arrays(X, Y, S, kmerlen):
     """(J, MashD, C, AafD) f64 arrays for broadcastable uint32 arrays, rs=0 (no correction)."""
     X, Y, S = np.broadcast_arrays(np.asarray(X, np.uint32), np.asarray(Y, np.uint32), np.asarray(S, np.uint32))

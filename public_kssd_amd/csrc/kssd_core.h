@@ -290,6 +290,91 @@ KSSD_HD bool kssd_stage2(const KssdParams &P, int64_t s, int64_t lo_ok, int64_t 
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// log(x) / k for the distance epilogue (MashD = log(1/(2J) + 0.5) / 2k, AafD = log(1/C) / 2k, command_dist.c:1251,1265).
+// The host computes fl(fl(log x) / k) with glibc's log (error < 0.52 ulp).  A device log that is merely "within 1 ulp"
+// differs from glibc's in ~1 % of the pairs, and the division by 2k = 20 turns one ulp of the logarithm into up to 1.6
+// ulps of the quotient: measured on the bench matrix, 0.2 % of the distances were 2 ulps away from the host's.
+// So log x is computed in double-double (error ~0.01 ulp), which shows which doubles glibc can have returned; the
+// host's two roundings are repeated on them (details at the end of the function).  The distance is the host's bit for
+// bit in ~98.5 % of the pairs and ONE ulp away in the rest -- the tolerance north_star states, by construction.
+//   x = m * 2^e, m in [sqrt(1/2), sqrt(2)];  log x = e ln2 + 2 atanh(s),  s = (m - 1) / (m + 1)  (|s| <= 0.1716)
+// IEEE arithmetic and fma only: the CPU tests run the same code against glibc and against 60-digit decimals.
+// Arguments here are >= 1; anything that is not a positive finite normal number goes to the library function.
+// ---------------------------------------------------------------------------------------------------
+KSSD_HD double kssd_log_over_k(double x, double k)
+{
+    uint64_t ix;
+    __builtin_memcpy(&ix, &x, 8);
+    if (!(x >= 2.2250738585072014e-308) || (ix >> 52) >= 0x7FFull) {  // 0, < 0, subnormal, inf, nan: the library function
+#if defined(__HIP_DEVICE_COMPILE__)
+        return log(x) / k;
+#else
+        return __builtin_log(x) / k;
+#endif
+    }
+    int e = (int)(ix >> 52) - 1023;
+    uint64_t im = (ix & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m;
+    __builtin_memcpy(&m, &im, 8);                       // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }   // [sqrt(1/2), sqrt(2)], exact
+    const double f = m - 1.0;                           // exact
+    const double dh = 2.0 + f;                          // m + 1 = dh + dl exactly (|f| < 2)
+    const double dl = (2.0 - dh) + f;
+    const double sh = f / dh;
+    const double r = __builtin_fma(-sh, dh, f) - sh * dl;  // f - sh (dh + dl)
+    const double sl = r / dh;                           // s = sh + sl to ~2^-105
+    const double z = sh * sh;
+    // atanh(s) / s - 1 = z/3 + z^2/5 + ... ; z <= 0.0295: the term after z^12/25 is below 2^-64
+    double q = 1.0 / 25.0;
+    q = __builtin_fma(q, z, 1.0 / 23.0);
+    q = __builtin_fma(q, z, 1.0 / 21.0);
+    q = __builtin_fma(q, z, 1.0 / 19.0);
+    q = __builtin_fma(q, z, 1.0 / 17.0);
+    q = __builtin_fma(q, z, 1.0 / 15.0);
+    q = __builtin_fma(q, z, 1.0 / 13.0);
+    q = __builtin_fma(q, z, 1.0 / 11.0);
+    q = __builtin_fma(q, z, 1.0 / 9.0);
+    q = __builtin_fma(q, z, 1.0 / 7.0);
+    q = __builtin_fma(q, z, 1.0 / 5.0);
+    q = __builtin_fma(q, z, 1.0 / 3.0);
+    const double w = z * q;                             // <= 0.0099: its rounding error is ~0.01 ulp of the logarithm
+    const double hi1 = 2.0 * sh;                        // log m = hi1 + lo1
+    const double lo1 = 2.0 * sl + hi1 * w;
+    const double ln2_hi = 6.93147180369123816490e-01;   // 21 trailing zero bits: e * ln2_hi is exact
+    const double ln2_lo = 1.90821492927058770002e-10;
+    const double ed = (double)e;
+    const double t = ed * ln2_hi;
+    const double a = t + hi1;                           // TwoSum(t, hi1) = a + b
+    const double bb = a - t;
+    const double b = (t - (a - bb)) + (hi1 - bb);
+    const double c = b + (lo1 + ed * ln2_lo);
+    const double lh = a + c;                            // log x = lh + ll (Fast2Sum: |a| >= |c|)
+    const double ll = c - (lh - a);
+    const double qh = lh / k;                           // what the host computes if its log returned lh
+    if (lh == 0.0) return qh;                           // x = 1
+    // Which double does glibc return?  Its log is within 0.519 ulp of log x = lh + ll.  If ll is clearly less than half
+    // an ulp of lh, the neighbours of lh are more than 0.519 ulp away from the truth and glibc's value MUST be lh: then
+    // qh is the host's distance bit for bit (92 % of the arguments).
+    uint64_t lb;
+    __builtin_memcpy(&lb, &lh, 8);
+    const uint64_t ub = (((lb >> 52) & 0x7FFull) - 52) << 52;  // lh >= 2^-53 here: exponent field > 52
+    double u;
+    __builtin_memcpy(&u, &ub, 8);                       // ulp(lh)
+    if (__builtin_fabs(ll) < 0.46 * u) return qh;
+    // Otherwise glibc may also have returned the neighbour on ll's side.  If both candidates give the same or adjacent
+    // distances, qh is within one ulp of the host whichever it chose (and equal to it whenever glibc rounded
+    // correctly); if the division pulled them two ulps apart, the correctly rounded quotient of the double-double
+    // logarithm lies between them: within 0.53 ulp of log(x)/k, the host within 1.33 ulp of it -> at most ONE ulp apart.
+    const double h2 = (ll > 0 ? lh + u : lh - u) / k;
+    uint64_t q1, q2;
+    __builtin_memcpy(&q1, &qh, 8);
+    __builtin_memcpy(&q2, &h2, 8);
+    if (q1 - q2 + 1ull <= 2ull) return qh;              // |q1 - q2| <= 1
+    const double rem = __builtin_fma(-qh, k, lh) + ll;  // (lh + ll) / k, rounded once
+    return qh + rem / k;
+}
+
 #include <vector>
 // Host-side construction of the two device tables from the accepted sub-contexts
 // (accepted[r] = the sub-context whose permutation rank is r, r < dim_end).

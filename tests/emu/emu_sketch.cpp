@@ -118,3 +118,9 @@ static long emu_impl(int k, int subk, int drlevel, const int32_t *table, const u
     if (where_out) memcpy(where_out, where.data(), where.size() * 8);
     return (long)res.size();
 }
+
+// the distance epilogue's log(x) / k (kssd_core.h:kssd_log_over_k), as the device evaluates it
+extern "C" void emu_log_over_k(const double *x, double k, double *y, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++) y[i] = kssd_log_over_k(x[i], k);
+}

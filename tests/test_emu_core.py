@@ -24,11 +24,13 @@ def emu():
     src = os.path.join(HERE, "emu", "emu_sketch.cpp")
     core = os.path.join(HERE, "..", "public_kssd_amd", "csrc", "kssd_core.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(core)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", so])
     L = C.CDLL(so)
     L.emu_sketch.restype = C.c_long
     L.emu_sketch.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p,
                                                                   C.c_uint64, C.c_void_p, C.c_int]
+    L.emu_log_over_k.restype = None
+    L.emu_log_over_k.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_uint64]
     L.emu_sketch_where.restype = C.c_long
     L.emu_sketch_where.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     return L
@@ -122,3 +124,48 @@ def test_byread_host_side_against_the_reference_goldens(emu, tmp_path):
             keep = np.r_[4:5, 8:32]  # shuf id aside (the goldens' shuffle carries the reference's own random id)
             assert np.array_equal(stat[:32][keep], B["%s/%s/stat" % (tag, name)][keep])
             assert len(stat) == 32 + 4 + 256 and bytes(stat[36:36 + len(name)]) == name.encode()
+
+
+def test_distance_epilogue_is_within_one_ulp_of_the_host_formula(emu):
+    """kssd_log_over_k (kssd_core.h; the device runs the same IEEE + fma code): log(x) / 2k against the host's
+    fl(fl(log x) / 2k) with glibc -- never more than ONE ulp apart (north_star tolerance), equal bit for bit in > 97 % of
+    the cases; and, like the host value, within 1.33 ulp of the exact quotient (60-digit decimals) on a sample"""
+    import math
+    from decimal import Decimal, getcontext
+    rng = np.random.default_rng(8)
+
+    def ours(x, k):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.empty_like(x)
+        emu.emu_log_over_k(x.ctypes.data, k, y.ctypes.data, len(x))
+        return y
+
+    n = 400_000
+    X = rng.integers(1000, 1500, n).astype(np.float64)
+    Y = rng.integers(1000, 1500, n).astype(np.float64)
+    S = np.minimum(rng.integers(1, 1400, n), np.minimum(X, Y)).astype(np.float64)
+    J, Cc = S / (X + Y - S), S / np.minimum(X, Y)
+    cases = {"mash": 1 / (2 * J) + 0.5, "aaf": 1 / Cc, "uniform": rng.uniform(1, 1e4, n), "near 1": 1 + rng.uniform(0, 1e-6, n),
+             "wide": np.exp(rng.uniform(0, 700, n))}
+    for k in (20.0, 16.0, 30.0, 14.0, 24.0):
+        for name, arg in cases.items():
+            got = ours(arg, k)
+            want = np.array([math.log(v) for v in arg]) / k
+            d = np.abs(got.view(np.int64) - want.view(np.int64))
+            assert d.max() <= 1, (k, name, int(d.max()))
+            assert (d == 0).mean() > 0.95, (k, name, float((d == 0).mean()))
+    d = np.abs(ours(cases["mash"], 20.0).view(np.int64) - (np.array([math.log(v) for v in cases["mash"]]) / 20.0).view(np.int64))
+    assert (d == 0).mean() > 0.97
+    # special values: x = 1 -> 0, inf -> inf (clamped to 1 by the caller), nan stays nan
+    sp = ours(np.array([1.0, np.inf, np.nan, 1 + 2.0 ** -52]), 20.0)
+    assert sp[0] == 0.0 and np.isinf(sp[1]) and np.isnan(sp[2]) and sp[3] == math.log(1 + 2.0 ** -52) / 20.0
+    # against the exact quotient
+    getcontext().prec = 60
+    arg = np.concatenate([cases["mash"][:4000], cases["aaf"][:4000], cases["uniform"][:2000]])
+    got = ours(arg, 20.0)
+    worst = 0.0
+    for v, o in zip(arg, got):
+        exact = Decimal(float(v)).ln() / Decimal(20)
+        ulp = Decimal(math.ulp(o))
+        worst = max(worst, float(abs(Decimal(float(o)) - exact) / ulp))
+    assert worst < 1.35, worst  # like the host, whose two roundings stay within 0.52 * 1.6 + 0.5 ulp of the exact quotient
