@@ -427,7 +427,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     unsigned long long c0 = wid * per, c1 = c0 + per;
     if (c1 > a.n_chunks) c1 = a.n_chunks;
     const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
-    uint32_t n_stage1 = 0, n_bloom = 0;  // telemetry (wave-uniform)
+    uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
 
     // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
     // first reads overlaps the 144 KiB copy instead of following it
@@ -482,15 +482,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 // registers and buffer (position, pattern) by ballot compaction.  No LDS read in this loop: a read
                 // would have to wait behind the table reads of chunk c+1 that are in flight
                 const uint32_t ebase = ((uint32_t)(c - c0) << 12) | (lane << 6);
-                for (;;) {
+                for (uint64_t hbal = __ballot((cl | ch) != 0); hbal; hbal = __ballot((cl | ch) != 0)) {
                     const bool has = (cl | ch) != 0;
-                    const uint64_t hbal = __ballot(has);
-                    if (!hbal) break;
                     if (cn + 64 > CBUF) {  // dense parameter sets only: make room
                         wave_lds_sync();
                         const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - 64, 64, stored, lane, abl_acc);
                         stored += m;
-                        n_bloom += m;
+                        n_rounded += 64;
                         cn -= 64;
                         wave_lds_sync();
                     }
@@ -505,7 +503,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                         cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b, kssd_extract_m<SUBK>(cur.W, b));
                     }
                     cn += __builtin_popcountll(hbal);
-                    n_stage1 += __builtin_popcountll(hbal);
                 }
             }
             __builtin_amdgcn_s_setprio(2);
@@ -516,7 +513,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 wave_lds_sync();
                 const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - 64, 64, stored, lane, abl_acc);
                 stored += m;
-                n_bloom += m;
+                n_rounded += 64;
                 cn -= 64;
             }
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
@@ -533,13 +530,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         wave_lds_sync();
         const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - n, n, stored, lane, abl_acc);
         stored += m;
-        n_bloom += m;
+        n_rounded += n;
         cn -= n;
     }
     if (lane == 0) {
         a.cand_count[wid] = stored;
-        atomicAdd(&a.status->n_stage1, (unsigned long long)n_stage1);
-        atomicAdd(&a.status->n_bloom, (unsigned long long)n_bloom);
+        atomicAdd(&a.status->n_stage1, (unsigned long long)n_rounded);
+        atomicAdd(&a.status->n_bloom, (unsigned long long)stored);  // every survivor of a round was counted into `stored`
     }
     if (ABL != 0) {
         for (int i = 0; i < Gp::NMAX; i++) abl_acc ^= raw[i];
