@@ -331,6 +331,23 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
     chunk_gid[c] = lo;
 }
 
+// the same map written genome by genome (one workgroup each, plain coalesced stores, no search): the cheaper way
+// when genomes span many chunks.  The per-call state is zeroed by the first workgroups like above.
+__global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes,
+                                           uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
+                                           uint32_t n_slices, unsigned long long *__restrict__ lane_valid_tail,
+                                           uint32_t *__restrict__ status_words)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
+    if (t < 2) lane_valid_tail[t] = 0;
+    for (uint64_t i = t; i < n_genomes; i += (uint64_t)gridDim.x * blockDim.x) cursor[i] = 0;
+    for (uint64_t i = t; i < n_slices; i += (uint64_t)gridDim.x * blockDim.x) cand_count[i] = 0;
+    if (blockIdx.x >= n_genomes) return;
+    const uint32_t g = blockIdx.x;
+    for (uint64_t c = chunk_off[g] + threadIdx.x; c < chunk_off[g + 1]; c += blockDim.x) chunk_gid[c] = g;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // kernel 1: the scan.  One wave per 4096-position chunk iteration, one lane per 64 positions.
 //   HBM -> registers: 16 B of packed bases + 4 B halo + 8 B of mask per lane, coalesced, two chunks ahead
@@ -1114,6 +1131,13 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
     uint64_t init_n = pl.n_chunks > pl.n_genomes ? pl.n_chunks : pl.n_genomes;
     if (init_n < pl.n_slices) init_n = pl.n_slices;
     if (init_n < sizeof(SketchStatus) / 4) init_n = sizeof(SketchStatus) / 4;
+    if (pl.n_chunks >= 64ull * pl.n_genomes) {  // long genomes: fill the map genome by genome
+        hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64), dim3(256), 0, s,
+                           (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
+                           c->d_lane_valid + pl.n_chunks, reinterpret_cast<uint32_t *>(c->d_status));
+        HIPCK(hipGetLastError());
+        return KSSD_OK;
+    }
     hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
                        (const uint64_t *)c->d_chunk_off, pl.n_genomes, pl.n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
                        pl.n_slices, c->d_lane_valid + pl.n_chunks, reinterpret_cast<uint32_t *>(c->d_status));
