@@ -15,8 +15,8 @@ so the R x G block a rank writes is the transpose of its G x R query block.
 By default the steps run back to back on one stream (--inflight 1): the roofline figure of the scan is then the kernel's
 own.  --inflight 3 pipelines the steps over three contexts and streams, so that the latency-bound kernels of one step
 (exact stage, index build) run underneath the scan of the next one: +8 % genomes/s on one MI355X, at the price of a scan
-that shares the machine (its launch takes 0.60-0.64 ms instead of 0.56); DESIGN.md section 5 has both sets of numbers and
-the other schedules that were measured.
+that shares the machine (its launch takes a few per cent longer); DESIGN.md section 5 has both sets of numbers and the
+other schedules that were measured.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
