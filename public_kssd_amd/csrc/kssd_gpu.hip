@@ -688,6 +688,68 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum /
     return off + incl - v;
 }
 
+// Bitonic sort of np = EPT * DEDUP_THREADS keys with the keys in registers: thread t holds elements t*EPT .. t*EPT+EPT-1.
+// A pass whose partner distance j is below EPT stays inside a thread, one below 64*EPT inside a wave (one shuffle per
+// key), and only the few passes beyond that go through LDS -- 6 of the 66 passes of a 2 048-key sort, where the plain
+// LDS version moves every key through LDS (and a block barrier) in all 66.  Leaves the sorted keys in a[0 .. np).
+__device__ __forceinline__ uint32_t shfl_xor_key(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ unsigned long long shfl_xor_key(unsigned long long v, int m)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename K, int EPT>
+__device__ __forceinline__ void sort_in_registers(K *a, const K *__restrict__ src, uint32_t n, uint32_t tid)
+{
+    constexpr uint32_t np = EPT * DEDUP_THREADS;
+    K x[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; r++) {
+        const uint32_t e = tid * EPT + r;
+        x[r] = e < n ? src[e] : KeyOps<K>::pad();
+    }
+    for (uint32_t k = 2; k <= np; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j < (uint32_t)EPT) {  // partner in this thread
+#pragma unroll
+                for (int r = 0; r < EPT; r++) {
+                    if ((r & j) == 0) {
+                        const uint32_t e = tid * EPT + r;
+                        const bool asc = (e & k) == 0;
+                        const K lo = x[r], hi = x[r | j];
+                        if ((lo > hi) == asc) { x[r] = hi; x[r | j] = lo; }
+                    }
+                }
+            } else if (j < 64u * EPT) {  // partner in this wave
+                const int m = (int)(j / EPT);
+#pragma unroll
+                for (int r = 0; r < EPT; r++) {
+                    const uint32_t e = tid * EPT + r;
+                    const K y = shfl_xor_key(x[r], m);
+                    const bool take_min = ((e & j) == 0) == ((e & k) == 0);
+                    x[r] = take_min ? (x[r] < y ? x[r] : y) : (x[r] > y ? x[r] : y);
+                }
+            } else {  // partner in another wave: through LDS
+#pragma unroll
+                for (int r = 0; r < EPT; r++) a[tid * EPT + r] = x[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < EPT; r++) {
+                    const uint32_t e = tid * EPT + r;
+                    const K y = a[e ^ j];
+                    const bool take_min = ((e & j) == 0) == ((e & k) == 0);
+                    x[r] = take_min ? (x[r] < y ? x[r] : y) : (x[r] > y ? x[r] : y);
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; r++) a[tid * EPT + r] = x[r];
+    __syncthreads();
+}
+
 template <typename K>
 __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
                                                                       const uint32_t *__restrict__ cursor,
@@ -717,8 +779,12 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
         atomicMax(&st->max_need_q8, (uint32_t)(((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1)));
     uint32_t np = 1;
     while (np < n) np <<= 1;
-    for (uint32_t i = tid; i < np; i += DEDUP_THREADS) a[i] = i < n ? regions[r0 + i] : KeyOps<K>::pad();
     if (tid == 0) { s_distinct = 0; s_zero_occ = 0; }
+    if (np == 2 * DEDUP_THREADS) sort_in_registers<K, 2>(a, regions + r0, n, tid);
+    else if (np == 4 * DEDUP_THREADS) sort_in_registers<K, 4>(a, regions + r0, n, tid);
+    else if (np == 8 * DEDUP_THREADS) sort_in_registers<K, 8>(a, regions + r0, n, tid);
+    else {
+    for (uint32_t i = tid; i < np; i += DEDUP_THREADS) a[i] = i < n ? regions[r0 + i] : KeyOps<K>::pad();
     __syncthreads();
     for (uint32_t k = 2; k <= np; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -733,12 +799,13 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
             __syncthreads();
         }
     }
+    }
     // runs of equal tuples; only the first n entries are real (in first-position mode the first entry of a run is
     // the tuple's first occurrence)
     uint32_t out_base = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += DEDUP_THREADS) {
         const uint32_t i = i0 + tid;
-        bool keep = false;
+        bool keep = false, counted = false;
         K kv = 0;
         if (i < n) {
             kv = a[i];
@@ -746,6 +813,7 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
             const bool start = (i == 0) || (KeyOps<K>::id(a[i - 1]) != v);
             if (start) {
                 uint32_t lo = i + 1, hi = n;  // first index > i with a different tuple
+                if (lo < n && KeyOps<K>::id(a[lo]) != v) hi = lo;  // the common case: a run of one
                 while (lo < hi) {
                     uint32_t mid = (lo + hi) >> 1;
                     if (KeyOps<K>::id(a[mid]) == v) lo = mid + 1;
@@ -759,9 +827,13 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
                     keep = false;  // fasta2co leaves the slot empty (iseq2comem.c:258-261) ...
                     atomicAdd(&s_zero_occ, len);  // ... but counts every occurrence against the limit
                 } else {
-                    atomicAdd(&s_distinct, 1u);
+                    counted = true;
                 }
             }
+        }
+        {   // distinct tuples: one LDS atomic per wave, not one per tuple (they would queue up on one address)
+            const uint64_t cb = __ballot(counted);
+            if (cb && lane_id() == 0) atomicAdd(&s_distinct, (uint32_t)__builtin_popcountll(cb));
         }
         uint32_t tot;
         const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
