@@ -6,6 +6,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC kssd_gpu.hip -o libkssd_gpu.so
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1019,10 +1020,13 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
 // ---------------------------------------------------------------------------------------------------
 // sketch entry points
 // ---------------------------------------------------------------------------------------------------
+// the launch carries its own start / stop events (hipExtLaunchKernelGGL): they take the timestamps of the dispatch itself,
+// so kssd_gpu_kernel_time reports the kernel's execution time like the profiler does, not the distance between two
+// stream markers (which also holds the launch latency whenever the kernel in front is too short to hide it)
 template <int SUBK, int ABL = 0>
-static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s)
+static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
+    hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -1229,25 +1233,24 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     a.status = c->d_status;
     const int grid = pl.grid;
     const unsigned evi = c->ev_n[0] % EV_RING;
-    HIPCK(hipEventRecord(c->ev_a[0][evi], s));
+    hipEvent_t e0 = c->ev_a[0][evi], e1 = c->ev_b[0][evi];
     switch (c->P.subk) {
-    case 2: rc = launch_scan<2>(c, a, grid, s); break;
-    case 3: rc = launch_scan<3>(c, a, grid, s); break;
-    case 4: rc = launch_scan<4>(c, a, grid, s); break;
-    case 5: rc = launch_scan<5>(c, a, grid, s); break;
+    case 2: rc = launch_scan<2>(c, a, grid, s, e0, e1); break;
+    case 3: rc = launch_scan<3>(c, a, grid, s, e0, e1); break;
+    case 4: rc = launch_scan<4>(c, a, grid, s, e0, e1); break;
+    case 5: rc = launch_scan<5>(c, a, grid, s, e0, e1); break;
     case 6: {
         static const int abl = getenv("KSSD_DEV_ABLATE") ? atoi(getenv("KSSD_DEV_ABLATE")) : 0;  // profiling only
-        if (abl == 1) rc = launch_scan<6, 1>(c, a, grid, s);
-        else if (abl == 2) rc = launch_scan<6, 2>(c, a, grid, s);
-        else if (abl == 3) rc = launch_scan<6, 3>(c, a, grid, s);
-        else rc = launch_scan<6>(c, a, grid, s);
+        if (abl == 1) rc = launch_scan<6, 1>(c, a, grid, s, e0, e1);
+        else if (abl == 2) rc = launch_scan<6, 2>(c, a, grid, s, e0, e1);
+        else if (abl == 3) rc = launch_scan<6, 3>(c, a, grid, s, e0, e1);
+        else rc = launch_scan<6>(c, a, grid, s, e0, e1);
         break;
     }
-    case 7: rc = launch_scan<7>(c, a, grid, s); break;
+    case 7: rc = launch_scan<7>(c, a, grid, s, e0, e1); break;
     default: rc = KSSD_ERR_UNSUPPORTED;
     }
     if (rc != KSSD_OK) return rc;
-    HIPCK(hipEventRecord(c->ev_b[0][evi], s));
     c->ev_n[0]++;
     return KSSD_OK;
 }
