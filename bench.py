@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--clades", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
+    ap.add_argument("--spinup", type=int, default=40, help="untimed steps before the warmup steps (GPU clock ramp; 0 = none)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
                     help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial, the default; 3 = pipelined)")
     a = ap.parse_args()
@@ -301,6 +302,10 @@ def main():
                 raise SystemExit("sketch failed: rc=%d" % rc)
         else:
             raise SystemExit("sketch kept overflowing")
+    sync()
+    # setup, untimed like the sizing passes above: the clocks of an idle GPU need some tens of milliseconds of work to
+    # settle (measured: the scan launch takes 0.54 ms in the first dozen steps after a pause and 0.52 ms from then on)
+    run_steps(a.spinup)
     sync()
     run_steps(a.warmup)
     sync()
