@@ -8,9 +8,9 @@ mkdir -p gpurun_out
 ( timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/${tag}_pytest.log
 timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 timeout 300 python bench.py --inflight 3 --steps 30 --warmup 3 --cpu-sample 0 > gpurun_out/${tag}_bench_inflight3.json 2> gpurun_out/${tag}_bench_inflight3.err
-# the N = 2 flow on this one GPU (both ranks on cuda:0, gloo instead of RCCL): checks the pipelined multi-rank path
+# the N = 2 flow on this one GPU (both ranks on cuda:0, gloo instead of RCCL): checks the multi-rank path of the default schedule
 KSSD_BENCH_ONE_DEVICE=1 KSSD_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-  --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --genomes 400 --cpu-sample 0 --inflight 3 \
+  --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --genomes 400 --cpu-sample 0 \
   > gpurun_out/${tag}_bench_n2_onegpu.json 2> gpurun_out/${tag}_bench_n2_onegpu.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/${tag}_prof.log 2>&1
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
