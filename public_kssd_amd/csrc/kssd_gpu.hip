@@ -723,27 +723,31 @@ __device__ __forceinline__ void sort_in_registers(K *a, const K *__restrict__ sr
                         if ((lo > hi) == asc) { x[r] = hi; x[r | j] = lo; }
                     }
                 }
-            } else if (j < 64u * EPT) {  // partner in this wave
-                const int m = (int)(j / EPT);
+            } else {
+                // j >= EPT (and k > j): whether this thread keeps the smaller or the larger key of a pair is the same for
+                // all its keys
+                const uint32_t e0 = tid * EPT;
+                const bool take_min = ((e0 & j) == 0) == ((e0 & k) == 0);
+                if (j < 64u * EPT) {  // partner in this wave
+                    const int m = (int)(j / EPT);
 #pragma unroll
-                for (int r = 0; r < EPT; r++) {
-                    const uint32_t e = tid * EPT + r;
-                    const K y = shfl_xor_key(x[r], m);
-                    const bool take_min = ((e & j) == 0) == ((e & k) == 0);
-                    x[r] = take_min ? (x[r] < y ? x[r] : y) : (x[r] > y ? x[r] : y);
+                    for (int r = 0; r < EPT; r++) {
+                        const K y = shfl_xor_key(x[r], m);
+                        const K lo = x[r] < y ? x[r] : y, hi = x[r] < y ? y : x[r];
+                        x[r] = take_min ? lo : hi;
+                    }
+                } else {  // partner in another wave: through LDS
+#pragma unroll
+                    for (int r = 0; r < EPT; r++) a[e0 + r] = x[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EPT; r++) {
+                        const K y = a[(e0 ^ j) + r];
+                        const K lo = x[r] < y ? x[r] : y, hi = x[r] < y ? y : x[r];
+                        x[r] = take_min ? lo : hi;
+                    }
+                    __syncthreads();
                 }
-            } else {  // partner in another wave: through LDS
-#pragma unroll
-                for (int r = 0; r < EPT; r++) a[tid * EPT + r] = x[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < EPT; r++) {
-                    const uint32_t e = tid * EPT + r;
-                    const K y = a[e ^ j];
-                    const bool take_min = ((e & j) == 0) == ((e & k) == 0);
-                    x[r] = take_min ? (x[r] < y ? x[r] : y) : (x[r] > y ? x[r] : y);
-                }
-                __syncthreads();
             }
         }
     }
