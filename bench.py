@@ -49,8 +49,10 @@ def log(*a):
 # ------------------------------------------------------------------------------------------------------
 # synthetic batch, generated and packed on the device (setup, untimed)
 # ------------------------------------------------------------------------------------------------------
-def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0):
-    """returns packed int32[words+slack], mask int32[...], chunk_off uint64[n+1], kept [(codes u8, nmask bool)]"""
+def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0, on_genome=None, keep_on_device=False):
+    """returns packed int32[words+slack], mask int32[...], chunk_off uint64[n+1], kept [(codes u8, nmask bool)]
+    on_genome(gi, codes u8 tensor, nmask bool tensor): called for every genome (device tensors, valid during the call);
+    keep_on_device: `kept` holds device tensors instead of numpy arrays"""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     chunks = (length + K.CHUNK_BASES - 1) // K.CHUNK_BASES
@@ -83,7 +85,9 @@ def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0):
             packed[gi * chunks * K.CHUNK_WORDS:(gi + 1) * chunks * K.CHUNK_WORDS] = w.to(torch.int32)
             mask[gi * chunks * K.CHUNK_MASKW:(gi + 1) * chunks * K.CHUNK_MASKW] = mw.to(torch.int32)
             if gi < keep_codes:
-                kept.append((codes.cpu().numpy(), nmask.cpu().numpy()))
+                kept.append((codes, nmask) if keep_on_device else (codes.cpu().numpy(), nmask.cpu().numpy()))
+            if on_genome is not None:
+                on_genome(gi, codes, nmask)
             gi += 1
     chunk_off = np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(chunks)
     return packed, mask, chunk_off, kept

@@ -149,6 +149,13 @@ int kssd_gpu_scan_stats(kssd_gpu_ctx *ctx, uint64_t *stage1, uint64_t *bloom, vo
  */
 int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *ctx, uint32_t *d_out_pos);
 
+/*
+ * Tuning knob of the per-genome dedup: genomes whose staging region holds more than max_tuples tuples are sorted
+ * in global memory instead of in one workgroup's LDS (default and upper limit: 32 768 four-byte keys; 0 = default).
+ * The results do not depend on it; the parity tests use it to send small genomes down the large-genome path.
+ */
+int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *ctx, uint32_t max_tuples);
+
 /* host-level convenience: HOST packed/mask in, malloc'd HOST CSR out (free with kssd_gpu_free) */
 int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
                           const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,
@@ -161,6 +168,15 @@ int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *ctx, const uint32_t *packed, const u
                               uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos,
                               int64_t *bad_genome);
 void kssd_gpu_free(void *p);
+
+/*
+ * Page-locked host memory (hipHostMalloc): a batch tokenised into it (kssd_batch_create_ex of the host library takes
+ * these two as its allocator) goes to the device by DMA at PCIe speed, without the runtime's staging copy.  The
+ * reference reads its inputs through popen("zcat") into a 64 KiB buffer (iseq2comem.c:196-208); this is that buffer's
+ * counterpart.  kssd_gpu_host_alloc returns NULL when the memory cannot be had.
+ */
+void *kssd_gpu_host_alloc(size_t bytes);
+void kssd_gpu_host_free(void *p);
 
 /*
  * Build the inverted index of the reference sketches on the device: replaces combco2mco
@@ -188,6 +204,18 @@ int kssd_gpu_dist_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32
 int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref,
                   const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,
                   double *jaccard, double *mashd, double *contain, double *aafd);
+
+/*
+ * The same search on several devices: the query rows are cut into n_devices contiguous blocks (the reference gives
+ * every output row one owner thread, command_dist.c:774-785), every device of `devices` receives the whole reference
+ * CSR, builds its own index and writes its block of rows into the caller's matrices.  No exchange between the devices
+ * (the sketches come from the host).  One host thread per entry; an entry may name a device twice.  kmerlen = 2k.
+ */
+int kssd_gpu_dist_multi(const int *devices, int n_devices, int kmerlen, const uint64_t *roff, const uint32_t *rids,
+                        uint32_t n_ref, const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,
+                        double *jaccard, double *mashd, double *contain, double *aafd);
+/* how many gfx950 devices this process sees (0 without any; never an error) */
+int kssd_gpu_device_count(void);
 
 /*
  * Set operations on sketches of ONE component (ids below 16^7): replace the 2^28-bit dictionary walks of

@@ -39,7 +39,8 @@ GPU_SYMBOLS = [
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
     "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
-    "kssd_gpu_sketch_phase",
+    "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
+    "kssd_gpu_host_alloc", "kssd_gpu_host_free",
 ]
 
 
@@ -83,6 +84,7 @@ class _Shuf(C.Structure):
 
 _gpu = None
 _host = None
+DEFAULT_LDS_SORT_LIMIT = 0  # tests: kssd_gpu_set_lds_sort_limit for every new GpuCtx (0 = the library's default)
 
 
 def gpu_lib():
@@ -121,6 +123,13 @@ def gpu_lib():
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
         L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
+        L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
+        L.kssd_gpu_dist_multi.argtypes = [vp, i32, i32, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
+        L.kssd_gpu_device_count.restype = i32
+        L.kssd_gpu_host_alloc.restype = vp
+        L.kssd_gpu_host_alloc.argtypes = [C.c_size_t]
+        L.kssd_gpu_host_free.restype = None
+        L.kssd_gpu_host_free.argtypes = [vp]
         _gpu = L
     return _gpu
 
@@ -162,6 +171,10 @@ def host_lib():
         L.kssd_batch_n_positions.restype = u64
         L.kssd_batch_n_positions.argtypes = [vp, u32]
         L.kssd_batch_append.argtypes = [vp, vp]
+        L.kssd_batch_create_ex.restype = vp
+        L.kssd_batch_create_ex.argtypes = [vp, vp]
+        L.kssd_batch_reserve.argtypes = [vp, u32, vp, C.POINTER(u32)]
+        L.kssd_batch_fill_text.argtypes = [vp, u32, i32, C.c_char_p, C.c_size_t, i32, C.POINTER(u64)]
         L.kssd_derive.argtypes = [C.POINTER(_Derived), i32, i32, i32]
         L.kssd_sketchset_release.argtypes = [C.POINTER(_SketchSet)]
         L.kssd_sketchset_release.restype = None
@@ -344,8 +357,14 @@ def distance_print(path, shared, ref, qry, metric=0, pfield=2, correction=0, dth
 class Batch:
     """Genomes tokenised into the packed device layout (2-bit bases + validity mask, 4096-base chunks)."""
 
-    def __init__(self):
-        self.h = host_lib().kssd_batch_create()
+    def __init__(self, pinned=False):
+        """pinned: packed / mask arrays in page-locked memory of the GPU runtime (kssd_gpu_host_alloc)"""
+        if pinned:
+            g = gpu_lib()
+            self.h = host_lib().kssd_batch_create_ex(C.cast(g.kssd_gpu_host_alloc, C.c_void_p),
+                                                     C.cast(g.kssd_gpu_host_free, C.c_void_p))
+        else:
+            self.h = host_lib().kssd_batch_create()
         if not self.h:
             raise MemoryError
 
@@ -388,6 +407,20 @@ class Batch:
         finally:
             host_lib().kssd_host_free(p)
 
+    def reserve(self, max_positions):
+        """append len(max_positions) empty genomes with that much room each; returns the index of the first"""
+        mp = np.ascontiguousarray(max_positions, dtype=np.uint64)
+        first = C.c_uint32(0)
+        _hck(host_lib().kssd_batch_reserve(self.h, len(mp), mp.ctypes.data, C.byref(first)))
+        return first.value
+
+    def fill_text(self, genome, text, kind=0, Q=0):
+        """tokenise text into a reserved genome (thread-safe across genomes); kind 0 FASTA, 1 FASTQ, 2 reads of -A"""
+        text = bytes(text)
+        n = C.c_uint64(0)
+        _hck(host_lib().kssd_batch_fill_text(self.h, genome, kind, text, len(text), Q, C.byref(n)))
+        return n.value
+
     def add_file(self, path, is_fastq=False, Q=0):
         n = C.c_uint64(0)
         _hck(host_lib().kssd_batch_add_file(self.h, os.fsencode(path), int(is_fastq), Q, C.byref(n)))
@@ -424,6 +457,25 @@ class Batch:
 # ------------------------------------------------------------------------------------------------------
 # the device context
 # ------------------------------------------------------------------------------------------------------
+def device_count():
+    return gpu_lib().kssd_gpu_device_count()
+
+
+def dist_multi(devices, kmerlen, roff, rids, qoff, qids, planes=True):
+    """kssd_gpu_dist_multi: the query rows in len(devices) contiguous blocks, one per device (entries may repeat)"""
+    roff = np.ascontiguousarray(roff, dtype=np.uint64)
+    qoff = np.ascontiguousarray(qoff, dtype=np.uint64)
+    rids = np.ascontiguousarray(rids, dtype=np.uint32)
+    qids = np.ascontiguousarray(qids, dtype=np.uint32)
+    R, Q = len(roff) - 1, len(qoff) - 1
+    devs = (C.c_int * len(devices))(*devices)
+    shared = np.zeros((Q, R), dtype=np.uint32)
+    pl = [np.zeros((Q, R), dtype=np.float64) for _ in range(4)] if planes else [None] * 4
+    _gck(gpu_lib().kssd_gpu_dist_multi(devs, len(devices), kmerlen, roff.ctypes.data, rids.ctypes.data, R, qoff.ctypes.data,
+                                       qids.ctypes.data, Q, shared.ctypes.data, *[_ptr(p) for p in pl]))
+    return (shared, *pl) if planes else shared
+
+
 def _ptr(x):
     """device or host address of a numpy array / torch tensor / int / None"""
     if x is None:
@@ -448,6 +500,8 @@ class GpuCtx:
             _gck(gpu_lib().kssd_gpu_create(C.byref(self.h), C.byref(hdr), shuf.table.ctypes.data, device))
         self.info = GpuInfo()
         _gck(gpu_lib().kssd_gpu_get_info(self.h, C.byref(self.info)))
+        if DEFAULT_LDS_SORT_LIMIT:
+            self.set_lds_sort_limit(DEFAULT_LDS_SORT_LIMIT)
 
     def close(self):
         if getattr(self, "h", None):
@@ -582,6 +636,10 @@ class GpuCtx:
             gpu_lib().kssd_gpu_free(po)
             gpu_lib().kssd_gpu_free(pi)
         return ooff, oids
+
+    def set_lds_sort_limit(self, max_tuples):
+        """genomes staging more tuples than this take the global-memory dedup path (0 = default); results unchanged"""
+        _gck(gpu_lib().kssd_gpu_set_lds_sort_limit(self.h, max_tuples))
 
     def scan_stats(self, stream=None):
         """(positions that passed the stage-1 filter, positions that also passed the Bloom test) of the last scan"""

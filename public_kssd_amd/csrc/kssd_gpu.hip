@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "../../include/kssd_gpu.h"
@@ -78,6 +79,7 @@ struct SketchStatus {
 struct kssd_gpu_ctx {
     int device;
     int cu_count;
+    hipStream_t own_stream;  // non-blocking stream of the host-level calls (contexts on different host threads do not meet on the null stream)
     bool dist_only;  // created by kssd_gpu_create_for_dist: no sketch tables
     KssdParams P;
     uint8_t *d_T1;
@@ -106,6 +108,7 @@ struct kssd_gpu_ctx {
     double region_factor;
     uint32_t last_n_genomes;
     int last_launch_rc;
+    uint32_t lds_sort_limit;  // kssd_gpu_set_lds_sort_limit (0 = DEDUP_MAX_N)
     std::vector<uint64_t> h_reg_off;
     std::vector<uint32_t> h_big;  // genomes of the last batch that take the global-memory dedup path
     // the planned call (kssd_gpu_sketch_plan), executed phase by phase (kssd_gpu_sketch_phase)
@@ -121,6 +124,10 @@ struct kssd_gpu_ctx {
     } plan;
     std::vector<uint64_t> h_chunk_off;      // the planned batch's chunk offsets
     std::vector<uint64_t> dev_chunk_off, dev_reg_off;  // what d_chunk_off / d_reg_off hold (copies are skipped when unchanged)
+    // device-side buffers of the host-level sketch call (kssd_gpu_sketch_batch): grow-only
+    uint32_t *d_in_packed, *d_in_mask, *d_b_ids, *d_b_pos;
+    uint64_t *d_b_off;
+    size_t cap_in_packed, cap_in_mask, cap_b_ids, cap_b_pos, cap_b_off;
     uint32_t *d_big_alt;          // sort output | tile counts | 2 accumulators
     size_t cap_big_alt;
     void *d_big_tmp;              // rocPRIM temporary storage
@@ -176,6 +183,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
     c->P = P;
     c->region_factor = 2.0;
     c->cand_factor = 1.5;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     int rc = ctx_upload_tables(c, accepted);
     if (rc != KSSD_OK) { delete c; return rc; }
     if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) {
@@ -226,6 +234,7 @@ extern "C" int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int dev
     memset(&c->P, 0, sizeof c->P);
     c->P.k = kmerlen / 2;
     c->dist_only = true;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) { delete c; return KSSD_ERR_NOMEM; }
     for (int w = 0; w < 2; w++)
         for (int i = 0; i < EV_RING; i++) {
@@ -241,9 +250,11 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp, c->d_lane_valid};
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp, c->d_lane_valid,
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     for (int w = 0; w < 2; w++)
         for (int i = 0; i < EV_RING; i++) {
             hipEventDestroy(c->ev_a[w][i]);
@@ -264,6 +275,13 @@ extern "C" int kssd_gpu_get_info(const kssd_gpu_ctx *c, kssd_gpu_info *o)
 }
 
 extern "C" void kssd_gpu_free(void *p) { free(p); }
+
+extern "C" int kssd_gpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 0) return 0;
+    return n;
+}
 
 template <typename T>
 static int ensure(T **p, size_t *cap, size_t need, size_t slack = 0)
@@ -1135,8 +1153,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     c->h_reg_off.resize((size_t)n_genomes + 1);
     c->h_big.clear();
-    const uint32_t big_min_env = getenv("KSSD_DEV_BIG_MIN") ? (uint32_t)atoi(getenv("KSSD_DEV_BIG_MIN")) : 0u;  // tests only
-    uint32_t big_min = big_min_env ? big_min_env : DEDUP_MAX_N;
+    uint32_t big_min = c->lds_sort_limit && c->lds_sort_limit < DEDUP_MAX_N ? c->lds_sort_limit : DEDUP_MAX_N;
     if (with_pos && big_min > DEDUP_MAX_N / 2) big_min = DEDUP_MAX_N / 2;  // 8-byte keys: half as many fit the LDS sort
     uint64_t acc = 0, max_cap = 0, max_big = 0;
     for (uint32_t g = 0; g < n_genomes; g++) {
@@ -1245,11 +1262,13 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     case 4: rc = launch_scan<4>(c, a, grid, s, e0, e1); break;
     case 5: rc = launch_scan<5>(c, a, grid, s, e0, e1); break;
     case 6: {
-        static const int abl = getenv("KSSD_DEV_ABLATE") ? atoi(getenv("KSSD_DEV_ABLATE")) : 0;  // profiling only
-        if (abl == 1) rc = launch_scan<6, 1>(c, a, grid, s, e0, e1);
-        else if (abl == 2) rc = launch_scan<6, 2>(c, a, grid, s, e0, e1);
-        else if (abl == 3) rc = launch_scan<6, 3>(c, a, grid, s, e0, e1);
-        else rc = launch_scan<6>(c, a, grid, s, e0, e1);
+#ifdef KSSD_DEV  // development build only (libkssd_gpu_dev.so, `make tools`): ablated scans for profiles/scanbench
+        static const int abl = getenv("KSSD_DEV_ABLATE") ? atoi(getenv("KSSD_DEV_ABLATE")) : 0;
+        if (abl == 1) { rc = launch_scan<6, 1>(c, a, grid, s, e0, e1); break; }
+        if (abl == 2) { rc = launch_scan<6, 2>(c, a, grid, s, e0, e1); break; }
+        if (abl == 3) { rc = launch_scan<6, 3>(c, a, grid, s, e0, e1); break; }
+#endif
+        rc = launch_scan<6>(c, a, grid, s, e0, e1);
         break;
     }
     case 7: rc = launch_scan<7>(c, a, grid, s, e0, e1); break;
@@ -1328,6 +1347,13 @@ extern "C" int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *c, uint32_t *d_out_p
     return KSSD_OK;
 }
 
+extern "C" int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *c, uint32_t max_tuples)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    c->lds_sort_limit = max_tuples;
+    return KSSD_OK;
+}
+
 extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int64_t *bad_genome, void *stream)
 {
     if (!c) return KSSD_ERR_PARAM;
@@ -1340,12 +1366,14 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
     HIPCK(hipMemcpyAsync(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     if (total_ids) *total_ids = st.total_ids;
+#ifdef KSSD_DEV
     if (getenv("KSSD_DEV_TRACE"))
         fprintf(stderr, "[kssd_gpu] status: ids %llu, stage1 %llu, bloom %llu, cand_overflow %u (need %u of %llu), region_overflow %u "
                         "(need x%.2f, factor %.2f), out_overflow %u, capacity %u\n",
                 (unsigned long long)st.total_ids, (unsigned long long)st.n_stage1, (unsigned long long)st.n_bloom, st.cand_overflow,
                 st.cand_need, (unsigned long long)c->last_cand_cap, st.region_overflow, st.max_need_q8 / 256.0, c->region_factor,
                 st.out_overflow, st.capacity_genome_p1);
+#endif
     if (st.cand_overflow) {
         c->cand_floor = (uint64_t)st.cand_need + st.cand_need / 4 + 64;
         return KSSD_ERR_OVERFLOW;
@@ -1382,6 +1410,9 @@ extern "C" int kssd_gpu_scan_stats(kssd_gpu_ctx *c, uint64_t *stage1, uint64_t *
     return KSSD_OK;
 }
 
+// Host-level sketch call.  The device-side input and output buffers belong to the context and only ever grow, the
+// work runs on the context's own stream, and a caller that keeps its batch in page-locked memory (kssd_gpu_host_alloc)
+// gets plain DMA transfers: a sequence of calls then costs transfers and kernels, not allocations.
 static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask, const uint64_t *chunk_off,
                              uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                              uint32_t **out_pos, int64_t *bad_genome)
@@ -1391,64 +1422,65 @@ static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint
     *out_off = nullptr;
     *out_ids = nullptr;
     if (out_pos) *out_pos = nullptr;
+    hipStream_t s = c->own_stream;
     const uint64_t n_chunks = chunk_off[n_genomes];
-    const size_t pw = (size_t)n_chunks * KSSD_CHUNK_WORDS + KSSD_PACK_SLACK_WORDS;
-    const size_t mw = (size_t)n_chunks * KSSD_CHUNK_MASKW + KSSD_PACK_SLACK_WORDS;
-    uint32_t *d_p = nullptr, *d_m = nullptr, *d_ids = nullptr, *d_pos = nullptr;
-    uint64_t *d_off = nullptr;
-    int rc = KSSD_OK;
-    auto cleanup = [&]() {
-        if (d_p) hipFree(d_p);
-        if (d_m) hipFree(d_m);
-        if (d_ids) hipFree(d_ids);
-        if (d_pos) hipFree(d_pos);
-        if (d_off) hipFree(d_off);
-        c->d_out_pos = nullptr;
-    };
-#define BCK(x) do { if ((x) != hipSuccess) { rc = hip_fail(hipGetLastError(), #x, __LINE__); cleanup(); return rc; } } while (0)
-    BCK(hipMalloc(&d_p, pw * 4));
-    BCK(hipMalloc(&d_m, mw * 4));
-    BCK(hipMalloc(&d_off, ((size_t)n_genomes + 1) * 8));
-    BCK(hipMemset(d_p, 0, pw * 4));
-    BCK(hipMemset(d_m, 0, mw * 4));
+    const size_t pw = (size_t)n_chunks * KSSD_CHUNK_WORDS, mw = (size_t)n_chunks * KSSD_CHUNK_MASKW;
+    int rc;
+    if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, pw + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, mw + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_b_off, &c->cap_b_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if (n_chunks) {
-        BCK(hipMemcpy(d_p, packed, (size_t)n_chunks * KSSD_CHUNK_WORDS * 4, hipMemcpyHostToDevice));
-        BCK(hipMemcpy(d_m, mask, (size_t)n_chunks * KSSD_CHUNK_MASKW * 4, hipMemcpyHostToDevice));
+        HIPCK(hipMemcpyAsync(c->d_in_packed, packed, pw * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(c->d_in_mask, mask, mw * 4, hipMemcpyHostToDevice, s));
     }
+    HIPCK(hipMemsetAsync(c->d_in_packed + pw, 0, KSSD_PACK_SLACK_WORDS * 4, s));  // the slack behind the last chunk: no bases
+    HIPCK(hipMemsetAsync(c->d_in_mask + mw, 0, KSSD_PACK_SLACK_WORDS * 4, s));
     if (out_pos && !(flags & (KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS))) flags |= KSSD_SKETCH_FIRST_POS;
     if (!out_pos) flags &= ~(KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS);
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     uint64_t out_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * rate * 1.5) + 1024;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 12; attempt++) {
-        if (d_ids) { hipFree(d_ids); d_ids = nullptr; }
-        if (d_pos) { hipFree(d_pos); d_pos = nullptr; }
-        BCK(hipMalloc(&d_ids, (size_t)out_cap * 4));
+        if ((rc = ensure(&c->d_b_ids, &c->cap_b_ids, (size_t)out_cap)) != KSSD_OK) break;
         if (out_pos) {
-            BCK(hipMalloc(&d_pos, (size_t)out_cap * 4));
-            c->d_out_pos = d_pos;
+            if ((rc = ensure(&c->d_b_pos, &c->cap_b_pos, (size_t)out_cap)) != KSSD_OK) break;
+            c->d_out_pos = c->d_b_pos;
         }
-        rc = kssd_gpu_sketch_device(c, d_p, d_m, chunk_off, n_genomes, flags, min_occ, d_off, d_ids, out_cap, nullptr);
+        rc = kssd_gpu_sketch_device(c, c->d_in_packed, c->d_in_mask, chunk_off, n_genomes, flags, min_occ, c->d_b_off, c->d_b_ids,
+                                    out_cap, s);
         if (rc != KSSD_OK) break;
-        rc = kssd_gpu_sketch_status(c, &total, bad_genome, nullptr);
+        rc = kssd_gpu_sketch_status(c, &total, bad_genome, s);
         if (rc != KSSD_ERR_OVERFLOW) break;
         if (total > out_cap) out_cap = total + 1024;
     }
-    if (rc == KSSD_OK) {
-        uint64_t *h_off = (uint64_t *)malloc(((size_t)n_genomes + 1) * 8);
-        uint32_t *h_ids = (uint32_t *)malloc((size_t)(total ? total : 1) * 4);
-        uint32_t *h_pos = out_pos ? (uint32_t *)malloc((size_t)(total ? total : 1) * 4) : nullptr;
-        if (!h_off || !h_ids || (out_pos && !h_pos)) { free(h_off); free(h_ids); free(h_pos); cleanup(); return KSSD_ERR_NOMEM; }
-        BCK(hipMemcpy(h_off, d_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost));
-        if (total) BCK(hipMemcpy(h_ids, d_ids, (size_t)total * 4, hipMemcpyDeviceToHost));
-        if (total && out_pos) BCK(hipMemcpy(h_pos, d_pos, (size_t)total * 4, hipMemcpyDeviceToHost));
-        *out_off = h_off;
-        *out_ids = h_ids;
-        if (out_pos) *out_pos = h_pos;
-    }
-    cleanup();
-    return rc;
-#undef BCK
+    c->d_out_pos = nullptr;
+    if (rc != KSSD_OK) return rc;
+    uint64_t *h_off = (uint64_t *)malloc(((size_t)n_genomes + 1) * 8);
+    uint32_t *h_ids = (uint32_t *)malloc((size_t)(total ? total : 1) * 4);
+    uint32_t *h_pos = out_pos ? (uint32_t *)malloc((size_t)(total ? total : 1) * 4) : nullptr;
+    if (!h_off || !h_ids || (out_pos && !h_pos)) { free(h_off); free(h_ids); free(h_pos); return KSSD_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(h_off, c->d_b_off, ((size_t)n_genomes + 1) * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(h_ids, c->d_b_ids, (size_t)total * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && total && out_pos) e = hipMemcpyAsync(h_pos, c->d_b_pos, (size_t)total * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { free(h_off); free(h_ids); free(h_pos); return hip_fail(e, "sketch results to host", __LINE__); }
+    *out_off = h_off;
+    *out_ids = h_ids;
+    if (out_pos) *out_pos = h_pos;
+    return KSSD_OK;
+}
+
+// page-locked host memory for batches that travel by DMA (hipHostMalloc); NULL when it cannot be had
+extern "C" void *kssd_gpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void kssd_gpu_host_free(void *p)
+{
+    if (p) hipHostFree(p);
 }
 
 extern "C" int kssd_gpu_sketch_batch(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask,

@@ -11,10 +11,14 @@
 #include <dirent.h>
 #include <errno.h>
 #include <getopt.h>
+#include <pthread.h>
+#include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #ifdef _OPENMP
@@ -173,7 +177,7 @@ typedef struct {
         pipecmd[KSSD_PATHLEN];
     int nargs;
     char **args;
-    int device;
+    int device, gpus; /* first device, number of devices (--gpus / KSSD_GPUS) */
     unsigned long long seed;
 } dist_opt;
 
@@ -210,19 +214,24 @@ static void load_shuf(const dist_opt *o, kssd_shuf *s)
 /* ---------------------------------------------------------------------------------------------------
  * stage I on the GPU (run_stageI, command_dist.c:258-380)
  * ------------------------------------------------------------------------------------------------- */
-typedef struct {
-    uint64_t *off;
-    uint32_t *ids;
-    uint16_t *counts; /* -A: occurrences of every id */
-    uint64_t n_ids, cap_ids;
-    uint32_t n;
-    uint32_t hashsize;
-} csr_acc;
 
-static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *acc, filelist *fl, uint32_t first_file)
+/* One unit of stage-I work: a run of consecutive input files of one kind (FASTA or FASTQ), tokenised into one packed
+ * batch in page-locked memory; a device worker sketches it and leaves the genomes' ids in the reference's file order. */
+typedef struct job {
+    kssd_batch *b;
+    int is_fq, first_file, n_files;
+    uint64_t *off;    /* n_files + 1 */
+    uint32_t *ids;    /* slot order per genome */
+    uint16_t *counts; /* -A */
+    struct job *next;
+} job;
+
+static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize)
 {
+    kssd_batch *b = j->b;
+    const int is_fq = j->is_fq;
+    const uint32_t first_file = (uint32_t)j->first_file;
     uint32_t n = kssd_batch_n_genomes(b);
-    if (!n) return;
     uint32_t flags = is_fq ? (KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY) : (o->u ? KSSD_SKETCH_UNIQ : KSSD_SKETCH_FASTA);
     uint32_t min_occ = is_fq ? (uint32_t)o->kmerocrs : 1u;
     if (o->abundance) { /* mt_shortreads2koc (iseq2comem.c:554-615): every k-mer kept, -n not looked at, crowding is fatal */
@@ -237,9 +246,9 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     const uint64_t *co = kssd_batch_chunk_off(b);
     for (uint32_t g = 0; g < n; g++)
         if (co[g + 1] - co[g] >= (1ull << 20)) with_pos = 0;
-    int rc = with_pos ? kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
+    int rc = with_pos ? kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
                                                   min_occ, &off, &ids, &pos, &bad)
-                      : kssd_gpu_sketch_batch(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
+                      : kssd_gpu_sketch_batch(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
                                               min_occ, &off, &ids, &bad);
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
@@ -249,7 +258,7 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
     uint64_t *aoff = NULL;
     uint32_t *aids = NULL, *acnt = NULL;
     if (o->abundance) {
-        gck(kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n,
+        gck(kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n,
                                       KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &aoff, &aids,
                                       &acnt, &bad),
             "sketch (abundances)");
@@ -259,17 +268,12 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
      * a genome of 2^32 positions and more, in ascending id order: exact unless two of its ids probe the same slot) */
 #pragma omp parallel for schedule(dynamic, 16)
     for (uint32_t g = 0; g < n; g++) {
-        if (with_pos) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], acc->hashsize);
-        else kssd_slot_order(ids + off[g], off[g + 1] - off[g], acc->hashsize);
+        if (with_pos) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], hashsize);
+        else kssd_slot_order(ids + off[g], off[g + 1] - off[g], hashsize);
     }
-    uint64_t add = off[n];
-    if (acc->n_ids + add > acc->cap_ids) {
-        acc->cap_ids = (acc->n_ids + add) * 2 + 1024;
-        acc->ids = realloc(acc->ids, acc->cap_ids * 4);
-        if (o->abundance) acc->counts = realloc(acc->counts, acc->cap_ids * 2);
-    }
-    memcpy(acc->ids + acc->n_ids, ids, add * 4);
     if (o->abundance) {
+        uint16_t *counts = malloc((size_t)(off[n] ? off[n] : 1) * 2);
+        if (!counts) die(ENOMEM, "out of memory");
         int bad_follow = 0;
 #pragma omp parallel for schedule(dynamic, 16) reduction(| : bad_follow)
         for (uint32_t g = 0; g < n; g++) {
@@ -277,21 +281,88 @@ static void flush_batch(kssd_batch *b, int is_fq, const dist_opt *o, csr_acc *ac
             if (aoff[g + 1] - aoff[g] != m) { bad_follow |= 1; continue; }
             uint16_t *c16 = malloc((m ? m : 1) * 2);
             for (uint64_t i = 0; i < m; i++) c16[i] = (uint16_t)acnt[aoff[g] + i]; /* saturated at 65535 on the device */
-            bad_follow |= kssd_counts_follow(aids + aoff[g], c16, ids + off[g], acc->counts + acc->n_ids + off[g], m) != 0;
+            bad_follow |= kssd_counts_follow(aids + aoff[g], c16, ids + off[g], counts + off[g], m) != 0;
             free(c16);
         }
         if (bad_follow) die(EIO, "sketch (abundances): the two passes disagree");
         kssd_gpu_free(aoff);
         kssd_gpu_free(aids);
         kssd_gpu_free(acnt);
+        j->counts = counts;
     }
-    for (uint32_t g = 0; g < n; g++) acc->off[acc->n + g + 1] = acc->n_ids + off[g + 1];
-    acc->n += n;
-    acc->n_ids += add;
-    kssd_gpu_free(off);
-    kssd_gpu_free(ids);
+    j->off = off;
+    j->ids = ids;
     kssd_gpu_free(pos);
-    kssd_batch_clear(b);
+}
+
+/* the stage-I pipeline: the main thread reads and tokenises waves of files on all host threads; device workers (two per
+ * GPU, each with its own context and stream, so that one batch's transfer runs under the other's kernels) sketch the
+ * batches; batches are recycled through a small pool of page-locked buffers, which also bounds what is in flight */
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    job *todo_head, *todo_tail; /* tokenised, waiting for a device */
+    job *done;                  /* sketched */
+    kssd_batch **pool;          /* free batches */
+    int n_pool, closed;
+    const dist_opt *o;
+    filelist *fl;
+    uint32_t hashsize;
+    kssd_shuf_hdr hdr;
+    const int32_t *table;
+    double t_gpu; /* summed over the workers: seconds inside the sketch calls */
+} pipeline;
+
+typedef struct {
+    pipeline *pl;
+    int device;
+    pthread_t th;
+} worker;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void *worker_main(void *arg)
+{
+    worker *w = arg;
+    pipeline *pl = w->pl;
+    kssd_gpu_ctx *ctx = NULL;
+    gck(kssd_gpu_create(&ctx, &pl->hdr, pl->table, w->device), "kssd_gpu_create");
+    for (;;) {
+        pthread_mutex_lock(&pl->mu);
+        while (!pl->todo_head && !pl->closed) pthread_cond_wait(&pl->cv, &pl->mu);
+        job *j = pl->todo_head;
+        if (j) {
+            pl->todo_head = j->next;
+            if (!pl->todo_head) pl->todo_tail = NULL;
+        }
+        pthread_mutex_unlock(&pl->mu);
+        if (!j) break;
+        const double t0 = now_s();
+        process_job(ctx, j, pl->o, pl->fl, pl->hashsize);
+        const double dt = now_s() - t0;
+        kssd_batch_clear(j->b);
+        pthread_mutex_lock(&pl->mu);
+        pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
+        j->b = NULL;
+        j->next = pl->done;
+        pl->done = j;
+        pl->t_gpu += dt;
+        pthread_cond_broadcast(&pl->cv);
+        pthread_mutex_unlock(&pl->mu);
+    }
+    kssd_gpu_destroy(ctx);
+    return NULL;
+}
+
+static int cmp_job(const void *a, const void *b)
+{
+    const job *x = *(job *const *)a, *y = *(job *const *)b;
+    return x->first_file < y->first_file ? -1 : x->first_file > y->first_file;
 }
 
 /* dist --byread (run_stageI command_dist.c:267-273 + reads2mco iseq2comem.c:78-186): every input file is one genome on
@@ -370,68 +441,168 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         die(EINVAL, "get_hashsz(): primer_ind out of range(0 ~ 24): this might caused by too small or too large k (k=%d, level=%d)", shuf.k, shuf.drlevel);
     printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
-    gck(kssd_gpu_create(&g_ctx, &hdr, shuf.table, o->device), "kssd_gpu_create");
-    kssd_shuf_release(&shuf);
-
-    csr_acc acc = {0};
-    acc.hashsize = d.hashsize;
-    acc.off = calloc((size_t)fl->n + 1, sizeof(uint64_t));
-    kssd_batch *cur = kssd_batch_create();
-    const uint64_t max_chunks = 1ull << 19; /* ~2 Gbases per device batch */
-    int threads = o->p > 0 ? o->p : 1;
-    int cur_fq = -1;
-    uint32_t first_file = 0;
-    int done = 0;
-    for (int i0 = 0; i0 < fl->n; i0 += threads) {
-        int i1 = i0 + threads < fl->n ? i0 + threads : fl->n;
-        kssd_batch **tb = calloc((size_t)(i1 - i0), sizeof(kssd_batch *));
-        int *trc = calloc((size_t)(i1 - i0), sizeof(int));
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-        for (int i = i0; i < i1; i++) { /* gunzip + tokenise on host threads, one file each */
-            tb[i - i0] = kssd_batch_create();
-            uint64_t lines = 0;
-            int fq = has_fmt(fl->path[i], fq_fmt);
-            /* -A reads the bases only: no quality filter (iseq2comem.c:566-573) */
-            trc[i - i0] = kssd_batch_add_file(tb[i - i0], fl->path[i], fq && o->abundance ? 2 : fq, o->kmerqlty, &lines);
-            if (fq && trc[i - i0] == 0 && !o->abundance) printf("%llu reads detected\n", (unsigned long long)lines);
-        }
-        for (int i = i0; i < i1; i++) {
-            if (trc[i - i0]) die(EIO, "%s: %s", fl->path[i], kssd_host_strerror(trc[i - i0]));
-            int fq = has_fmt(fl->path[i], fq_fmt);
-            if (cur_fq != -1 && (fq != cur_fq || kssd_batch_n_chunks(cur) + kssd_batch_n_chunks(tb[i - i0]) > max_chunks)) {
-                flush_batch(cur, cur_fq, o, &acc, fl, first_file);
-                first_file = (uint32_t)i;
-            }
-            cur_fq = fq;
-            if (kssd_batch_append(cur, tb[i - i0])) die(ENOMEM, "out of memory");
-            kssd_batch_destroy(tb[i - i0]);
-            printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i]);
-        }
-        free(tb);
-        free(trc);
+    const double t_start = now_s();
+    int n_dev = o->gpus > 0 ? o->gpus : 1;
+    {
+        const int have = kssd_gpu_device_count();
+        if (have <= 0) die(ENODEV, "kssd_gpu_create: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
+        if (o->device + n_dev > have) die(ENODEV, "--gpus %d from device %d: only %d device(s) visible", n_dev, o->device, have);
     }
-    if (cur_fq != -1) flush_batch(cur, cur_fq, o, &acc, fl, first_file);
-    printf("\n");
-    kssd_batch_destroy(cur);
+    const int n_workers = 2 * n_dev;
+    const int threads = o->p > 0 ? o->p : 1;
+    pipeline pl;
+    memset(&pl, 0, sizeof pl);
+    pthread_mutex_init(&pl.mu, NULL);
+    pthread_cond_init(&pl.cv, NULL);
+    pl.o = o;
+    pl.fl = fl;
+    pl.hashsize = d.hashsize;
+    pl.hdr = hdr;
+    pl.table = shuf.table;
+    const int n_batches = n_workers + 1; /* one being filled, one per worker */
+    pl.pool = calloc((size_t)n_batches, sizeof *pl.pool);
+    for (int i = 0; i < n_batches; i++) {
+        pl.pool[i] = kssd_batch_create_ex(kssd_gpu_host_alloc, kssd_gpu_host_free);
+        if (!pl.pool[i]) die(ENOMEM, "out of memory");
+    }
+    pl.n_pool = n_batches;
+    worker *ws = calloc((size_t)n_workers, sizeof *ws);
+    for (int i = 0; i < n_workers; i++) {
+        ws[i].pl = &pl;
+        ws[i].device = o->device + i % n_dev;
+        if (pthread_create(&ws[i].th, NULL, worker_main, &ws[i])) die(EAGAIN, "pthread_create");
+    }
 
+    /* a device batch: at most ~0.5 Gbases (so that several are in flight and the transfers hide under the kernels) */
+    const uint64_t max_chunks = 1ull << 17;
+    double t_read = 0, t_tok = 0;
+    uint64_t n_bytes = 0;
+    int done = 0, n_jobs = 0;
+    for (int i0 = 0; i0 < fl->n; i0 += threads) {
+        const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
+        unsigned char **txt = calloc((size_t)nw, sizeof *txt);
+        size_t *len = calloc((size_t)nw, sizeof *len);
+        int *trc = calloc((size_t)nw, sizeof *trc);
+        uint64_t *lines = calloc((size_t)nw, sizeof *lines);
+        double t0 = now_s();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (int i = 0; i < nw; i++) trc[i] = kssd_slurp(fl->path[i0 + i], &txt[i], &len[i]); /* read + gunzip, one file each */
+        t_read += now_s() - t0;
+        for (int i = 0; i < nw; i++) {
+            if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
+            n_bytes += len[i];
+        }
+        /* runs of one kind that fit a device batch */
+        for (int r0 = 0; r0 < nw;) {
+            const int fq = has_fmt(fl->path[i0 + r0], fq_fmt);
+            uint64_t chunks = 0;
+            int r1 = r0;
+            while (r1 < nw && has_fmt(fl->path[i0 + r1], fq_fmt) == fq) {
+                const uint64_t c = (len[r1] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES;
+                if (r1 > r0 && chunks + c > max_chunks) break;
+                chunks += c;
+                r1++;
+            }
+            pthread_mutex_lock(&pl.mu);
+            while (pl.n_pool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
+            kssd_batch *b = pl.pool[--pl.n_pool];
+            pthread_mutex_unlock(&pl.mu);
+            uint64_t *maxpos = malloc((size_t)(r1 - r0) * sizeof *maxpos);
+            for (int i = r0; i < r1; i++) maxpos[i - r0] = len[i];
+            uint32_t first = 0;
+            if (kssd_batch_reserve(b, (uint32_t)(r1 - r0), maxpos, &first)) die(ENOMEM, "out of memory");
+            free(maxpos);
+            t0 = now_s();
+            /* -A reads the bases only: no quality filter (iseq2comem.c:566-573) */
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+            for (int i = r0; i < r1; i++) {
+                trc[i] = kssd_batch_fill_text(b, first + (uint32_t)(i - r0), fq && o->abundance ? 2 : fq, txt[i], len[i], o->kmerqlty, &lines[i]);
+                if (trc[i] == KSSD_HOST_ERR_EMPTY) trc[i] = 0; /* an empty file is an empty genome here */
+                free(txt[i]);
+                txt[i] = NULL;
+            }
+            t_tok += now_s() - t0;
+            for (int i = r0; i < r1; i++) {
+                if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
+                if (fq && !o->abundance) printf("%llu reads detected\n", (unsigned long long)lines[i]);
+                printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + i]);
+            }
+            job *j = calloc(1, sizeof *j);
+            j->b = b;
+            j->is_fq = fq;
+            j->first_file = i0 + r0;
+            j->n_files = r1 - r0;
+            pthread_mutex_lock(&pl.mu);
+            if (pl.todo_tail) pl.todo_tail->next = j;
+            else pl.todo_head = j;
+            pl.todo_tail = j;
+            pthread_cond_broadcast(&pl.cv);
+            pthread_mutex_unlock(&pl.mu);
+            n_jobs++;
+            r0 = r1;
+        }
+        free(txt);
+        free(len);
+        free(trc);
+        free(lines);
+    }
+    pthread_mutex_lock(&pl.mu);
+    pl.closed = 1;
+    pthread_cond_broadcast(&pl.cv);
+    pthread_mutex_unlock(&pl.mu);
+    for (int i = 0; i < n_workers; i++) pthread_join(ws[i].th, NULL);
+    printf("\n");
+    kssd_shuf_release(&shuf);
+    const double t_sketched = now_s();
+
+    /* the jobs' results in file order */
+    job **jl = calloc((size_t)(n_jobs ? n_jobs : 1), sizeof *jl);
+    int nj = 0;
+    for (job *j = pl.done; j; j = j->next) jl[nj++] = j;
+    if (nj != n_jobs) die(EIO, "stage I: %d of %d batches came back", nj, n_jobs);
+    qsort(jl, (size_t)nj, sizeof *jl, cmp_job);
+    uint64_t total = 0;
+    for (int i = 0; i < nj; i++) total += jl[i]->off[jl[i]->n_files];
     kssd_sketchset s = {0};
+    s.off = calloc((size_t)fl->n + 1, sizeof(uint64_t));
+    s.ids = malloc((size_t)(total ? total : 1) * 4);
+    s.counts = o->abundance ? malloc((size_t)(total ? total : 1) * 2) : NULL;
+    if (!s.off || !s.ids || (o->abundance && !s.counts)) die(ENOMEM, "out of memory");
+    uint64_t at = 0;
+    for (int i = 0; i < nj; i++) {
+        job *j = jl[i];
+        const uint64_t m = j->off[j->n_files];
+        for (int g = 0; g < j->n_files; g++) s.off[j->first_file + g + 1] = at + j->off[g + 1];
+        memcpy(s.ids + at, j->ids, (size_t)m * 4);
+        if (o->abundance) memcpy(s.counts + at, j->counts, (size_t)m * 2);
+        at += m;
+        kssd_gpu_free(j->off);
+        kssd_gpu_free(j->ids);
+        free(j->counts);
+        free(j);
+    }
+    free(jl);
+    for (int i = 0; i < pl.n_pool; i++) kssd_batch_destroy(pl.pool[i]);
+    free(pl.pool);
+    free(ws);
     s.shuf_id = (uint32_t)hdr.id;
     s.kmerlen = d.kmerlen;
     s.dim_rd_len = d.dim_rd_len;
     s.comp_num = d.comp_num;
     s.n = (uint32_t)fl->n;
-    s.off = acc.off;
-    s.ids = acc.ids ? acc.ids : calloc(1, 4);
     s.names = fl->path;
     s.koc = o->abundance;
-    s.counts = o->abundance ? (acc.counts ? acc.counts : calloc(1, 2)) : NULL;
     int rc = kssd_sketchset_write(&s, outdir, d.hashsize, 0); /* already in slot order */
     if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
-    free(acc.off);
+    free(s.off);
     free(s.ids);
     free(s.counts);
-    kssd_gpu_destroy(g_ctx);
-    g_ctx = NULL;
+    if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
+        fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
+                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
+                        "\"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
+                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, t_read, t_tok,
+                pl.t_gpu, now_s() - t_sketched);
 }
 
 /* stage II (run_stageII, command_dist.c:381-417): the index FILES are for the reference binary; our own search
@@ -465,28 +636,40 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
     snprintf(skf, sizeof skf, "%s/sharedk_ct.dat", o->outdir);
     snprintf(distf, sizeof distf, "%s/distance.out", o->outdir);
     const size_t cells = (size_t)ref.n * qry.n;
-    uint32_t *shared = malloc((cells ? cells : 1) * 4);
-    if (!shared) die(ENOMEM, "out of memory for %zu pairs", cells);
+    /* the count matrix lives in the file itself, mapped like the reference maps it (command_dist.c:741-748): Q x R may
+     * exceed the host's memory, the device works it off in row tiles (kssd_gpu_dist) */
+    uint32_t *shared = NULL;
+    int skfd = -1;
     if (o->skf[0]) { /* -f: reuse a kept shared-k-mer file (command_dist.c:735-738) */
-        FILE *f = fopen(o->skf, "rb");
-        if (!f || fread(shared, 4, cells, f) != cells) die(EIO, "open %s failed", o->skf);
-        fclose(f);
+        skfd = open(o->skf, O_RDONLY);
+        struct stat st;
+        if (skfd < 0 || fstat(skfd, &st) != 0 || (size_t)st.st_size != cells * 4) die(EIO, "open %s failed", o->skf);
+        if (cells) shared = mmap(NULL, cells * 4, PROT_READ, MAP_PRIVATE, skfd, 0);
+        if (cells && shared == MAP_FAILED) die(errno, "mmap %s", o->skf);
     } else {
         if (access(skf, F_OK) == 0) die(EEXIST, " mco_cbdco_nobin_dist():%s", skf); /* the reference refuses to overwrite */
         printf("disf_sz=%zu\trefnum=%u\tqrynum=%u\n", cells * 4, ref.n, qry.n);
-        gck(kssd_gpu_create_for_dist(&g_ctx, qry.kmerlen, o->device), "kssd_gpu_create_for_dist");
-        gck(kssd_gpu_dist(g_ctx, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
-        kssd_gpu_destroy(g_ctx);
-        g_ctx = NULL;
-        FILE *f = fopen(skf, "wb");
-        if (!f || fwrite(shared, 4, cells, f) != cells) die(EIO, "mco_cbdco_nobin_dist()::%s", skf);
-        fclose(f);
+        skfd = open(skf, O_RDWR | O_CREAT, 0600);
+        if (skfd < 0 || ftruncate(skfd, (off_t)(cells * 4)) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+        if (cells) shared = mmap(NULL, cells * 4, PROT_READ | PROT_WRITE, MAP_SHARED, skfd, 0);
+        if (cells && shared == MAP_FAILED) die(errno, "mmap %s", skf);
+        int n_dev = o->gpus > 0 ? o->gpus : 1;
+        const int have = kssd_gpu_device_count();
+        if (have <= 0) die(ENODEV, "kssd_gpu_create_for_dist: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
+        if (o->device + n_dev > have) die(ENODEV, "--gpus %d from device %d: only %d device(s) visible", n_dev, o->device, have);
+        int *devs = malloc((size_t)n_dev * sizeof *devs);
+        for (int i = 0; i < n_dev; i++) devs[i] = o->device + i;
+        /* query rows in contiguous blocks, one per device; every device indexes all references (command_dist.c:774-785) */
+        gck(kssd_gpu_dist_multi(devs, n_dev, qry.kmerlen, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
+        free(devs);
+        if (cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
     }
     kssd_print_opt po = {o->metric, o->outfields, o->correction, o->mut_dist_max, o->num_neigb, o->p};
     if ((rc = kssd_distance_print(distf, shared, &ref, &qry, &po)) != 0)
         die(rc == KSSD_HOST_ERR_PARAM ? EINVAL : EIO, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, ref.n);
+    if (cells && shared) munmap(shared, cells * 4);
+    if (skfd >= 0) close(skfd);
     if (!o->keep_skf && !o->skf[0]) remove(skf);
-    free(shared);
     kssd_sketchset_release(&ref);
     kssd_sketchset_release(&qry);
 }
@@ -548,13 +731,14 @@ static int cmd_dist(int argc, char **argv)
     o.k = 8; o.dr_level = 2; o.kmerocrs = 1; o.mut_dist_max = 1; o.outfields = 2;
     strcpy(o.outdir, ".");
     o.device = getenv("KSSD_DEVICE") ? atoi(getenv("KSSD_DEVICE")) : 0;
+    o.gpus = getenv("KSSD_GPUS") ? atoi(getenv("KSSD_GPUS")) : 1; /* extension: devices device .. device+gpus-1 */
     static struct option lo[] = {
         {"halfKmerlength", 1, 0, 'k'}, {"threadN", 1, 0, 'p'},      {"list", 1, 0, 'l'},       {"DimRdcLevel", 1, 0, 'L'},
         {"maxMemory", 1, 0, 'm'},      {"LstKmerOcrs", 1, 0, 'n'},  {"quality", 1, 0, 'Q'},    {"reference_dir", 1, 0, 'r'},
         {"outdir", 1, 0, 'o'},         {"neighborN_max", 1, 0, 'N'}, {"mutDist_max", 1, 0, 'D'}, {"metric", 1, 0, 'M'},
         {"outfields", 1, 0, 'O'},      {"correction", 1, 0, 333},   {"abundance", 0, 0, 'A'},  {"dedup", 0, 0, 'u'},
         {"keepcofile", 0, 0, 888},     {"pipecmd", 1, 0, 'P'},      {"keepskf", 0, 0, 777},    {"skf", 1, 0, 'f'},
-        {"byread", 0, 0, 555},         {"seed", 1, 0, 998},         {0, 0, 0, 0}};
+        {"byread", 0, 0, 555},         {"seed", 1, 0, 998},         {"gpus", 1, 0, 997},       {0, 0, 0, 0}};
     if (argc < 2) die(EINVAL, "usage: kssd dist [-L <.shuf|level>] [-k K] [-r <reference>] [-o <outdir>] [<query> ...]");
     int c;
     while ((c = getopt_long(argc, argv, "k:p:l:L:m:n:Q:r:o:N:D:M:O:AuP:f:", lo, NULL)) != -1) {
@@ -590,9 +774,11 @@ static int cmd_dist(int argc, char **argv)
         case 'f': snprintf(o.skf, sizeof o.skf, "%s", optarg); break;
         case 555: o.byread = 1; break;
         case 998: o.seed = strtoull(optarg, NULL, 10); break;
+        case 997: o.gpus = atoi(optarg); break;
         default: die(EINVAL, "dist: unknown option");
         }
     }
+    if (o.gpus < 1) die(EINVAL, "--gpus: at least one device");
     if (o.p == 0) {
 #ifdef _OPENMP
         o.p = omp_get_num_procs();

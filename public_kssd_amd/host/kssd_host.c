@@ -156,12 +156,20 @@ struct kssd_batch {
     uint64_t *chunk_off; /* n_genomes + 1 */
     uint64_t *n_pos;     /* per genome */
     uint32_t n_genomes, cap_genomes;
+    void *(*alloc)(size_t);  /* where packed / mask live: NULL = malloc, else e.g. page-locked memory of the GPU runtime */
+    void (*release)(void *);
 };
 
-kssd_batch *kssd_batch_create(void)
+kssd_batch *kssd_batch_create(void) { return kssd_batch_create_ex(NULL, NULL); }
+
+kssd_batch *kssd_batch_create_ex(void *(*alloc)(size_t), void (*release)(void *))
 {
     kssd_batch *b = calloc(1, sizeof *b);
     if (!b) return NULL;
+    if (alloc && release) {
+        b->alloc = alloc;
+        b->release = release;
+    }
     b->cap_genomes = 16;
     b->chunk_off = calloc(b->cap_genomes + 1, sizeof(uint64_t));
     b->n_pos = calloc(b->cap_genomes, sizeof(uint64_t));
@@ -175,8 +183,13 @@ kssd_batch *kssd_batch_create(void)
 void kssd_batch_destroy(kssd_batch *b)
 {
     if (!b) return;
-    free(b->packed);
-    free(b->mask);
+    if (b->release) {
+        if (b->packed) b->release(b->packed);
+        if (b->mask) b->release(b->mask);
+    } else {
+        free(b->packed);
+        free(b->mask);
+    }
     free(b->chunk_off);
     free(b->n_pos);
     free(b);
@@ -184,8 +197,10 @@ void kssd_batch_destroy(kssd_batch *b)
 
 void kssd_batch_clear(kssd_batch *b)
 {
-    if (b->packed) memset(b->packed, 0, ((size_t)b->cap_chunks * CHUNK_WORDS + SLACK_WORDS) * 4);
-    if (b->mask) memset(b->mask, 0, ((size_t)b->cap_chunks * CHUNK_MASKW + SLACK_WORDS) * 4);
+    /* everything past n_chunks is zero already (growth zeroes new memory, every writer stays inside its genome) */
+    uint64_t used = b->n_chunks + 1 < b->cap_chunks ? b->n_chunks + 1 : b->cap_chunks;
+    if (b->packed) memset(b->packed, 0, (size_t)used * CHUNK_WORDS * 4);
+    if (b->mask) memset(b->mask, 0, (size_t)used * CHUNK_MASKW * 4);
     b->n_chunks = 0;
     b->n_genomes = 0;
     b->chunk_off[0] = 0;
@@ -199,11 +214,32 @@ static int batch_reserve_chunks(kssd_batch *b, uint64_t need)
     size_t pw_old = b->packed ? (size_t)b->cap_chunks * CHUNK_WORDS + SLACK_WORDS : 0;
     size_t mw_old = b->mask ? (size_t)b->cap_chunks * CHUNK_MASKW + SLACK_WORDS : 0;
     size_t pw = (size_t)nc * CHUNK_WORDS + SLACK_WORDS, mw = (size_t)nc * CHUNK_MASKW + SLACK_WORDS;
-    uint32_t *p = realloc(b->packed, pw * 4);
+    uint32_t *p, *m;
+    if (b->alloc) { /* no realloc for foreign memory: new block, copy what is in use, release the old one */
+        p = b->alloc(pw * 4);
+        if (!p) return KSSD_HOST_ERR_NOMEM;
+        if (b->packed) {
+            memcpy(p, b->packed, pw_old * 4);
+            b->release(b->packed);
+        }
+        b->packed = p;
+        memset(p + pw_old, 0, (pw - pw_old) * 4);
+        m = b->alloc(mw * 4);
+        if (!m) return KSSD_HOST_ERR_NOMEM;
+        if (b->mask) {
+            memcpy(m, b->mask, mw_old * 4);
+            b->release(b->mask);
+        }
+        b->mask = m;
+        memset(m + mw_old, 0, (mw - mw_old) * 4);
+        b->cap_chunks = nc;
+        return KSSD_HOST_OK;
+    }
+    p = realloc(b->packed, pw * 4);
     if (!p) return KSSD_HOST_ERR_NOMEM;
     b->packed = p;
     memset(p + pw_old, 0, (pw - pw_old) * 4);
-    uint32_t *m = realloc(b->mask, mw * 4);
+    m = realloc(b->mask, mw * 4);
     if (!m) return KSSD_HOST_ERR_NOMEM;
     b->mask = m;
     memset(m + mw_old, 0, (mw - mw_old) * 4);
@@ -232,11 +268,14 @@ typedef struct {
     uint64_t base_pos; /* first position of this genome in the batch */
     uint64_t p;        /* positions written so far */
     int pending_break; /* a run-breaking byte was seen since the last base */
+    uint64_t limit;    /* fixed mode (kssd_batch_fill_text): the genome's reserved positions; 0 = growing mode */
+    uint32_t genome;   /* fixed mode: which genome */
 } gwriter;
 
 static inline int gw_room(gwriter *w)
 {
     /* make sure position base_pos + p is inside the buffers */
+    if (w->limit) return w->p < w->limit ? KSSD_HOST_OK : KSSD_HOST_ERR_PARAM; /* reserved and zeroed up front */
     uint64_t chunk = (w->base_pos + w->p) / CHUNK_BASES;
     if (chunk >= w->b->cap_chunks) return batch_reserve_chunks(w->b, chunk + 1);
     return KSSD_HOST_OK;
@@ -267,11 +306,28 @@ static void gw_start(gwriter *w, kssd_batch *b)
     w->base_pos = b->n_chunks * CHUNK_BASES;
     w->p = 0;
     w->pending_break = 0;
+    w->limit = 0;
+    w->genome = 0;
+}
+
+static void gw_start_fixed(gwriter *w, kssd_batch *b, uint32_t g)
+{
+    w->b = b;
+    w->base_pos = b->chunk_off[g] * CHUNK_BASES;
+    w->p = 0;
+    w->pending_break = 0;
+    w->limit = (b->chunk_off[g + 1] - b->chunk_off[g]) * CHUNK_BASES;
+    if (!w->limit) w->limit = 1; /* an empty reservation: nothing may be written */
+    w->genome = g;
 }
 
 static void gw_finish(gwriter *w)
 {
     kssd_batch *b = w->b;
+    if (w->limit) { /* the layout was fixed by kssd_batch_reserve */
+        b->n_pos[w->genome] = w->p;
+        return;
+    }
     uint64_t chunks = (w->p + CHUNK_BASES - 1) / CHUNK_BASES;
     b->n_pos[b->n_genomes] = w->p;
     b->n_chunks += chunks;
@@ -283,6 +339,13 @@ static void gw_finish(gwriter *w)
 static void gw_abort(gwriter *w)
 {
     kssd_batch *b = w->b;
+    if (w->limit) {
+        const uint64_t c0 = b->chunk_off[w->genome], c1 = b->chunk_off[w->genome + 1];
+        memset(b->packed + c0 * CHUNK_WORDS, 0, (size_t)(c1 - c0) * CHUNK_WORDS * 4);
+        memset(b->mask + c0 * CHUNK_MASKW, 0, (size_t)(c1 - c0) * CHUNK_MASKW * 4);
+        b->n_pos[w->genome] = 0;
+        return;
+    }
     uint64_t c0 = b->n_chunks, c1 = (w->base_pos + w->p + CHUNK_BASES - 1) / CHUNK_BASES;
     if (c1 > b->cap_chunks) c1 = b->cap_chunks;
     if (c1 > c0) {
@@ -293,46 +356,55 @@ static void gw_abort(gwriter *w)
 
 /* byte classes of the FASTA scanner (iseq2comem.c:213-242, Basemap global_basic.c:64-71) */
 enum { C_A = 0, C_C = 1, C_G = 2, C_T = 3, C_SKIP = 4, C_HEADER = 5, C_BREAK = 6 };
-static unsigned char fa_class[256];
-static int fa_class_ready = 0;
+/* constant table (every byte not named is C_BREAK = 6): no lazy initialisation, the tokenisers run on many threads */
+#define B6 C_BREAK
+#define B6x8 B6, B6, B6, B6, B6, B6, B6, B6
+#define B6x16 B6x8, B6x8
+static const unsigned char fa_class[256] = {
+    /* 0x00 */ B6x8, B6, B6, C_SKIP /* \n */, B6, B6, C_SKIP /* \r */, B6, B6,
+    /* 0x10 */ B6x16,
+    /* 0x20 */ B6x16,
+    /* 0x30 */ B6x8, B6, B6, B6, B6, B6, B6, C_HEADER /* > */, B6,
+    /* 0x40 */ B6, C_A, B6, C_C, B6, B6, B6, C_G, B6x8,
+    /* 0x50 */ B6, B6, B6, B6, C_T, B6, B6, B6, B6x8,
+    /* 0x60 */ B6, C_A, B6, C_C, B6, B6, B6, C_G, B6x8,
+    /* 0x70 */ B6, B6, B6, B6, C_T, B6, B6, B6, B6x8,
+    /* 0x80 */ B6x16, B6x16, B6x16, B6x16, B6x16, B6x16, B6x16, B6x16};
+#undef B6x16
+#undef B6x8
+#undef B6
 
-static void fa_class_init(void)
+static int tok_fasta(gwriter *w, const unsigned char *text, size_t n)
 {
-    for (int i = 0; i < 256; i++) fa_class[i] = C_BREAK;
-    fa_class['A'] = fa_class['a'] = C_A;
-    fa_class['C'] = fa_class['c'] = C_C;
-    fa_class['G'] = fa_class['g'] = C_G;
-    fa_class['T'] = fa_class['t'] = C_T;
-    fa_class['\n'] = fa_class['\r'] = C_SKIP;
-    fa_class['>'] = C_HEADER;
-    fa_class_ready = 1;
+    int rc;
+    if (n == 0) return KSSD_HOST_ERR_EMPTY;
+    for (size_t i = 0; i < n; i++) {
+        unsigned cls = fa_class[text[i]];
+        if (cls < 4) {
+            if ((rc = gw_base(w, cls)) != 0) { gw_abort(w); return rc; }
+        } else if (cls == C_SKIP) {
+            /* line ends are transparent: k-mers run across them */
+        } else if (cls == C_HEADER) {
+            const unsigned char *nl = memchr(text + i, '\n', n - i);
+            if (!nl) { gw_abort(w); return KSSD_HOST_ERR_HEADER; }
+            i = (size_t)(nl - text);
+            w->pending_break = 1;
+        } else {
+            w->pending_break = 1;
+        }
+    }
+    gw_finish(w);
+    return KSSD_HOST_OK;
 }
 
 int kssd_batch_add_fasta(kssd_batch *b, const unsigned char *text, size_t n)
 {
-    if (!fa_class_ready) fa_class_init();
     if (n == 0) return KSSD_HOST_ERR_EMPTY;
     int rc = batch_begin(b);
     if (rc) return rc;
     gwriter w;
     gw_start(&w, b);
-    for (size_t i = 0; i < n; i++) {
-        unsigned cls = fa_class[text[i]];
-        if (cls < 4) {
-            if ((rc = gw_base(&w, cls)) != 0) { gw_abort(&w); return rc; }
-        } else if (cls == C_SKIP) {
-            /* line ends are transparent: k-mers run across them */
-        } else if (cls == C_HEADER) {
-            const unsigned char *nl = memchr(text + i, '\n', n - i);
-            if (!nl) { gw_abort(&w); return KSSD_HOST_ERR_HEADER; }
-            i = (size_t)(nl - text);
-            w.pending_break = 1;
-        } else {
-            w.pending_break = 1;
-        }
-    }
-    gw_finish(&w);
-    return KSSD_HOST_OK;
+    return tok_fasta(&w, text, n);
 }
 
 /* The same scanner for dist --byread (reads2mco, iseq2comem.c:110-156): one genome per file, and for every '>' the
@@ -341,7 +413,6 @@ int kssd_batch_add_fasta(kssd_batch *b, const unsigned char *text, size_t n)
  * position the header leaves, every earlier one entirely before it. */
 int kssd_batch_add_fasta_reads(kssd_batch *b, const unsigned char *text, size_t n, uint64_t **read_start, uint64_t *n_reads)
 {
-    if (!fa_class_ready) fa_class_init();
     if (!read_start || !n_reads) return KSSD_HOST_ERR_PARAM;
     *read_start = NULL;
     *n_reads = 0;
@@ -403,15 +474,23 @@ static char *ms_gets(char *buf, int size, mstream *s)
 
 #define FQ_LINE 20000 /* LEN, iseq2comem.c:274 */
 
+static int tok_fastq(gwriter *wp, const unsigned char *text, size_t n, int Q, uint64_t *n_lines);
+
 int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int Q, uint64_t *n_lines)
 {
-    if (!fa_class_ready) fa_class_init();
     int rc = batch_begin(b);
     if (rc) return rc;
-    char *seq = calloc(1, FQ_LINE + 10), *qual = calloc(1, FQ_LINE + 10);
-    if (!seq || !qual) { free(seq); free(qual); return KSSD_HOST_ERR_NOMEM; }
     gwriter w;
     gw_start(&w, b);
+    return tok_fastq(&w, text, n, Q, n_lines);
+}
+
+static int tok_fastq(gwriter *wp, const unsigned char *text, size_t n, int Q, uint64_t *n_lines)
+{
+    int rc;
+    char *seq = calloc(1, FQ_LINE + 10), *qual = calloc(1, FQ_LINE + 10);
+    if (!seq || !qual) { free(seq); free(qual); gw_abort(wp); return KSSD_HOST_ERR_NOMEM; }
+#define w (*wp)
     mstream ms = {text, n, 0, 0};
     uint64_t lines = 0;
     /* record = name, bases, '+', qualities; the second and fourth line are what the scanner keeps */
@@ -441,6 +520,7 @@ int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int
     gw_finish(&w);
     if (n_lines) *n_lines = lines;
     return KSSD_HOST_OK;
+#undef w
 }
 
 #define KOC_LINE 4096 /* FQ_LEN of the abundance scanner, iseq2comem.c:553 */
@@ -449,15 +529,23 @@ int kssd_batch_add_fastq(kssd_batch *b, const unsigned char *text, size_t n, int
  * most KOC_LINE-1 bytes, the second one scanned up to its newline, no quality filter; a read restarts the k-mer and
  * so does every byte that is not ACGT/acgt.  (A line without newline inside KOC_LINE-1 bytes makes the reference
  * run off its buffer; here the scan stops at the end of what fgets() returned.) */
+static int tok_reads(gwriter *wp, const unsigned char *text, size_t n, uint64_t *n_reads);
+
 int kssd_batch_add_reads(kssd_batch *b, const unsigned char *text, size_t n, uint64_t *n_reads)
 {
-    if (!fa_class_ready) fa_class_init();
     int rc = batch_begin(b);
     if (rc) return rc;
-    char *seq = calloc(1, KOC_LINE + 10), *tmp = calloc(1, KOC_LINE + 10);
-    if (!seq || !tmp) { free(seq); free(tmp); return KSSD_HOST_ERR_NOMEM; }
     gwriter w;
     gw_start(&w, b);
+    return tok_reads(&w, text, n, n_reads);
+}
+
+static int tok_reads(gwriter *wp, const unsigned char *text, size_t n, uint64_t *n_reads)
+{
+    int rc;
+    char *seq = calloc(1, KOC_LINE + 10), *tmp = calloc(1, KOC_LINE + 10);
+    if (!seq || !tmp) { free(seq); free(tmp); gw_abort(wp); return KSSD_HOST_ERR_NOMEM; }
+#define w (*wp)
     mstream ms = {text, n, 0, 0};
     uint64_t reads = 0;
     while (ms_gets(tmp, KOC_LINE, &ms) && ms_gets(seq, KOC_LINE, &ms) && ms_gets(tmp, KOC_LINE, &ms) && ms_gets(tmp, KOC_LINE, &ms)) {
@@ -477,6 +565,36 @@ int kssd_batch_add_reads(kssd_batch *b, const unsigned char *text, size_t n, uin
     gw_finish(&w);
     if (n_reads) *n_reads = reads;
     return KSSD_HOST_OK;
+#undef w
+}
+
+/* ---- parallel fill: the layout first (serial), then one tokeniser per genome on as many threads as the caller has ---- */
+int kssd_batch_reserve(kssd_batch *b, uint32_t n, const uint64_t *max_pos, uint32_t *first)
+{
+    if (!b || (!max_pos && n)) return KSSD_HOST_ERR_PARAM;
+    if (first) *first = b->n_genomes;
+    uint64_t need = b->n_chunks;
+    for (uint32_t i = 0; i < n; i++) need += (max_pos[i] + CHUNK_BASES - 1) / CHUNK_BASES;
+    int rc = batch_reserve_chunks(b, need + 1);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+        if ((rc = batch_begin(b)) != 0) return rc;
+        b->n_pos[b->n_genomes] = 0;
+        b->n_chunks += (max_pos[i] + CHUNK_BASES - 1) / CHUNK_BASES;
+        b->n_genomes++;
+        b->chunk_off[b->n_genomes] = b->n_chunks;
+    }
+    return KSSD_HOST_OK;
+}
+
+int kssd_batch_fill_text(kssd_batch *b, uint32_t genome, int kind, const unsigned char *text, size_t n, int Q, uint64_t *n_lines)
+{
+    if (!b || genome >= b->n_genomes) return KSSD_HOST_ERR_PARAM;
+    gwriter w;
+    gw_start_fixed(&w, b, genome);
+    if (kind == 2) return tok_reads(&w, text, n, n_lines);
+    if (kind == 1) return tok_fastq(&w, text, n, Q, n_lines);
+    return tok_fasta(&w, text, n);
 }
 
 int kssd_slurp(const char *path, unsigned char **buf, size_t *len)

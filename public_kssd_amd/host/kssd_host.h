@@ -43,6 +43,9 @@ void kssd_shuf_release(kssd_shuf *s);
 /* ---- packed batches (layout: include/kssd_gpu.h) ----------------------------------------------- */
 typedef struct kssd_batch kssd_batch;
 kssd_batch *kssd_batch_create(void);
+/* the same with the packed / mask arrays in memory of the caller's choice (e.g. page-locked memory from
+ * kssd_gpu_host_alloc, so that the batch can travel to the device by DMA without a staging copy) */
+kssd_batch *kssd_batch_create_ex(void *(*alloc)(size_t), void (*release)(void *));
 void kssd_batch_destroy(kssd_batch *b);
 void kssd_batch_clear(kssd_batch *b);
 /* append one genome; tokenisation rules of fasta2co (iseq2comem.c:213-242) */
@@ -66,6 +69,13 @@ const uint64_t *kssd_batch_chunk_off(const kssd_batch *b);
 uint64_t kssd_batch_n_chunks(const kssd_batch *b);
 uint32_t kssd_batch_n_genomes(const kssd_batch *b);
 uint64_t kssd_batch_n_positions(const kssd_batch *b, uint32_t genome); /* bases + run breaks */
+
+/* Parallel fill.  kssd_batch_reserve appends n empty genomes with room for max_pos[i] positions each (an input of
+ * B bytes never needs more than B positions) and returns the index of the first; kssd_batch_fill_text then tokenises
+ * one input into one reserved genome and may run on many threads at once, one genome each.  kind: 0 FASTA, 1 FASTQ
+ * (quality floor Q), 2 reads of dist -A.  Unused room stays padding (invalid positions). */
+int kssd_batch_reserve(kssd_batch *b, uint32_t n, const uint64_t *max_pos, uint32_t *first);
+int kssd_batch_fill_text(kssd_batch *b, uint32_t genome, int kind, const unsigned char *text, size_t n, int Q, uint64_t *n_lines);
 
 /* append every genome of src to dst (used to tokenise files in parallel, one batch per thread) */
 int kssd_batch_append(kssd_batch *dst, const kssd_batch *src);

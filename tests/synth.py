@@ -47,3 +47,59 @@ def fastq_text(codes_list, qual=b"I", names=None):
         nm = names[i] if names else b"r%d" % i
         out.append(b"@" + nm + b"\n" + s + b"\n+\n" + qual * len(s) + b"\n")
     return b"".join(out)
+
+
+def fastq_records(reads2d, qual=ord("I")):
+    """FASTQ text of n equally long reads (uint8 codes [n, len]) with fixed-width names, built without a Python loop:
+    @r0000000\\n<bases>\\n+\\n<qualities>\\n"""
+    n, ln = reads2d.shape
+    nd = max(7, len(str(max(n - 1, 0))))
+    rec = 2 + nd + 1 + ln + 1 + 2 + ln + 1
+    out = np.empty((n, rec), dtype=np.uint8)
+    out[:, 0] = ord("@")
+    out[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(nd):
+        out[:, 2 + d] = ord("0") + (idx // 10 ** (nd - 1 - d)) % 10
+    c = 2 + nd
+    out[:, c] = ord("\n")
+    out[:, c + 1:c + 1 + ln] = ACGT[reads2d]
+    c += 1 + ln
+    out[:, c] = ord("\n")
+    out[:, c + 1] = ord("+")
+    out[:, c + 2] = ord("\n")
+    out[:, c + 3:c + 3 + ln] = qual
+    out[:, c + 3 + ln] = ord("\n")
+    return out.tobytes()
+
+
+def sample_reads(genomes, n_reads, read_len, seed, err=0.005):
+    """uint8 codes [n_reads, read_len]: uniform start positions on uniformly chosen genomes (equally long uint8 code
+    arrays), either strand, per-base substitution errors at rate err"""
+    rng = np.random.default_rng(seed)
+    L = len(genomes[0])
+    flat = np.concatenate(genomes)
+    g = rng.integers(0, len(genomes), n_reads)
+    s = rng.integers(0, L - read_len, n_reads)
+    rev = rng.random(n_reads) < 0.5
+    j = np.arange(read_len, dtype=np.int64)
+    first = g * L + s + np.where(rev, read_len - 1, 0)
+    step = np.where(rev, -1, 1)
+    r = np.empty((n_reads, read_len), dtype=np.uint8)
+    B = 65536  # block-wise: large temporaries are expensive to fault in
+    idx = np.empty((B, read_len), dtype=np.int64)
+    for b0 in range(0, n_reads, B):
+        b1 = min(n_reads, b0 + B)
+        ix = idx[:b1 - b0]
+        np.multiply(step[b0:b1, None], j[None, :], out=ix)
+        ix += first[b0:b1, None]
+        blk = np.take(flat, ix)
+        rv = rev[b0:b1]
+        blk[rv] = 3 - blk[rv]
+        r[b0:b1] = blk
+    if err > 0:
+        ne = rng.binomial(r.size, err)
+        at = rng.integers(0, r.size, ne)
+        rf = r.reshape(-1)
+        rf[at] = (rf[at] + rng.integers(1, 4, ne, dtype=np.uint8)) & 3
+    return r

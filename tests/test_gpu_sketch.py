@@ -120,25 +120,27 @@ def test_occurrence_counts_of_the_abundance_sketches(gpu_ctx, shuf_l3k10, monkey
     hot = next(r for r in reads if len(sk.fastq_koc(fastq_text([r]))[0]) > 0)
     fq_a = fastq_text(reads)
     fq_b = fastq_text(reads[:2000] + [hot] * 70000)
-    for big in (False, True):
-        if big:
-            monkeypatch.setenv("KSSD_DEV_BIG_MIN", "64")  # read per call
-        ctx = gpu_ctx
-        b = K.Batch()
-        assert b.add_reads(fq_a) == len(reads)
-        assert b.add_reads(fq_b) == 72000
-        off, ids, cnt = ctx.sketch_batch_pos(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY | K.SKETCH_COUNTS)
-        for g, fq in enumerate((fq_a, fq_b)):
-            wi, wc = sk.fastq_koc(fq)
-            o = np.argsort(wi)
-            lo, hi = int(off[g]), int(off[g + 1])
-            assert np.array_equal(ids[lo:hi], wi[o]), (big, g)
-            assert np.array_equal(cnt[lo:hi], wc[o].astype(np.uint32)), (big, g)
-        assert cnt[int(off[1]):].max() == 65535 and cnt[:int(off[1])].max() < 100
-        # positions and counts are one or the other per call
-        with pytest.raises(K.KssdError):
-            ctx.sketch_batch_pos(b, K.SKETCH_KEEP_ZERO | K.SKETCH_FIRST_POS | K.SKETCH_COUNTS)
-    monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
+    try:
+        for big in (False, True):
+            if big:
+                gpu_ctx.set_lds_sort_limit(64)
+            ctx = gpu_ctx
+            b = K.Batch()
+            assert b.add_reads(fq_a) == len(reads)
+            assert b.add_reads(fq_b) == 72000
+            off, ids, cnt = ctx.sketch_batch_pos(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY | K.SKETCH_COUNTS)
+            for g, fq in enumerate((fq_a, fq_b)):
+                wi, wc = sk.fastq_koc(fq)
+                o = np.argsort(wi)
+                lo, hi = int(off[g]), int(off[g + 1])
+                assert np.array_equal(ids[lo:hi], wi[o]), (big, g)
+                assert np.array_equal(cnt[lo:hi], wc[o].astype(np.uint32)), (big, g)
+            assert cnt[int(off[1]):].max() == 65535 and cnt[:int(off[1])].max() < 100
+            # positions and counts are one or the other per call
+            with pytest.raises(K.KssdError):
+                ctx.sketch_batch_pos(b, K.SKETCH_KEEP_ZERO | K.SKETCH_FIRST_POS | K.SKETCH_COUNTS)
+    finally:
+        gpu_ctx.set_lds_sort_limit(0)
 
 
 def _byread_text(rng, n_reads, max_len, repeat_every=0):
@@ -168,7 +170,7 @@ def test_by_position_stream_of_the_byread_sketches(k, subk, dr, monkeypatch):
     try:
         for big in (False, True):
             if big:
-                monkeypatch.setenv("KSSD_DEV_BIG_MIN", "16")  # read per call
+                ctx.set_lds_sort_limit(16)
             b = K.Batch()
             cuts = [b.add_fasta_reads(t) for t in texts]
             off, ids, pos = ctx.sketch_batch_pos(b, K.SKETCH_BY_POS)
@@ -190,7 +192,6 @@ def test_by_position_stream_of_the_byread_sketches(k, subk, dr, monkeypatch):
         with pytest.raises(K.KssdError):  # no keep rule may interfere
             ctx.sketch_batch_pos(b, K.SKETCH_BY_POS | K.SKETCH_UNIQ)
     finally:
-        monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
         ctx.close()
 
 
@@ -242,11 +243,13 @@ def test_empty_batch_and_empty_genome(gpu_ctx, shuf_l3k10):
 
 
 @pytest.fixture
-def force_big_path(monkeypatch):
-    """route every genome with more than ~100 expected ids through the global-memory dedup (rocPRIM sort + run kernels)"""
-    monkeypatch.setenv("KSSD_DEV_BIG_MIN", "100")
+def force_big_path(gpu_ctx, monkeypatch):
+    """route every genome with more than ~100 expected ids through the global-memory dedup (rocPRIM sort + run kernels):
+    kssd_gpu_set_lds_sort_limit on the session context and on every context created meanwhile"""
+    monkeypatch.setattr(K.capi, "DEFAULT_LDS_SORT_LIMIT", 100)
+    gpu_ctx.set_lds_sort_limit(100)
     yield
-    monkeypatch.delenv("KSSD_DEV_BIG_MIN", raising=False)
+    gpu_ctx.set_lds_sort_limit(0)
 
 
 def test_big_genome_path_matches_oracle(gpu_ctx, shuf_l3k10, force_big_path):
