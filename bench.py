@@ -94,62 +94,330 @@ def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0, on_genome=N
 
 
 # ------------------------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N=1, bounded sample)
+# CPU baseline + end-to-end leg (rank 0, N=1, bounded sample, outside the timed region)
 # ------------------------------------------------------------------------------------------------------
-def cpu_baseline(shuf, kept, cores, gpu_sets):
+KSSD_BIN = os.path.join(ROOT, "public_kssd_amd", "kssd")
+
+
+def _run_ours(args, cwd, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    t0 = time.time()
+    r = subprocess.run([KSSD_BIN] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
+    dt = time.time() - t0
+    if r.returncode != 0:
+        raise RuntimeError("kssd %s -> %d\n%s" % (args, r.returncode, r.stderr.decode(errors="replace")[-2000:]))
+    timing = None
+    for line in r.stderr.decode(errors="replace").splitlines():
+        if line.startswith('{"kssd_timing"'):
+            timing = json.loads(line)
+    return dt, timing
+
+
+def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
+    """The CPU comparators and the end-to-end leg, on the same inputs in the same run:
+      port       oracle/kssd_oracle.c (our restatement) sketching the sample texts, OpenMP over genomes
+      reference  oracle/_ref/kssd (the real reference, when the snapshot carries it): stage I on FASTA files in tmpfs,
+                 stage II (its fixed-cost 2 GiB mco.index), search incl. distance.out
+      end_to_end the product's own command line on the same files: read + tokenise + H2D + kernels + D2H + file write
+    The GPU sketches of the sample are checked against the oracle and the reference while we are here."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import kssd_oracle as ko
     from synth import fasta_text
     texts = [fasta_text(c, b"g%d" % i, n_mask=m) for i, (c, m) in enumerate(kept)]
     nb = sum(len(c) for c, _ in kept)
+    n = len(texts)
     out = {}
     # the port (our C restatement of the reference algorithm), OpenMP over genomes like run_stageI
     t0 = time.time()
     off, ids = ko.sketch_texts(shuf.table, shuf.k, shuf.subk, shuf.drlevel, texts, threads=cores)
     t_port = time.time() - t0
-    # parity of the bench inputs while we are here: the GPU sketches of the sample must equal the oracle's
-    for g in range(len(texts)):
+    for g in range(n):
         want = np.sort(ids[int(off[g]):int(off[g + 1])])
         assert np.array_equal(gpu_sets[g], want), "bench sample genome %d: GPU sketch != oracle" % g
-    port = {"value": len(texts) / t_port, "unit": "genomes/s", "cores": min(cores, len(texts)), "kind": "port",
-            "sample": "%d of the bench genomes (%.0f Mbase) as 70-col FASTA text in memory, oracle/kssd_oracle.c "
-                      "sketch_texts, OpenMP over genomes" % (len(texts), nb / 1e6),
-            "mbase_per_s": nb / 1e6 / t_port}
-    out["port"] = port
-    # the real reference binary when the snapshot carries it
-    if ko.have_ref() and shutil.which("zcat"):
-        d = tempfile.mkdtemp(prefix="kssd_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-        try:
-            os.mkdir(os.path.join(d, "fa"))
-            for i, t in enumerate(texts):
-                with open(os.path.join(d, "fa", "g%04d.fasta" % i), "wb") as f:
-                    f.write(t)
-            shuf.write(os.path.join(d, "L3K10.shuf"))
-            t0 = time.time()
-            # the reference only goes parallel when there are more files than threads (command_dist.c:275)
-            p_ref = max(1, min(cores, len(texts) - 1))
-            ko.run_ref(["dist", "-p", p_ref, "-L", "L3K10.shuf", "-o", "sk", "fa"], cwd=d, timeout=900)
-            t_ref = time.time() - t0
-            sets = ko.sketch_sets_by_name(os.path.join(d, "sk"))
-            for i in range(len(texts)):
-                assert np.array_equal(sets["g%04d.fasta" % i], gpu_sets[i]), "reference binary sketch != GPU sketch"
-            out["reference"] = {"value": len(texts) / t_ref, "unit": "genomes/s", "cores": p_ref, "kind": "reference",
-                                "sample": "%d of the bench genomes (%.0f Mbase) as FASTA files in tmpfs, "
-                                          "`oracle/_ref/kssd dist -p %d -L L3K10.shuf` wall time incl. process start "
-                                          "and the 64 MiB .shuf load" % (len(texts), nb / 1e6, p_ref),
-                                "mbase_per_s": nb / 1e6 / t_ref}
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    # distances: posting traversal + output_ctrl arithmetic of the port on the sample's all-pairs
+    out["port"] = {"value": n / t_port, "unit": "genomes/s", "cores": min(cores, n), "kind": "port",
+                   "sample": "%d of the bench genomes (%.0f Mbase) as 70-col FASTA text in memory, oracle/kssd_oracle.c "
+                             "sketch_texts, OpenMP over genomes" % (n, nb / 1e6),
+                   "mbase_per_s": nb / 1e6 / t_port}
     t0 = time.time()
     sh = ko.shared_counts(off, ids, off, ids, threads=cores)
     t_cnt = time.time() - t0
     out["dist_port"] = {"value": sh.size / t_cnt, "unit": "pairs/s", "cores": cores, "kind": "port",
-                        "sample": "%dx%d all-pairs of the sample sketches, index build + posting traversal only "
-                                  "(the reference adds a fixed ~7-25 s for its 2 GiB mco.index and ~2 us/pair of "
-                                  "text formatting)" % (len(texts), len(texts))}
+                        "sample": "%dx%d all-pairs of the sample sketches, index build + posting traversal only" % (n, n)}
+    d = tempfile.mkdtemp(prefix="kssd_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        os.mkdir(os.path.join(d, "fa"))
+        reps = max(1, e2e_files // n)
+        nf = 0
+        for i, t in enumerate(texts):
+            with open(os.path.join(d, "fa", "r00_g%04d.fasta" % i), "wb") as f:
+                f.write(t)
+            nf += 1
+            for r in range(1, reps):   # the same genomes again under other names: whole-pipeline work, bounded setup time
+                os.symlink("r00_g%04d.fasta" % i, os.path.join(d, "fa", "r%02d_g%04d.fasta" % (r, i)))
+                nf += 1
+        del texts
+        shuf.write(os.path.join(d, "L3K10.shuf"))
+        fa_desc = "%d FASTA files in tmpfs (%d distinct bench genomes of %.1f Mb x %d names, %.0f Mbase)" % (nf, n, nb / n / 1e6, reps, nb * reps / 1e6)
+        # ---- end to end through the product's command line ----
+        if os.access(KSSD_BIN, os.X_OK):
+            dt, tm = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_sk", "fa"], d, {"KSSD_TIMING": "1"})
+            ours = ko.sketch_sets_by_name(os.path.join(d, "our_sk"))
+            for i in range(n):
+                assert np.array_equal(ours["r00_g%04d.fasta" % i], gpu_sets[i]), "kssd CLI sketch != device-level sketch"
+            e2e = {"value": nf / dt, "unit": "genomes/s", "mbase_per_s": nb * reps / 1e6 / dt, "seconds": dt, "host_threads": cores,
+                   "what": "`kssd dist -L L3K10.shuf -o <dir> <fasta dir>`: process start, .shuf load, read + tokenise on all host "
+                           "threads into page-locked batches, H2D, kernels, D2H, slot order, combco.* written -- wall time of the "
+                           "command", "sample": fa_desc, "stages": tm}
+            dt2, _ = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist", "--keepskf", "our_sk"], d)
+            e2e["search"] = {"value": nf * nf / dt2, "unit": "pairs/s", "seconds": dt2,
+                             "what": "`kssd dist -r <sketches> -o <dir> <sketches>`: %d x %d all-pairs incl. reading the sketches, the device "
+                                     "search and the distance.out text (%d MB) on %d host threads"
+                                     % (nf, nf, os.path.getsize(os.path.join(d, "our_dist", "distance.out")) >> 20, cores)}
+            out["end_to_end"] = e2e
+        # ---- the real reference binary when the snapshot carries it ----
+        if ko.have_ref() and shutil.which("zcat"):
+            # the reference only goes parallel when there are more files than threads (command_dist.c:275)
+            p_ref = max(1, min(cores, nf - 1))
+            t0 = time.time()
+            ko.run_ref(["dist", "-p", p_ref, "-L", "L3K10.shuf", "-o", "ref_sk", "fa"], cwd=d, timeout=1800)
+            t_ref = time.time() - t0
+            sets = ko.sketch_sets_by_name(os.path.join(d, "ref_sk"))
+            for i in range(n):
+                assert np.array_equal(sets["r00_g%04d.fasta" % i], gpu_sets[i]), "reference binary sketch != GPU sketch"
+            out["reference"] = {"value": nf / t_ref, "unit": "genomes/s", "cores": p_ref, "kind": "reference",
+                                "sample": fa_desc + ", `oracle/_ref/kssd dist -p %d -L L3K10.shuf` wall time incl. process start "
+                                          "and the 64 MiB .shuf load" % p_ref,
+                                "mbase_per_s": nb * reps / 1e6 / t_ref}
+            t0 = time.time()
+            ko.run_ref(["dist", "-p", p_ref, "-o", "ref_idx", "ref_sk"], cwd=d, timeout=1800)
+            t_idx = time.time() - t0
+            t0 = time.time()
+            ko.run_ref(["dist", "-p", p_ref, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", "ref_sk"], cwd=d, timeout=1800)
+            t_srch = time.time() - t0
+            out["dist_reference"] = {"value": nf * nf / t_srch, "unit": "pairs/s", "cores": p_ref, "kind": "reference",
+                                     "sample": "%d x %d all-pairs of the reference's own sketches of those files: `kssd dist -r <mco> "
+                                               "--keepskf <co>` wall time incl. distance.out text; its stage II (2 GiB mco.index, "
+                                               "co2mco.c:57-62) took %.1f s on top and is not in the figure" % (nf, nf, t_idx),
+                                     "stage2_seconds": t_idx, "seconds": t_srch}
+            if "end_to_end" in out:
+                # parity of the whole product path at this size: our command line, fed the REFERENCE's sketch directory, must
+                # leave the reference's sharedk_ct.dat and distance.out byte for byte
+                _run_ours(["dist", "-p", cores, "-r", "ref_sk", "-o", "our_dist_on_ref", "--keepskf", "ref_sk"], d)
+                for fn in ("sharedk_ct.dat", "distance.out"):
+                    a = open(os.path.join(d, "our_dist_on_ref", fn), "rb").read()
+                    b = open(os.path.join(d, "ref_dist", fn), "rb").read()
+                    assert a == b, "kssd CLI %s differs from the reference's" % fn
+                out["end_to_end"]["search"]["byte_identical_to_reference"] = "sharedk_ct.dat and distance.out on the reference's sketch directory"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: reads -> read-set sketch (fastq2co, iseq2comem.c:277-356) -> containment (-M 1) against the
+# reference sketches.  The reads are generated and packed on the device exactly as the host tokeniser lays a FASTQ
+# file out (kssd_batch_add_fastq: the reads of a file are ONE genome, one invalid position between two reads).
+# ------------------------------------------------------------------------------------------------------
+READ_LEN = 150
+
+
+def make_reads_batch(src_codes, n_reads, seed, dev, err=0.005, keep_reads=0, slice_reads=1 << 21):
+    """packed / mask / chunk_off of n_reads x 150 bp drawn from the device code tensors `src_codes` (equally long),
+    either strand, substitution errors at rate err; the codes of the first keep_reads reads come back as a host array"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    L = int(src_codes[0].numel())
+    flat = torch.cat(src_codes)
+    stride = READ_LEN + 1
+    n_pos = n_reads * stride
+    chunks = (n_pos + K.CHUNK_BASES - 1) // K.CHUNK_BASES
+    packed = torch.zeros(chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
+    mask = torch.zeros(chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
+    wsh = (30 - 2 * torch.arange(16, device=dev, dtype=torch.int64))
+    msh = torch.arange(32, device=dev, dtype=torch.int64)
+    j = torch.arange(stride, device=dev, dtype=torch.int64)
+    validj = (j < READ_LEN)
+    kept = np.zeros((keep_reads, READ_LEN), dtype=np.uint8)
+    for r0 in range(0, n_reads, slice_reads):
+        S = min(slice_reads, n_reads - r0)
+        S32 = (S + 31) // 32 * 32                       # whole mask words per slice (the surplus reads are cut off below)
+        gi = torch.randint(0, len(src_codes), (S32,), generator=g, device=dev)
+        st = torch.randint(0, L - READ_LEN, (S32,), generator=g, device=dev)
+        rev = torch.rand(S32, generator=g, device=dev) < 0.5
+        jj = torch.where(rev[:, None], (READ_LEN - 1 - j).clamp(min=0)[None, :], j.clamp(max=READ_LEN - 1)[None, :])
+        v = flat[(gi * L + st)[:, None] + jj]
+        v = torch.where(rev[:, None], 3 - v, v)
+        e = torch.rand(v.shape, generator=g, device=dev) < err
+        v = torch.where(e, (v + torch.randint(1, 4, v.shape, generator=g, device=dev, dtype=torch.uint8)) & 3, v)
+        ok = validj[None, :] & (torch.arange(S32, device=dev) < S)[:, None]
+        v = torch.where(ok, v, torch.zeros_like(v))
+        if r0 < keep_reads:
+            m = min(keep_reads - r0, S)
+            kept[r0:r0 + m] = v[:m, :READ_LEN].cpu().numpy()
+        w = (v.reshape(-1, 16).to(torch.int64) << wsh).sum(1).to(torch.int32)
+        mw = (ok.reshape(-1, 32).to(torch.int64) << msh).sum(1).to(torch.int32)
+        p0 = r0 * stride
+        assert p0 % 32 == 0
+        nw = min(len(w), (n_pos - p0 + 15) // 16)
+        nm = min(len(mw), (n_pos - p0 + 31) // 32)
+        packed[p0 // 16:p0 // 16 + nw] = w[:nw]
+        mask[p0 // 32:p0 // 32 + nm] = mw[:nm]
+        del v, e, ok, w, mw, jj
+    return packed, mask, np.array([0, chunks], dtype=np.uint64), kept
+
+
+def run_fastq(a, shuf, dev):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    G, L, NSRC = a.genomes, a.length, 64
+    t0 = time.time()
+    packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101, dev, keep_codes=min(NSRC, G), keep_on_device=True)
+    ctx = K.GpuCtx(shuf, dev.index or 0)
+    cap = int(G * L / 4096 * 1.25) + 4096
+    roff = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    rids = torch.zeros(cap, dtype=torch.int32, device=dev)
+    for attempt in range(6):
+        ctx.sketch_device(packed, mask, chunk_off, roff, rids, cap)
+        rc, rtotal, bad = ctx.sketch_status()
+        if rc == 0:
+            break
+    assert rc == 0, rc
+    del packed, mask
+    torch.cuda.empty_cache()
+    src = [c for c, _ in kept]
+    log("[bench] %d reference genomes sketched (%d ids) in %.1f s" % (G, rtotal, time.time() - t0))
+    t0 = time.time()
+    n_par = min(a.parity_reads, a.reads)
+    rp, rm, rco, host_reads = make_reads_batch(src, a.reads, 4242, dev, keep_reads=n_par)
+    n_bases = a.reads * READ_LEN
+    n_pos = a.reads * (READ_LEN + 1)
+    torch.cuda.synchronize()
+    log("[bench] %d reads packed on device in %.1f s (%d chunks)" % (a.reads, time.time() - t0, int(rco[1])))
+    # the reference index (untimed setup; `kssd dist -r` finds it prebuilt as mco.* too)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ctx.index_build_device(roff, rids, G, int(rtotal))
+    e1.record()
+    torch.cuda.synchronize()
+    index_ms = e0.elapsed_time(e1)
+    qcap = int(n_pos / 4096 * 1.5) + 4096
+    res_m = {}
+    for M in (1, 2):
+        qoff = torch.zeros(2, dtype=torch.int64, device=dev)
+        qids = torch.zeros(qcap, dtype=torch.int32, device=dev)
+        shared = torch.zeros(G, dtype=torch.int32, device=dev)
+        cont = torch.zeros(G, dtype=torch.float64, device=dev)
+        aaf = torch.zeros(G, dtype=torch.float64, device=dev)
+        flags = K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY
+
+        def step(timed=None):
+            ctx.sketch_plan(rp, rm, rco, qoff, qids, qcap, flags, M)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed is not None else None
+            for i, ph in enumerate((K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH)):
+                if ev:
+                    ev[i].record()
+                ctx.sketch_phase(ph, None)
+            if ev:
+                ev[4].record()
+            ctx.dist_device(qoff, qids, 1, 0, 1, shared, None, None, cont, aaf)
+            if ev:
+                ev[5].record()
+                timed.append(ev)
+        for attempt in range(8):                          # sizes the workspaces
+            step()
+            rc, qtotal, bad = ctx.sketch_status()
+            if rc == 0:
+                break
+            assert rc == K.capi.ERR_OVERFLOW, rc
+        assert rc == 0
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        ctx.kernel_time(0, reset=True)
+        timed = []
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step(timed)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        scan_ms, scan_n = ctx.kernel_time(0)
+        ph = np.array([[ev[i].elapsed_time(ev[i + 1]) for i in range(5)] for ev in timed]).mean(0)
+        rc, qtotal, bad = ctx.sketch_status()
+        assert rc == 0
+        res_m[M] = dict(dt=dt, scan_ms=scan_ms, phases=ph, qtotal=int(qtotal), qids=qids[:int(qtotal)].cpu().numpy().view(np.uint32),
+                        shared=shared.cpu().numpy().view(np.uint32), cont=cont.cpu().numpy(), aaf=aaf.cpu().numpy())
+    # ---- parity: the oracle on a slice of the same reads (FASTQ text through the host tokeniser), CPU baseline beside it
+    import kssd_oracle as ko
+    par = None
+    cpu = None
+    if n_par:
+        from synth import fastq_records
+        t0 = time.time()
+        fq = fastq_records(host_reads)
+        hb = K.Batch()
+        assert hb.add_fastq(fq, Q=0) == 4 * n_par
+        # the device-side generator writes what the tokeniser writes: same packed words and mask for the slice
+        nchk = hb.n_chunks
+        whole = (n_par * (READ_LEN + 1)) // K.CHUNK_BASES    # chunks that hold slice reads only
+        assert np.array_equal(hb.packed()[:whole * K.CHUNK_WORDS], rp[:whole * K.CHUNK_WORDS].cpu().numpy().view(np.uint32))
+        assert np.array_equal(hb.mask()[:whole * K.CHUNK_MASKW], rm[:whole * K.CHUNK_MASKW].cpu().numpy().view(np.uint32))
+        t_tok = time.time() - t0
+        sk = ko.Sketcher(shuf.table, 10, 6, 3)
+        par = {"reads": n_par, "mbase": n_par * READ_LEN / 1e6}
+        for M in (1, 2):
+            t0 = time.time()
+            want = np.sort(sk.fastq(fq, Q=0, M=M))
+            t_or = time.time() - t0
+            off_s, ids_s = ctx.sketch_batch(hb, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY, min_occ=M)
+            assert np.array_equal(ids_s, want), "fastq slice -n %d: GPU sketch != oracle (%d vs %d ids)" % (M, len(ids_s), len(want))
+            par["n%d_ids" % M] = int(len(want))
+            if M == 1:
+                cpu = {"value": n_par * READ_LEN / 1e9 / t_or, "unit": "Gbase/s", "cores": 1, "kind": "port",
+                       "sample": "%d of the reads (%.0f Mbase) as FASTQ text in memory, oracle/kssd_oracle.c ko_fastq2co on one "
+                                 "thread (the reference sketches one FASTQ file on one thread, command_dist.c:275)" % (n_par, n_par * READ_LEN / 1e6)}
+        hb.close()
+        del fq
+    # containment rows of the full run against the oracle's posting traversal
+    oh = roff.cpu().numpy().astype(np.uint64)
+    ih = rids[:int(rtotal)].cpu().numpy().view(np.uint32)
+    szh = np.diff(oh).astype(np.uint32)
+    for M in (1, 2):
+        r = res_m[M]
+        qo = np.array([0, r["qtotal"]], dtype=np.uint64)
+        want = ko.shared_counts(oh, ih, qo, r["qids"], threads=os.cpu_count() or 1)
+        assert np.array_equal(r["shared"][None, :], want), "containment row -n %d: shared counts != oracle" % M
+        oJ, oMD, oC, oAD = ko.metrics_batch(szh[None, :], np.array([[r["qtotal"]]], dtype=np.uint32), want, 20)
+        assert np.array_equal(r["cont"][None, :].view(np.int64), oC.view(np.int64))
+        assert np.abs(r["aaf"][None, :].view(np.int64) - oAD.view(np.int64)).max() <= 1
+    r1 = res_m[1]
+    scan_bytes = 0.375 * n_pos + 4.0 * r1["qtotal"]
+    achieved = scan_bytes / (r1["scan_ms"] * 1e-3) / 1e9
+    res = {
+        "metric": "Gbase of reads sketched/s (fastq2co sketch of one read set + containment row against the reference sketches, L3K10)",
+        "value": n_bases * a.steps / r1["dt"] / 1e9, "unit": "Gbase/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r1["dt"] / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: %d x %d bp reads from %d of %d reference genomes (%.1f Mb, %d clades), 0.5 %% "
+                               "substitutions, both strands, -n 1; containment (-M 1) against the %d reference sketches"
+                               % (a.reads, READ_LEN, len(src), G, L / 1e6, a.clades, G),
+                   "k": 10, "subk": 6, "drlevel": 3, "reads": a.reads, "read_len": READ_LEN, "references": G},
+        "reads_per_s": a.reads * a.steps / r1["dt"],
+        "n1": {"ids": r1["qtotal"], "ms_per_step": r1["dt"] / a.steps * 1e3,
+               "phase_ms": dict(zip(["prep", "scan", "exact", "dedup_finish(rocPRIM sort path)", "containment_row"], [float(x) for x in r1["phases"]]))},
+        "n2": {"ids": res_m[2]["qtotal"], "ms_per_step": res_m[2]["dt"] / a.steps * 1e3, "gbase_per_s": n_bases * a.steps / res_m[2]["dt"] / 1e9,
+               "phase_ms": dict(zip(["prep", "scan", "exact", "dedup_finish(rocPRIM sort path)", "containment_row"], [float(x) for x in res_m[2]["phases"]]))},
+        "reference_index_build_ms": index_ms, "reference_ids": int(rtotal),
+        "best_hit_shared": int(r1["shared"].max()), "source_genomes_min_shared": int(r1["shared"][:len(src)].min()),
+        "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": scan_bytes},
+        "parity": par,
+    }
+    if cpu:
+        res["cpu_baseline"] = cpu
+    print(json.dumps(res), flush=True)
+    ctx.close()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -164,6 +432,15 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
     ap.add_argument("--spinup", type=int, default=40, help="untimed steps before the warmup steps (GPU clock ramp; 0 = none)")
+    ap.add_argument("--workload", choices=["allpairs", "fastq"], default="allpairs",
+                    help="allpairs = BASELINE configs[1] (the metric's config; configs[2] with --genomes 10000 --clades 500); "
+                         "fastq = configs[3]: reads -> read-set sketch -> containment against the reference sketches")
+    ap.add_argument("--partition", choices=["transpose", "query"], default="transpose",
+                    help="N > 1: transpose = own sketches indexed, all gathered sketches as query rows (all-pairs only, the index "
+                         "build stays constant per rank); query = the north_star partition, full index on every rank, own query block")
+    ap.add_argument("--e2e-files", type=int, default=1024, help="files of the end-to-end / reference leg (the CPU sample under several names)")
+    ap.add_argument("--reads", type=int, default=100_000_000, help="fastq workload: reads of 150 bp")
+    ap.add_argument("--parity-reads", type=int, default=10_000_000, help="fastq workload: reads of the oracle slice (0 = skip)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
                     help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial, the default; 3 = pipelined)")
     a = ap.parse_args()
@@ -192,6 +469,10 @@ def main():
     G, L = a.genomes, a.length
     NF = max(1, a.inflight)
     shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
+    if a.workload == "fastq":
+        if world != 1:
+            raise SystemExit("--workload fastq is a single-GPU run (one read set = one sketch)")
+        return run_fastq(a, shuf, dev)
     t0 = time.time()
     n_keep = a.cpu_sample if (rank == 0 and world == 1) else 0
     packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * rank, dev, keep_codes=min(n_keep, G))
@@ -209,8 +490,7 @@ def main():
     exp_ids = int(G * L / 4096)
     cap = int(exp_ids * 1.25) + 4096                      # ids per rank (padded all-gather unit)
     R = G * world
-    if world > 1:
-        from public_kssd_amd.shard import SketchGather
+    from public_kssd_amd.shard import ShardedSearch
 
     class Slot:
         pass
@@ -226,7 +506,7 @@ def main():
         sl.tstream = torch.cuda.Stream(device=dev) if NF > 1 else torch.cuda.current_stream()
         sl.stream = sl.tstream.cuda_stream
         sl.scanned, sl.sorted = torch.cuda.Event(), torch.cuda.Event()
-        sl.gather = SketchGather(world, G, cap, dev) if world > 1 else None
+        sl.search = ShardedSearch(world, rank, G, cap, dev, sl.ctx, partition=a.partition)
         # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
         # status read-back has told the host how many ids this batch really has
         sl.idx_bound = cap
@@ -237,19 +517,12 @@ def main():
         sl.ctx.sketch_phase(K.PHASE_PREP, sl.stream)
 
     def index_build(sl):
-        if world == 1:
-            sl.q = (sl.off_l, sl.ids_l)
-        else:
-            # the one exchange step of the path: all-gather of every rank's packed sketches (RCCL over xGMI),
-            # fixed-size padded units compacted on the device, so that no size has to visit the host
-            with torch.cuda.stream(sl.tstream):
-                sl.q = sl.gather(sl.off_l, sl.ids_l)
-        # index this rank's own sketches only (constant work per rank), query with everybody's: the R x G block
-        # [all genomes] x [this rank's genomes] = transpose of rows [rank*G, (rank+1)*G) of the global matrix
-        sl.ctx.index_build_device(sl.off_l, sl.ids_l, G, sl.idx_bound, sl.stream)
+        # the one exchange step of the path (N > 1): all-gather of every rank's packed sketches (RCCL over xGMI), then the
+        # index in the chosen partition (public_kssd_amd/shard.py)
+        sl.search.index(sl.off_l, sl.ids_l, sl.idx_bound, stream=sl.stream, tstream=sl.tstream if world > 1 else None)
 
     def rows(sl):
-        sl.ctx.dist_device(sl.q[0], sl.q[1], R, 0, R, sl.shared, *sl.planes, stream=sl.stream)
+        sl.search.rows(sl.off_l, sl.ids_l, sl.shared, sl.planes, stream=sl.stream)
 
     def run_steps(n_steps):
         """n_steps whole steps, pipelined over the NF slots; everything is enqueued, nothing synchronised"""
@@ -361,12 +634,15 @@ def main():
         scan_alone_ms, _ = sl.ctx.kernel_time(0)
 
     if rank == 0:
-        # size-independent sanity on the full matrix of this rank
-        sh = shared.view(R, G)  # [all genomes (query rows)] x [this rank's genomes]; world 1: the full G x G matrix
+        # size-independent sanity on this rank's block of the matrix
         szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
-        diag = sh[rank * G + torch.arange(G, device=dev), torch.arange(G, device=dev)]
-        assert torch.equal(diag, szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
-        own = sh[rank * G:(rank + 1) * G, :]
+        if a.partition == "query":
+            sh = shared.view(G, R)   # [this rank's genomes (query rows)] x [all genomes]
+            own = sh[:, rank * G:(rank + 1) * G]
+        else:
+            sh = shared.view(R, G)   # [all genomes (query rows)] x [this rank's genomes]; world 1: the full G x G matrix
+            own = sh[rank * G:(rank + 1) * G, :]
+        assert torch.equal(own.diagonal(), szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
         assert torch.equal(own, own.t()), "all-pairs shared-count matrix must be symmetric"
         n_bases = G * L
         scan_bytes = 0.375 * n_bases + 4.0 * total        # 2-bit base + 1-bit mask, 4 B per id
@@ -384,9 +660,12 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
                                    "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
-                       "pairs_per_step": world * pairs, "batches_in_flight": NF, "parallelism": "genomes and matrix blocks sharded x%d (own genomes "
-                       "indexed, all gathered sketches as query rows), all-gather of sketches" % world if world > 1
-                       else "single GPU"},
+                       "pairs_per_step": world * pairs, "batches_in_flight": NF,
+                       "parallelism": ("genomes and matrix blocks sharded x%d, all-gather of sketches over RCCL; partition '%s': %s"
+                                       % (world, a.partition, "own genomes indexed, all gathered sketches as query rows (transpose of the "
+                                          "query block, all-pairs only)" if a.partition == "transpose" else
+                                          "full index on every rank, own query block as rows (north_star)")) if world > 1 else "single GPU"},
+            "spinup": a.spinup,
             "pairs_per_s": world * pairs * a.steps / dt,
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
@@ -395,7 +674,7 @@ def main():
                         "scan_positions_past_stage1": n_stage1 / n_bases, "scan_positions_past_bloom": n_bloom / n_bases},
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_launch": scan_bytes},
         }
         if scan_alone_ms:
@@ -406,14 +685,20 @@ def main():
             il = ids_l.cpu().numpy().view(np.uint32)
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
             cores = os.cpu_count() or 1
-            cb = cpu_baseline(shuf, kept, cores, gpu_sets)
+            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files)
             res["cpu_baseline"] = cb.get("reference", cb["port"])
             res["cpu_baseline_port"] = cb["port"]
-            res["cpu_baseline_dist"] = cb["dist_port"]
+            res["cpu_baseline_dist"] = cb.get("dist_reference", cb["dist_port"])
+            res["cpu_baseline_dist_port"] = cb["dist_port"]
+            if "end_to_end" in cb:
+                res["end_to_end"] = cb["end_to_end"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and G == 1000 and L == 5_000_000:  # the PMC passes were collected on the default workload
             try:
-                res["roofline"]["traffic"] = json.load(open(pmc)).get("sketch_scan_bytes_per_launch")
+                pj = json.load(open(pmc))
+                res["roofline"]["traffic"] = pj.get("sketch_scan_bytes_per_launch")
+                res["roofline"]["traffic_source"] = ("RECORDED, not measured by this run: profiles/pmc_traffic.json (rocprofv3 --pmc "
+                                                     "FETCH_SIZE pass of %s, kernel source %s)" % (pj.get("tag", "?"), pj.get("source_commit", "?")))
             except Exception:
                 pass
         print(json.dumps(res), flush=True)

@@ -206,6 +206,23 @@ int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids,
                   double *jaccard, double *mashd, double *contain, double *aafd);
 
 /*
+ * The search with the report's selection done on the device (dist_print_nobin + output_ctrl, command_dist.c:1196-1267):
+ * returns, per query row, the references that CAN appear in distance.out under -M metric (0 Jaccard / 1 containment),
+ * --correction, -D dthreshold and -N n_max -- with -N every pair with a positive metric (a metric of 0 never enters the
+ * reference's best-N list, :1212-1227), otherwise every pair whose distance, computed on the device, does not exceed
+ * the threshold by more than a margin that covers any difference to the host's libm.  The host applies the exact -N
+ * ranking and -D test to these candidates and formats only them (kssd_distance_print_pairs of the host library): the
+ * text is the dense report's byte for byte, the formatting work shrinks from Q x R lines to the pairs that matter.
+ *   shared       HOST u32[Q x R] or NULL: the dense counts as well (sharedk_ct.dat, --keepskf)
+ *   pair_off     malloc'd HOST u64[n_qry + 1]; pair_ref / pair_shared: malloc'd HOST u32[pair_off[n_qry]], references
+ *                ascending inside a row (free all three with kssd_gpu_free)
+ * dim_rd_len = 2 * drlevel as stored in cofiles.stat (only --correction uses it).
+ */
+int kssd_gpu_dist_select(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref, const uint64_t *qoff,
+                         const uint32_t *qids, uint32_t n_qry, int metric, int correction, int dim_rd_len, double dthreshold,
+                         int n_max, uint32_t *shared, uint64_t **pair_off, uint32_t **pair_ref, uint32_t **pair_shared);
+
+/*
  * The same search on several devices: the query rows are cut into n_devices contiguous blocks (the reference gives
  * every output row one owner thread, command_dist.c:774-785), every device of `devices` receives the whole reference
  * CSR, builds its own index and writes its block of rows into the caller's matrices.  No exchange between the devices

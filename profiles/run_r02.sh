@@ -1,0 +1,34 @@
+#!/bin/bash
+# usage (GPU box, through gpurun): profiles/run_r02.sh <tag> [tests|bench|fastq|c3|prof|pmc ...]
+# Round-2 measurement driver: GPU parity tests, the default bench line (configs[1]), configs[2] (10 000 genomes) and
+# configs[3] (FASTQ) lines, a rocprofv3 kernel-trace summary and the PMC passes (separate passes, counters + kernel trace only).
+tag=${1:-r02}; shift
+what=${@:-tests bench}
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+for w in $what; do
+case $w in
+tests) ( timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 2>&1 | tail -40 ) > gpurun_out/${tag}_pytest.log; tail -5 gpurun_out/${tag}_pytest.log ;;
+bench) timeout 1500 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -3 gpurun_out/${tag}_bench.err; cut -c1-1500 gpurun_out/${tag}_bench.json ;;
+fastq) timeout 1800 python bench.py --workload fastq --genomes 10000 --clades 500 --steps 10 --warmup 2 > gpurun_out/${tag}_bench_fastq.json 2> gpurun_out/${tag}_bench_fastq.err; tail -3 gpurun_out/${tag}_bench_fastq.err; cut -c1-1500 gpurun_out/${tag}_bench_fastq.json ;;
+c3) timeout 900 python bench.py --genomes 10000 --clades 500 --steps 10 --warmup 2 --spinup 5 --cpu-sample 0 > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/${tag}_bench_c3.err; tail -3 gpurun_out/${tag}_bench_c3.err; cut -c1-1200 gpurun_out/${tag}_bench_c3.json ;;
+n2) KSSD_BENCH_ONE_DEVICE=1 KSSD_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+      --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --genomes 400 --cpu-sample 0 \
+      > gpurun_out/${tag}_bench_n2_onegpu.json 2> gpurun_out/${tag}_bench_n2_onegpu.err
+    KSSD_BENCH_ONE_DEVICE=1 KSSD_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+      --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 6 --warmup 2 --genomes 400 --cpu-sample 0 --partition query \
+      > gpurun_out/${tag}_bench_n2q_onegpu.json 2> gpurun_out/${tag}_bench_n2q_onegpu.err
+    cut -c1-300 gpurun_out/${tag}_bench_n2_onegpu.json; tail -2 gpurun_out/${tag}_bench_n2_onegpu.err; cut -c1-300 gpurun_out/${tag}_bench_n2q_onegpu.json; tail -2 gpurun_out/${tag}_bench_n2q_onegpu.err ;;
+prof) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python bench.py --steps 10 --warmup 2 --cpu-sample 0 > gpurun_out/${tag}_prof.log 2>&1
+    f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_kernel_stats.csv
+    rm -rf gpurun_out/${tag}_prof; cat gpurun_out/${tag}_kernel_stats.csv ;;
+pmc) rx='sketch_scan_kernel|sketch_exact_kernel|idx_|dist_rows'
+    {
+    profiles/pmc_pass.sh ${tag}_sq2 "$rx" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE
+    profiles/pmc_pass.sh ${tag}_fetch "$rx" FETCH_SIZE
+    profiles/pmc_pass.sh ${tag}_write "$rx" WRITE_SIZE
+    } > gpurun_out/${tag}_pmc.txt 2>&1
+    rm -rf gpurun_out/pmc_${tag}_*/; cat gpurun_out/${tag}_pmc.txt ;;
+esac
+done

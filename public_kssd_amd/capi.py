@@ -40,7 +40,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
-    "kssd_gpu_host_alloc", "kssd_gpu_host_free",
+    "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select",
 ]
 
 
@@ -126,6 +126,8 @@ def gpu_lib():
         L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
         L.kssd_gpu_dist_multi.argtypes = [vp, i32, i32, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_device_count.restype = i32
+        L.kssd_gpu_dist_select.argtypes = [vp, vp, vp, u32, vp, vp, u32, i32, i32, i32, C.c_double, i32, vp,
+                                           C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.kssd_gpu_host_alloc.restype = vp
         L.kssd_gpu_host_alloc.argtypes = [C.c_size_t]
         L.kssd_gpu_host_free.restype = None
@@ -189,6 +191,8 @@ def host_lib():
         L.kssd_probe_dir.argtypes = [C.c_char_p]
         L.kssd_distance_print.argtypes = [C.c_char_p, vp, C.POINTER(_SketchSet), C.POINTER(_SketchSet),
                                           C.POINTER(_PrintOpt)]
+        L.kssd_distance_print_pairs.argtypes = [C.c_char_p, vp, vp, vp, C.POINTER(_SketchSet), C.POINTER(_SketchSet),
+                                                C.POINTER(_PrintOpt)]
         _host = L
     return _host
 
@@ -349,6 +353,19 @@ def distance_print(path, shared, ref, qry, metric=0, pfield=2, correction=0, dth
     o = _PrintOpt(metric, pfield, correction, dthreshold, n_max, threads)
     _hck(host_lib().kssd_distance_print(os.fsencode(path), shared.ctypes.data, C.byref(ref._c()), C.byref(qry._c()),
                                         C.byref(o)))
+
+
+def distance_print_pairs(path, pair_off, pair_ref, pair_shared, ref, qry, metric=0, pfield=2, correction=0, dthreshold=1.0,
+                         n_max=0, threads=1):
+    """the report from the candidate pairs of GpuCtx.dist_select"""
+    po = np.ascontiguousarray(pair_off, dtype=np.uint64)
+    pr = np.ascontiguousarray(pair_ref, dtype=np.uint32)
+    ps = np.ascontiguousarray(pair_shared, dtype=np.uint32)
+    if len(pr) == 0:
+        pr, ps = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    o = _PrintOpt(metric, pfield, correction, dthreshold, n_max, threads)
+    _hck(host_lib().kssd_distance_print_pairs(os.fsencode(path), po.ctypes.data, pr.ctypes.data, ps.ctypes.data,
+                                              C.byref(ref._c()), C.byref(qry._c()), C.byref(o)))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -575,6 +592,28 @@ class GpuCtx:
         _gck(gpu_lib().kssd_gpu_dist(self.h, roff.ctypes.data, rids.ctypes.data, R, qoff.ctypes.data,
                                      qids.ctypes.data, Q, shared.ctypes.data, *[_ptr(p) for p in pl]))
         return (shared, *pl) if planes else shared
+
+    def dist_select(self, roff, rids, qoff, qids, metric=0, correction=0, dim_rd_len=0, dthreshold=1.0, n_max=0, dense=False):
+        """(pair_off uint64[Q+1], pair_ref, pair_shared[, shared uint32[Q,R]]): the pairs that can appear in the report"""
+        roff = np.ascontiguousarray(roff, dtype=np.uint64)
+        qoff = np.ascontiguousarray(qoff, dtype=np.uint64)
+        rids = np.ascontiguousarray(rids, dtype=np.uint32)
+        qids = np.ascontiguousarray(qids, dtype=np.uint32)
+        R, Q = len(roff) - 1, len(qoff) - 1
+        shared = np.zeros((Q, R), dtype=np.uint32) if dense else None
+        po, pr, ps = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _gck(gpu_lib().kssd_gpu_dist_select(self.h, roff.ctypes.data, rids.ctypes.data, R, qoff.ctypes.data, qids.ctypes.data, Q,
+                                            metric, correction, dim_rd_len, dthreshold, n_max, _ptr(shared),
+                                            C.byref(po), C.byref(pr), C.byref(ps)))
+        try:
+            off = np.frombuffer((C.c_char * (8 * (Q + 1))).from_address(po.value), dtype=np.uint64).copy()
+            n = int(off[-1])
+            ref = (np.frombuffer((C.c_char * (4 * n)).from_address(pr.value), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32))
+            sh = (np.frombuffer((C.c_char * (4 * n)).from_address(ps.value), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32))
+        finally:
+            for q in (po, pr, ps):
+                gpu_lib().kssd_gpu_free(q)
+        return (off, ref, sh, shared) if dense else (off, ref, sh)
 
     # device-level (torch tensors or raw addresses; nothing is synchronised) ------------------------------
     def sketch_device(self, d_packed, d_mask, chunk_off, d_out_off, d_out_ids, out_cap, flags=SKETCH_FASTA,

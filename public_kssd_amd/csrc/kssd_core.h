@@ -230,6 +230,30 @@ KSSD_HD uint32_t kssd_extract_m(const uint32_t (&W)[5], uint32_t b)
     return top >> (32 - 4 * SUBK);
 }
 
+// What the scanning lane hands to the exact stage together with a candidate's position, so that stage 2 does not have
+// to read the packed stream again (one 128-byte HBM line per candidate for 5 useful bytes): the 16 bases from the
+// sub-context's first base on (top32: the word the Bloom pattern is the top of) and the 4 bases in front of it (the low
+// 8 bits of `front`; Wm1 = the packed word in front of W[0], i.e. the neighbouring lane's W[3]).  20 bases
+// [b-4, b+16) hold the whole 2k-mer whenever out = k - subk <= 4 and 2 subk + out <= 16 (kssd_carry_ok: L3K10, L2K8,
+// K9 ...); other parameter sets ignore the payload and read the stream.
+template <int SUBK>
+KSSD_HD void kssd_extract_carry(const uint32_t (&W)[5], uint32_t Wm1, uint32_t b, uint32_t &top32, uint32_t &front)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 4, 1), s2 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 5, 1);
+#else
+    const uint32_t s1 = 0u - ((b >> 4) & 1u), s2 = 0u - ((b >> 5) & 1u);
+#endif
+#define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
+    const uint32_t pre = KSSD_BSEL(s2, KSSD_BSEL(s1, W[2], W[1]), KSSD_BSEL(s1, W[0], Wm1));
+    const uint32_t hi = KSSD_BSEL(s2, KSSD_BSEL(s1, W[3], W[2]), KSSD_BSEL(s1, W[1], W[0]));
+    const uint32_t lo = KSSD_BSEL(s2, KSSD_BSEL(s1, W[4], W[3]), KSSD_BSEL(s1, W[2], W[1]));
+#undef KSSD_BSEL
+    const uint32_t sh = (b & 15u) * 2u;
+    top32 = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
+    front = (uint32_t)(((((uint64_t)pre << 32) | hi) << sh) >> 32);  // low 8 bits: the 4 bases before position b
+}
+
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank
     uint32_t key;  // sub-context, KSSD_EMPTY_KEY when free
     uint32_t rank;
@@ -240,10 +264,17 @@ struct KssdG {  // one slot of the exact table: accepted sub-context -> permutat
 // 8-byte reads and never a probe loop (the scan kernel keeps them in flight across a whole chunk).
 KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t mul, uint32_t g_log2) { return (dim * mul) >> (32 - g_log2); }
 
-// Stage 2, arithmetic only (shared by the pipelined device path and the plain function below).
+// Stage 2, arithmetic only.  fwd = the 2k bases of the k-mer (first base in the highest of the 4k bits);
+// u = canonical k-mer (iseq2comem.c:245), dim = its sub-context (:246).
+KSSD_HD void kssd_s2_canon(const KssdParams &P, uint64_t fwd, uint64_t &u, uint32_t &dim)
+{
+    const uint64_t rev = kssd_revcomp(fwd, P.nb);
+    u = fwd < rev ? fwd : rev;
+    dim = (uint32_t)((u >> (2 * P.out)) & P.dim_mask);
+}
+
 // p0..p2 = packed words (b0>>4)+0..2, m0,m1 = mask words (b0>>5)+0..1, b0 = first base of the k-mer.
-// Returns true if all 2k bases are valid (run counter "base > TL", iseq2comem.c:243); u = canonical k-mer
-// (iseq2comem.c:245), dim = its sub-context (:246).
+// Returns true if all 2k bases are valid (run counter "base > TL", iseq2comem.c:243).
 KSSD_HD bool kssd_s2_decode(const KssdParams &P, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t m0, uint32_t m1,
                             uint32_t b0_low, uint64_t &u, uint32_t &dim)
 {
@@ -254,11 +285,17 @@ KSSD_HD bool kssd_s2_decode(const KssdParams &P, uint32_t p0, uint32_t p1, uint3
     const int sh = (int)(b0_low & 15u) * 2;
     const uint64_t hi64 = ((uint64_t)p0 << 32) | p1;
     const uint64_t top = sh ? ((hi64 << sh) | ((uint64_t)p2 >> (32 - sh))) : hi64;
-    const uint64_t fwd = top >> (64 - 2 * P.nb);
-    const uint64_t rev = kssd_revcomp(fwd, P.nb);
-    u = fwd < rev ? fwd : rev;
-    dim = (uint32_t)((u >> (2 * P.out)) & P.dim_mask);
+    kssd_s2_canon(P, top >> (64 - 2 * P.nb), u, dim);
     return valid;
+}
+
+// the carried payload (kssd_extract_carry: 20 bases from 4 in front of the sub-context on) holds the whole k-mer
+KSSD_HD bool kssd_carry_ok(const KssdParams &P) { return P.out <= 4 && 2 * P.subk + P.out <= 16; }
+KSSD_HD uint64_t kssd_carry_payload(uint32_t top32, uint32_t front) { return ((uint64_t)(front & 0xFFu) << 32) | top32; }
+// the 2k bases of the k-mer out of the payload: they start 4 - out bases into its 20
+KSSD_HD uint64_t kssd_carry_fwd(const KssdParams &P, uint64_t payload40)
+{
+    return (payload40 >> (2 * (16 + P.out - P.nb))) & ((1ull << (2 * P.nb)) - 1ull);
 }
 
 // reduced tuple (iseq2comem.c:250-253): outer bases packed above the rank, literally as the reference adds them

@@ -99,8 +99,6 @@ struct kssd_gpu_ctx {
     size_t cap_cand;
     uint32_t *d_cand_count;
     size_t cap_cand_count;
-    unsigned long long *d_lane_valid;  // per chunk, written by the scan (+1 zero word at the end)
-    size_t cap_lane_valid;
     uint64_t last_cand_cap;
     uint64_t cand_floor;    // per-slice capacity an overflowed attempt asked for (kept for the retries)
     double cand_factor;
@@ -136,10 +134,14 @@ struct kssd_gpu_ctx {
     uint32_t n_ref;
     uint64_t n_ref_ids;
     uint32_t *d_ref_sz;     // n_ref sketch sizes
-    uint32_t *d_hkeys;      // 2^h_log2 slots of 16 bytes (IdxSlot) + the posting bump cursor
-    uint32_t h_log2;
+    uint32_t *d_hkeys;      // the bucketed table: 16-byte slots (IdxSlot)
+    uint32_t h_log2;        // log2 of the number of buckets
+    uint32_t *d_bkt;        // per bucket: counters | starts | cursors | descriptors (kssd_dist.inc)
+    size_t cap_bkt;
+    uint32_t *d_sel_cnt, *d_sel_out;  // report selection (kssd_gpu_dist_select): per-row counts / starts, candidate pairs
+    size_t cap_sel_cnt, cap_sel_out;
     size_t cap_hash;
-    uint32_t *d_post;       // postings (genome indices) | entry -> slot | entry -> place in its posting
+    uint32_t *d_post;       // postings (genome indices) | entries partitioned by bucket: ids | genomes
     size_t cap_pairs;
     size_t cap_ref;
     // timing: ring of HIP event pairs around the dominant kernel of each path (0 = sketch scan, 1 = dist rows)
@@ -250,8 +252,8 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp, c->d_lane_valid,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off};
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp,
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -332,14 +334,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 // (it also zeroes the small per-call state: four separate memsets cost more than this whole kernel)
 __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes, uint64_t n_chunks,
                                  uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                 uint32_t n_slices, unsigned long long *__restrict__ lane_valid_tail,
-                                 uint32_t *__restrict__ status_words)
+                                 uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < sizeof(SketchStatus) / 4) status_words[c] = 0;
     if (c < n_genomes) cursor[c] = 0;
     if (c < n_slices) cand_count[c] = 0;
-    if (c < 2) lane_valid_tail[c] = 0;  // a k-mer that would end past the batch is not "known valid"
     if (c >= n_chunks) return;
     uint32_t lo = 0, hi = n_genomes;  // last g with chunk_off[g] <= c
     while (hi - lo > 1) {
@@ -354,12 +354,10 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
 // when genomes span many chunks.  The per-call state is zeroed by the first workgroups like above.
 __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes,
                                            uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                           uint32_t n_slices, unsigned long long *__restrict__ lane_valid_tail,
-                                           uint32_t *__restrict__ status_words)
+                                           uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
-    if (t < 2) lane_valid_tail[t] = 0;
     for (uint64_t i = t; i < n_genomes; i += (uint64_t)gridDim.x * blockDim.x) cursor[i] = 0;
     for (uint64_t i = t; i < n_slices; i += (uint64_t)gridDim.x * blockDim.x) cand_count[i] = 0;
     if (blockIdx.x >= n_genomes) return;
@@ -383,11 +381,9 @@ struct ScanArgs {
     const uint32_t *mask;
     unsigned long long n_chunks;
     const uint8_t *tab;             // stage-1 table followed by the Bloom filter (SCAN_TAB_BYTES)
-    unsigned long long *cand;       // (waves of the grid) * cand_cap global positions
+    ulonglong2 *cand;               // (waves of the grid) * cand_cap records {global position, carried k-mer bits}
     unsigned long long cand_cap;    // per wave
     uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
-    unsigned long long *lane_valid; // per chunk: bit l <=> all 64 positions of lane l are bases (saves the exact stage
-                                    // its mask read, a second random HBM line per candidate, in all but ~1 % of the cases)
     SketchStatus *status;
 };
 
@@ -407,19 +403,25 @@ __device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long
     r.M[0] = m.x; r.M[1] = m.y;
 }
 
+// A buffered stage-1 candidate (8 bytes in LDS):
+//   x  [11:0] position inside its chunk (lane << 6 | b)   [22:12] chunk - c0, modulo 2048 (entries live for a few chunks)
+//      [23]   1 = all 2k bases are known to be valid (the lane's and both neighbours' 64 positions are bases)
+//      [31:24] the 4 bases in front of the sub-context
+//   y  the 16 bases from the sub-context's first base on (its top 4*SUBK bits are the Bloom pattern)
 // Stage 1.5 for up to 64 buffered stage-1 candidates (entries [first, first+n) of the wave's buffer): Bloom test
 // of the pattern the owning lane cut out of its registers, survivors go straight to the wave's slice of the
-// candidate list (plain stores, nothing to wait for).  Returns how many survived (wave-uniform).
-template <int ABL>
+// candidate list (plain 16-byte stores, nothing to wait for) as {global position, k-mer payload | valid << 63}.
+// crel = (the chunk being worked on) - c0.  Returns how many survived (wave-uniform).
+template <int SUBK, int ABL>
 __device__ __forceinline__ uint32_t bloom_round(const ScanArgs &a, const uint32_t *bloom, unsigned long long wid,
-                                                unsigned long long c0, const uint2 *cbuf, uint32_t first, uint32_t n,
+                                                unsigned long long c0, uint32_t crel, const uint2 *cbuf, uint32_t first, uint32_t n,
                                                 uint32_t stored, uint32_t lane, uint32_t &abl_acc)
 {
     bool pass = false;
     uint2 e = make_uint2(0u, 0u);
     if (lane < n) {
         e = cbuf[first + lane];
-        const uint32_t h = kssd_bloom_hash(e.y);
+        const uint32_t h = kssd_bloom_hash(e.y >> (32 - 4 * SUBK));
         const uint32_t bits = kssd_bloom_bits(h);
         pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
     }
@@ -427,7 +429,12 @@ __device__ __forceinline__ uint32_t bloom_round(const ScanArgs &a, const uint32_
     if (pass) {
         const unsigned long long at = (unsigned long long)stored + rank_in(bal);
         if (ABL != 0) abl_acc ^= e.x;
-        else if (at < a.cand_cap) a.cand[wid * a.cand_cap + at] = ((c0 + (e.x >> 12)) << 12) | (e.x & 4095u);
+        else if (at < a.cand_cap) {
+            const uint32_t age = (crel - (e.x >> 12)) & 2047u;  // chunks since the entry was buffered
+            const unsigned long long chunk = c0 + crel - age;
+            a.cand[wid * a.cand_cap + at] = make_ulonglong2((chunk << 12) | (e.x & 4095u),
+                                                            kssd_carry_payload(e.y, e.x >> 24) | ((unsigned long long)((e.x >> 23) & 1u) << 63));
+        }
     }
     return (uint32_t)__builtin_popcountll(bal);
 }
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // loop counter and every counter derived from a ballot live in VGPRs and the loops run on exec masks
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = lane_id();
-    uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // (chunk offset << 12 | position, pattern)
+    uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates, see bloom_round
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
     // static partition: every wave of the grid owns one contiguous run of chunks
@@ -478,6 +485,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
     __syncthreads();
     if (c0 >= c1) return;
+    // what a lane needs from its neighbours for the hand-over to the exact stage: the packed word in front of its own
+    // (lane 0: the last word of the chunk before, carried in an SGPR from step to step) and whether the neighbours' 64
+    // positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour is not looked at: its
+    // candidates -- 1.6 % -- let the exact stage read the mask)
+    uint32_t s_tail = c0 ? __builtin_amdgcn_readfirstlane(a.packed[c0 * 256 - 1]) : 0u;
+    uint64_t vb_prev = 0;
 
     // prologue: chunk c0 through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
@@ -496,10 +509,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         // table-read issue raised, 0.529 with everything but the loop at 2, 0.526 as it is here.
         __builtin_amdgcn_s_setprio(3);
         load_chunk(a, c + 3 < clast ? c + 3 : clast, lane, far);
-        if (ABL == 0) {
-            const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
-            if (lane == 0) a.lane_valid[c] = vb;
-        }
+        const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
         uint32_t rawa[Gp::NMAX];
         if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
         if (ABL == 1) {
@@ -517,12 +527,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 // every pass takes one candidate of every lane that still has one: cut its pattern out of the lane's
                 // registers and buffer (position, pattern) by ballot compaction.  No LDS read in this loop: a read
                 // would have to wait behind the table reads of chunk c+1 that are in flight
-                const uint32_t ebase = ((uint32_t)(c - c0) << 12) | (lane << 6);
+                const uint32_t crel = (uint32_t)(c - c0);
+                const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);  // lane and both neighbours all bases
+                const uint32_t ebase = ((crel & 2047u) << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
+                // the neighbouring lane's last packed word (v_mov_b32 wave_shr:1; lane 0 keeps the previous chunk's tail)
+                const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s_tail, (int)cur.W[3], 0x138, 0xf, 0xf, false);
                 for (uint64_t hbal = __ballot((cl | ch) != 0); hbal; hbal = __ballot((cl | ch) != 0)) {
                     const bool has = (cl | ch) != 0;
                     if (cn + 64 > CBUF) {  // dense parameter sets only: make room
                         wave_lds_sync();
-                        const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - 64, 64, stored, lane, abl_acc);
+                        const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
                         stored += m;
                         n_rounded += 64;
                         cn -= 64;
@@ -536,18 +550,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                         const uint32_t rest = word & (word - 1u);
                         cl = in_lo ? rest : 0u;
                         ch = in_lo ? ch : rest;
-                        cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b, kssd_extract_m<SUBK>(cur.W, b));
+                        uint32_t top32, front;
+                        kssd_extract_carry<SUBK>(cur.W, wm1, b, top32, front);
+                        cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b | (front << 24), top32);
                     }
                     cn += __builtin_popcountll(hbal);
                 }
             }
+            s_tail = __builtin_amdgcn_readlane(cur.W[3], 63);
+            vb_prev = vb;
             __builtin_amdgcn_s_setprio(2);
             // chunk c+1: alignment A is in; nothing is outstanding in LDS now, which is the cheap moment for a
             // stage-1.5 round; then alignment B goes in flight across the loop edge
             kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
             if (ABL != 2 && cn >= 64) {
                 wave_lds_sync();
-                const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - 64, 64, stored, lane, abl_acc);
+                const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, (uint32_t)(c - c0), cbuf, cn - 64, 64, stored, lane, abl_acc);
                 stored += m;
                 n_rounded += 64;
                 cn -= 64;
@@ -564,7 +582,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     while (cn) {
         const uint32_t n = cn < 64 ? cn : 64;
         wave_lds_sync();
-        const uint32_t m = bloom_round<ABL>(a, bloom, wid, c0, cbuf, cn - n, n, stored, lane, abl_acc);
+        const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, (uint32_t)(c1 - 1 - c0), cbuf, cn - n, n, stored, lane, abl_acc);
         stored += m;
         n_rounded += n;
         cn -= n;
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     }
     if (ABL != 0) {
         for (int i = 0; i < Gp::NMAX; i++) abl_acc ^= raw[i];
-        if (abl_acc == 0x9e3779b9u) a.cand[0] = abl_acc;  // keeps the ablated work alive
+        if (abl_acc == 0x9e3779b9u) a.cand[0] = make_ulonglong2(abl_acc, 0);  // keeps the ablated work alive
     }
 }
 
@@ -610,11 +628,11 @@ struct ExactArgs {
     const uint32_t *chunk_gid;
     const unsigned long long *chunk_off;  // per genome, in chunks
     const KssdG *G;
-    const unsigned long long *cand;
+    const ulonglong2 *cand;  // {global position of the sub-context, carried k-mer bits | known-valid << 63}
     unsigned long long cand_cap;
     const uint32_t *cand_count;
-    const unsigned long long *lane_valid;
     uint32_t n_slices;
+    uint32_t carry;  // kssd_carry_ok: the payload holds the whole k-mer, the packed stream is not read again
     const unsigned long long *reg_off;
     uint32_t *cursor;
     void *regions;  // uint32_t[] or, in first-position mode, unsigned long long[]
@@ -639,26 +657,35 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
     bool ok = false;
     uint32_t dr = 0, gid = 0, gpos = 0;
     if (i < n) {
-        // same arithmetic as kssd_stage2 (kssd_core.h), arranged so that the reads that do not depend on each
-        // other are issued together: {genome of the chunk, packed words, mask words}, then {genome bounds, both
-        // cuckoo slots} -- three memory round trips instead of five.  Out-of-genome k-mers are rejected at the end;
-        // their reads stay inside the batch (position clamped at 0, slack words after the last chunk).
-        const long long s = (long long)x.cand[(unsigned long long)w * x.cand_cap + i];
+        // same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases out of the scanning
+        // lane's registers (kssd_extract_carry) and whether all of them are known to be bases, so this stage is a
+        // streaming read of 16-byte records plus two probes of the L2-resident cuckoo table; the packed stream is read
+        // again only for parameter sets whose k-mer is longer than the 20 carried bases, the mask only for the ~2 % of the
+        // candidates near an invalid position.  Out-of-genome k-mers are rejected at the end; their reads stay inside the
+        // batch (position clamped at 0, slack words after the last chunk).
+        const ulonglong2 cd = x.cand[(unsigned long long)w * x.cand_cap + i];
+        const long long s = (long long)cd.x;
         const long long b0 = s - P.out;
         const unsigned long long b0c = b0 < 0 ? 0ull : (unsigned long long)b0;
         gid = x.chunk_gid[(unsigned long long)s >> 12];
-        const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
-        // (non-temporal: every line is used once; 119 -> 115 us)
-        const uint32_t p0 = __builtin_nontemporal_load(pp), p1 = __builtin_nontemporal_load(pp + 1), p2 = __builtin_nontemporal_load(pp + 2);
-        // validity: the scan's per-lane summary (a small, cache-resident array) answers for ~99 % of the k-mers;
-        // only the rest read the mask words themselves
-        const unsigned long long blk0 = b0c >> 6, blk1 = (b0c + (unsigned long long)P.nb - 1ull) >> 6;
-        const bool known = ((x.lane_valid[blk0 >> 6] >> (blk0 & 63ull)) & (x.lane_valid[blk1 >> 6] >> (blk1 & 63ull)) & 1ull) != 0;
-        uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
-        if (!known) { m0 = mp[0]; m1 = mp[1]; }
+        const bool known = (cd.y >> 63) != 0;
         uint64_t u;
         uint32_t dim;
-        const bool valid = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u, dim);
+        bool valid = true;
+        if (x.carry) {
+            kssd_s2_canon(P, kssd_carry_fwd(P, cd.y & 0xFFFFFFFFFFull), u, dim);
+            if (!known) {
+                const uint32_t *mp = x.mask + (b0c >> 5);
+                const uint64_t m64 = (uint64_t)mp[0] | ((uint64_t)mp[1] << 32), need = (1ull << P.nb) - 1ull;
+                valid = ((m64 >> (b0c & 31ull)) & need) == need;
+            }
+        } else {
+            const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
+            const uint32_t p0 = __builtin_nontemporal_load(pp), p1 = __builtin_nontemporal_load(pp + 1), p2 = __builtin_nontemporal_load(pp + 2);
+            uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+            if (!known) { m0 = mp[0]; m1 = mp[1]; }
+            valid = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u, dim);
+        }
         const KssdG e1 = x.G[kssd_g_slot(dim, P.g_mul[0], P.g_log2)];
         const KssdG e2 = x.G[(1u << P.g_log2) + kssd_g_slot(dim, P.g_mul[1], P.g_log2)];
         const long long glo = (long long)(x.chunk_off[gid] * KSSD_CHUNK), ghi = (long long)(x.chunk_off[gid + 1] * KSSD_CHUNK);
@@ -1198,10 +1225,9 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     const uint32_t n_slices = (uint32_t)(grid > 0 ? grid : 1) * SCAN_WAVES;
     uint64_t cand_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * (2.0 * rate + 0.0005) * c->cand_factor / n_slices) + 256;
     if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
-    if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices * 2)) != KSSD_OK) return rc;  // 16-byte records
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
-    if ((rc = ensure(&c->d_lane_valid, &c->cap_lane_valid, (size_t)n_chunks + 2)) != KSSD_OK) return rc;
     pl.big_min = big_min; pl.max_cap = max_cap; pl.max_big = max_big; pl.cand_cap = cand_cap; pl.n_slices = n_slices; pl.grid = grid;
     pl.valid = true;
     return KSSD_OK;
@@ -1232,13 +1258,13 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
     if (pl.n_chunks >= 64ull * pl.n_genomes) {  // long genomes: fill the map genome by genome
         hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
-                           c->d_lane_valid + pl.n_chunks, reinterpret_cast<uint32_t *>(c->d_status));
+                           reinterpret_cast<uint32_t *>(c->d_status));
         HIPCK(hipGetLastError());
         return KSSD_OK;
     }
     hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
                        (const uint64_t *)c->d_chunk_off, pl.n_genomes, pl.n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
-                       pl.n_slices, c->d_lane_valid + pl.n_chunks, reinterpret_cast<uint32_t *>(c->d_status));
+                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status));
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -1250,8 +1276,7 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     int rc;
     ScanArgs a;
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
-    a.cand = (unsigned long long *)c->d_cand; a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
-    a.lane_valid = c->d_lane_valid;
+    a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.status = c->d_status;
     const int grid = pl.grid;
     const unsigned evi = c->ev_n[0] % EV_RING;
@@ -1286,8 +1311,8 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     ExactArgs x;
     x.packed = pl.d_packed; x.mask = pl.d_mask; x.chunk_gid = c->d_chunk_gid;
     x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;
-    x.cand = (const unsigned long long *)c->d_cand; x.cand_cap = pl.cand_cap; x.cand_count = c->d_cand_count;
-    x.lane_valid = c->d_lane_valid;
+    x.cand = reinterpret_cast<const ulonglong2 *>(c->d_cand); x.cand_cap = pl.cand_cap; x.cand_count = c->d_cand_count;
+    x.carry = kssd_carry_ok(c->P) ? 1u : 0u;
     x.n_slices = pl.n_slices;
     x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
     x.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;

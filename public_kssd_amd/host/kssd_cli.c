@@ -183,6 +183,14 @@ typedef struct {
 
 static kssd_gpu_ctx *g_ctx;
 
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+
 static void gck(int rc, const char *what)
 {
     if (rc != KSSD_OK) die(rc == KSSD_ERR_CAPACITY ? ENOSPC : EIO, "%s: %s", what, kssd_gpu_strerror(rc));
@@ -226,8 +234,9 @@ typedef struct job {
     struct job *next;
 } job;
 
-static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize)
+static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, double *t_call)
 {
+    const double tc0 = now_s();
     kssd_batch *b = j->b;
     const int is_fq = j->is_fq;
     const uint32_t first_file = (uint32_t)j->first_file;
@@ -253,6 +262,7 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
+    *t_call += now_s() - tc0;
     /* -A: a second pass over the same batch returns the occurrences of every id (ids ascending inside a genome,
      * the same set as above) */
     uint64_t *aoff = NULL;
@@ -310,7 +320,8 @@ typedef struct {
     uint32_t hashsize;
     kssd_shuf_hdr hdr;
     const int32_t *table;
-    double t_gpu; /* summed over the workers: seconds inside the sketch calls */
+    double t_gpu;   /* summed over the workers: seconds inside process_job */
+    double t_call;  /* ... of which inside the kssd_gpu_sketch_batch* calls (H2D, kernels, D2H) */
 } pipeline;
 
 typedef struct {
@@ -318,13 +329,6 @@ typedef struct {
     int device;
     pthread_t th;
 } worker;
-
-static double now_s(void)
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec + 1e-9 * ts.tv_nsec;
-}
 
 static void *worker_main(void *arg)
 {
@@ -343,7 +347,8 @@ static void *worker_main(void *arg)
         pthread_mutex_unlock(&pl->mu);
         if (!j) break;
         const double t0 = now_s();
-        process_job(ctx, j, pl->o, pl->fl, pl->hashsize);
+        double tcall = 0;
+        process_job(ctx, j, pl->o, pl->fl, pl->hashsize, &tcall);
         const double dt = now_s() - t0;
         kssd_batch_clear(j->b);
         pthread_mutex_lock(&pl->mu);
@@ -352,6 +357,7 @@ static void *worker_main(void *arg)
         j->next = pl->done;
         pl->done = j;
         pl->t_gpu += dt;
+        pl->t_call += tcall;
         pthread_cond_broadcast(&pl->cv);
         pthread_mutex_unlock(&pl->mu);
     }
@@ -478,15 +484,17 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     double t_read = 0, t_tok = 0;
     uint64_t n_bytes = 0;
     int done = 0, n_jobs = 0;
+    /* the text buffers of a wave's files are kept from wave to wave (no fresh memory per file) */
+    unsigned char **txt = calloc((size_t)threads, sizeof *txt);
+    size_t *txt_cap = calloc((size_t)threads, sizeof *txt_cap);
+    size_t *len = calloc((size_t)threads, sizeof *len);
+    int *trc = calloc((size_t)threads, sizeof *trc);
+    uint64_t *lines = calloc((size_t)threads, sizeof *lines);
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
         const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
-        unsigned char **txt = calloc((size_t)nw, sizeof *txt);
-        size_t *len = calloc((size_t)nw, sizeof *len);
-        int *trc = calloc((size_t)nw, sizeof *trc);
-        uint64_t *lines = calloc((size_t)nw, sizeof *lines);
         double t0 = now_s();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-        for (int i = 0; i < nw; i++) trc[i] = kssd_slurp(fl->path[i0 + i], &txt[i], &len[i]); /* read + gunzip, one file each */
+        for (int i = 0; i < nw; i++) trc[i] = kssd_slurp_reuse(fl->path[i0 + i], &txt[i], &txt_cap[i], &len[i]); /* read + gunzip, one file each */
         t_read += now_s() - t0;
         for (int i = 0; i < nw; i++) {
             if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
@@ -518,8 +526,6 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             for (int i = r0; i < r1; i++) {
                 trc[i] = kssd_batch_fill_text(b, first + (uint32_t)(i - r0), fq && o->abundance ? 2 : fq, txt[i], len[i], o->kmerqlty, &lines[i]);
                 if (trc[i] == KSSD_HOST_ERR_EMPTY) trc[i] = 0; /* an empty file is an empty genome here */
-                free(txt[i]);
-                txt[i] = NULL;
             }
             t_tok += now_s() - t0;
             for (int i = r0; i < r1; i++) {
@@ -541,11 +547,13 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             n_jobs++;
             r0 = r1;
         }
-        free(txt);
-        free(len);
-        free(trc);
-        free(lines);
     }
+    for (int i = 0; i < threads; i++) free(txt[i]);
+    free(txt);
+    free(txt_cap);
+    free(len);
+    free(trc);
+    free(lines);
     pthread_mutex_lock(&pl.mu);
     pl.closed = 1;
     pthread_cond_broadcast(&pl.cv);
@@ -600,9 +608,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
         fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
                         "\"host_threads\": %d, \"s_total\": %.6f, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
-                        "\"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
+                        "\"s_workers_summed\": %.6f, \"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
                 fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, t_read, t_tok,
-                pl.t_gpu, now_s() - t_sketched);
+                pl.t_gpu, pl.t_call, now_s() - t_sketched);
 }
 
 /* stage II (run_stageII, command_dist.c:381-417): the index FILES are for the reference binary; our own search
@@ -639,6 +647,8 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
     /* the count matrix lives in the file itself, mapped like the reference maps it (command_dist.c:741-748): Q x R may
      * exceed the host's memory, the device works it off in row tiles (kssd_gpu_dist) */
     uint32_t *shared = NULL;
+    uint64_t *pair_off = NULL;
+    uint32_t *pair_ref = NULL, *pair_shared = NULL;
     int skfd = -1;
     if (o->skf[0]) { /* -f: reuse a kept shared-k-mer file (command_dist.c:735-738) */
         skfd = open(o->skf, O_RDONLY);
@@ -657,15 +667,32 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
         const int have = kssd_gpu_device_count();
         if (have <= 0) die(ENODEV, "kssd_gpu_create_for_dist: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
         if (o->device + n_dev > have) die(ENODEV, "--gpus %d from device %d: only %d device(s) visible", n_dev, o->device, have);
-        int *devs = malloc((size_t)n_dev * sizeof *devs);
-        for (int i = 0; i < n_dev; i++) devs[i] = o->device + i;
-        /* query rows in contiguous blocks, one per device; every device indexes all references (command_dist.c:774-785) */
-        gck(kssd_gpu_dist_multi(devs, n_dev, qry.kmerlen, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
-        free(devs);
+        if (o->num_neigb > 0 || o->mut_dist_max < 1.0) {
+            /* -N / -D leave few lines: let the device pick the pairs that can be printed (output_ctrl's rules with a
+             * margin), the host ranks / tests those exactly and formats only them */
+            if (o->num_neigb > 1024 || (uint32_t)o->num_neigb > ref.n)
+                die(EINVAL, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, ref.n);
+            gck(kssd_gpu_create_for_dist(&g_ctx, qry.kmerlen, o->device), "kssd_gpu_create_for_dist");
+            gck(kssd_gpu_dist_select(g_ctx, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, o->metric, o->correction, qry.dim_rd_len,
+                                     o->mut_dist_max, o->num_neigb, shared, &pair_off, &pair_ref, &pair_shared), "dist");
+            kssd_gpu_destroy(g_ctx);
+            g_ctx = NULL;
+        } else {
+            int *devs = malloc((size_t)n_dev * sizeof *devs);
+            for (int i = 0; i < n_dev; i++) devs[i] = o->device + i;
+            /* query rows in contiguous blocks, one per device; every device indexes all references (command_dist.c:774-785) */
+            gck(kssd_gpu_dist_multi(devs, n_dev, qry.kmerlen, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
+            free(devs);
+        }
         if (cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
     }
     kssd_print_opt po = {o->metric, o->outfields, o->correction, o->mut_dist_max, o->num_neigb, o->p};
-    if ((rc = kssd_distance_print(distf, shared, &ref, &qry, &po)) != 0)
+    rc = pair_off ? kssd_distance_print_pairs(distf, pair_off, pair_ref, pair_shared, &ref, &qry, &po)
+                  : kssd_distance_print(distf, shared, &ref, &qry, &po);
+    kssd_gpu_free(pair_off);
+    kssd_gpu_free(pair_ref);
+    kssd_gpu_free(pair_shared);
+    if (rc != 0)
         die(rc == KSSD_HOST_ERR_PARAM ? EINVAL : EIO, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, ref.n);
     if (cells && shared) munmap(shared, cells * 4);
     if (skfd >= 0) close(skfd);

@@ -585,8 +585,26 @@ static void sb_add(strbuf *b, const char *s, size_t n)
     b->n += n;
 }
 
+/* rows either dense (shared != NULL: Q x R counts) or as the pairs a selection left (poff/pr/ps: CSR over the queries,
+ * references ascending inside a row) */
+static int print_rows(const char *path, const uint32_t *shared, const uint64_t *poff, const uint32_t *pr, const uint32_t *ps,
+                      const kssd_sketchset *ref, const kssd_sketchset *qry, const kssd_print_opt *o);
+
 int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_sketchset *ref, const kssd_sketchset *qry,
                         const kssd_print_opt *o)
+{
+    return print_rows(path, shared, NULL, NULL, NULL, ref, qry, o);
+}
+
+int kssd_distance_print_pairs(const char *path, const uint64_t *pair_off, const uint32_t *pair_ref, const uint32_t *pair_shared,
+                              const kssd_sketchset *ref, const kssd_sketchset *qry, const kssd_print_opt *o)
+{
+    if (!pair_off) return KSSD_HOST_ERR_PARAM;
+    return print_rows(path, NULL, pair_off, pair_ref, pair_shared, ref, qry, o);
+}
+
+static int print_rows(const char *path, const uint32_t *shared, const uint64_t *poff, const uint32_t *pr, const uint32_t *ps,
+                      const kssd_sketchset *ref, const kssd_sketchset *qry, const kssd_print_opt *o)
 {
     static const char *cols[2][3] = {{"Jaccard\tMashD", "P-value(J)\tFDR(J)", "Jaccard_CI\tMashD_CI"},
                                      {"ContainmentM\tAafD", "P-value(C)\tFDR(C)", "ContainmentM_CI\tAafD_CI"}};
@@ -609,17 +627,23 @@ int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_ske
             strbuf *b = &sb[q - q0];
             b->n = 0;
             char line[1024];
-            const uint32_t *row = shared + (size_t)q * R;
+            const uint32_t *row = shared ? shared + (size_t)q * R : NULL;
+            const uint64_t nrow = row ? R : poff[q + 1] - poff[q]; /* entries of this row */
+            const uint32_t *rr = row ? NULL : pr + poff[q], *rs = row ? NULL : ps + poff[q];
+#define ROW_REF(i) (row ? (uint32_t)(i) : rr[i])
+#define ROW_SHARED(i) (row ? row[i] : rs[i])
             const uint32_t Y = (uint32_t)(qry->off[q + 1] - qry->off[q]);
             if (o->n_max) { /* -N: the n_max largest raw metrics, earlier reference wins ties (:1212-1227) */
                 double bm[1026];
                 int bi[1026];
                 for (int i = 0; i < o->n_max; i++) { bm[i] = 0; bi[i] = -1; }
-                for (uint32_t r = 0; r < R; r++) {
-                    const uint32_t X = (uint32_t)(ref->off[r + 1] - ref->off[r]), s = row[r];
+                uint32_t bs[1026];
+                for (uint64_t e = 0; e < nrow; e++) {
+                    const uint32_t r = ROW_REF(e), s = ROW_SHARED(e);
+                    const uint32_t X = (uint32_t)(ref->off[r + 1] - ref->off[r]);
                     const double m = o->metric == 1 ? (double)s / (X < Y ? X : Y) : (double)s / (X + Y - s);
                     for (int i = o->n_max - 1; i >= 0; i--) {
-                        if (m > bm[i]) { bm[i + 1] = bm[i]; bi[i + 1] = bi[i]; bm[i] = m; bi[i] = (int)r; }
+                        if (m > bm[i]) { bm[i + 1] = bm[i]; bi[i + 1] = bi[i]; bs[i + 1] = bs[i]; bm[i] = m; bi[i] = (int)r; bs[i] = s; }
                         else break;
                     }
                 }
@@ -627,16 +651,19 @@ int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_ske
                     if (bi[i] < 0) continue;
                     const uint32_t r = (uint32_t)bi[i];
                     int len = format_line(line, sizeof line, qry->names[q], ref->names[r],
-                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, row[r], kmerlen, drl, o, cmprsn);
+                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, bs[i], kmerlen, drl, o, cmprsn);
                     if (len > 1) sb_add(b, line, (size_t)len);
                 }
             } else {
-                for (uint32_t r = 0; r < R; r++) {
+                for (uint64_t e = 0; e < nrow; e++) {
+                    const uint32_t r = ROW_REF(e);
                     int len = format_line(line, sizeof line, qry->names[q], ref->names[r],
-                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, row[r], kmerlen, drl, o, cmprsn);
+                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, ROW_SHARED(e), kmerlen, drl, o, cmprsn);
                     if (len > 1) sb_add(b, line, (size_t)len);
                 }
             }
+#undef ROW_REF
+#undef ROW_SHARED
         }
         for (uint32_t q = q0; q < q1; q++)
             if (sb[q - q0].n) fwrite(sb[q - q0].p, 1, sb[q - q0].n, f);

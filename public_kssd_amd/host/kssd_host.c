@@ -8,6 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #define CHUNK_BASES 4096u
@@ -268,6 +271,7 @@ typedef struct {
     uint64_t base_pos; /* first position of this genome in the batch */
     uint64_t p;        /* positions written so far */
     int pending_break; /* a run-breaking byte was seen since the last base */
+    uint32_t pw, mw;   /* the packed / mask word being put together (stored when full, gw_put) */
     uint64_t limit;    /* fixed mode (kssd_batch_fill_text): the genome's reserved positions; 0 = growing mode */
     uint32_t genome;   /* fixed mode: which genome */
 } gwriter;
@@ -281,23 +285,48 @@ static inline int gw_room(gwriter *w)
     return KSSD_HOST_OK;
 }
 
+/* one position: the words are put together in registers and stored whole, 16 bases / 32 mask bits at a time (the batch
+ * may live in page-locked memory, where a read-modify-write per base costs a bus round trip); a genome starts on a
+ * chunk boundary and has one writer, so no word is shared */
+static inline int gw_put(gwriter *w, uint32_t code, uint32_t valid)
+{
+    if ((w->p & (CHUNK_BASES - 1)) == 0) { /* entering a chunk: room for it */
+        int rc = gw_room(w);
+        if (rc) return rc;
+    }
+    const unsigned q = (unsigned)(w->p & 31);
+    w->pw |= code << (30 - 2 * (q & 15));
+    w->mw |= valid << q;
+    w->p++;
+    if ((q & 15) == 15) {
+        const uint64_t g = w->base_pos + w->p - 1;
+        w->b->packed[g >> 4] = w->pw;
+        w->pw = 0;
+        if (q == 31) {
+            w->b->mask[g >> 5] = w->mw;
+            w->mw = 0;
+        }
+    }
+    return KSSD_HOST_OK;
+}
+
+/* store what the last, incomplete words hold */
+static inline void gw_flush(gwriter *w)
+{
+    if (w->p & 15) w->b->packed[(w->base_pos + w->p) >> 4] = w->pw;
+    if (w->p & 31) w->b->mask[(w->base_pos + w->p) >> 5] = w->mw;
+    w->pw = w->mw = 0;
+}
+
 static inline int gw_base(gwriter *w, unsigned code)
 {
     int rc;
     if (w->pending_break) {
         /* one invalid position stands for any stretch of bytes that reset the run counter */
-        if (w->p) {
-            if ((rc = gw_room(w)) != 0) return rc;
-            w->p++; /* bits stay 0 */
-        }
+        if (w->p && (rc = gw_put(w, 0, 0)) != 0) return rc;
         w->pending_break = 0;
     }
-    if ((rc = gw_room(w)) != 0) return rc;
-    const uint64_t g = w->base_pos + w->p;
-    w->b->packed[g >> 4] |= (uint32_t)code << (30 - 2 * (unsigned)(g & 15));
-    w->b->mask[g >> 5] |= 1u << (unsigned)(g & 31);
-    w->p++;
-    return KSSD_HOST_OK;
+    return gw_put(w, code, 1);
 }
 
 static void gw_start(gwriter *w, kssd_batch *b)
@@ -306,6 +335,7 @@ static void gw_start(gwriter *w, kssd_batch *b)
     w->base_pos = b->n_chunks * CHUNK_BASES;
     w->p = 0;
     w->pending_break = 0;
+    w->pw = w->mw = 0;
     w->limit = 0;
     w->genome = 0;
 }
@@ -316,6 +346,7 @@ static void gw_start_fixed(gwriter *w, kssd_batch *b, uint32_t g)
     w->base_pos = b->chunk_off[g] * CHUNK_BASES;
     w->p = 0;
     w->pending_break = 0;
+    w->pw = w->mw = 0;
     w->limit = (b->chunk_off[g + 1] - b->chunk_off[g]) * CHUNK_BASES;
     if (!w->limit) w->limit = 1; /* an empty reservation: nothing may be written */
     w->genome = g;
@@ -324,6 +355,7 @@ static void gw_start_fixed(gwriter *w, kssd_batch *b, uint32_t g)
 static void gw_finish(gwriter *w)
 {
     kssd_batch *b = w->b;
+    gw_flush(w);
     if (w->limit) { /* the layout was fixed by kssd_batch_reserve */
         b->n_pos[w->genome] = w->p;
         return;
@@ -620,6 +652,60 @@ int kssd_slurp(const char *path, unsigned char **buf, size_t *len)
     }
     gzclose(g);
     *buf = p;
+    *len = n;
+    return KSSD_HOST_OK;
+}
+
+/* the same into a buffer the caller keeps from file to file (grown when needed): no allocation, no page faults of fresh
+ * memory per file.  Plain files are read straight with read(2); gzip'ed ones (magic 1f 8b) go through zlib. */
+int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t *len)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return KSSD_HOST_ERR_IO;
+    unsigned char magic[2];
+    ssize_t got = pread(fd, magic, 2, 0);
+    *len = 0;
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        gzFile g = gzdopen(fd, "rb");
+        if (!g) { close(fd); return KSSD_HOST_ERR_IO; }
+        gzbuffer(g, 1 << 20);
+        size_t n = 0;
+        for (;;) {
+            if (*cap - n < (1u << 20)) {
+                size_t nc = *cap + *cap / 2 + (1u << 22);
+                unsigned char *q = realloc(*buf, nc);
+                if (!q) { gzclose(g); return KSSD_HOST_ERR_NOMEM; }
+                *buf = q;
+                *cap = nc;
+            }
+            size_t room = *cap - n;
+            int r = gzread(g, *buf + n, (unsigned)(room > (1u << 30) ? (1u << 30) : room));
+            if (r < 0) { gzclose(g); return KSSD_HOST_ERR_IO; }
+            if (r == 0) break;
+            n += (size_t)r;
+        }
+        gzclose(g);
+        *len = n;
+        return KSSD_HOST_OK;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return KSSD_HOST_ERR_IO; }
+    size_t want = (size_t)st.st_size, n = 0;
+    for (;;) { /* st_size is a hint: read until end of file */
+        if (*cap < n + (want > n ? want - n : 0) + 4096) {
+            size_t nc = n + (want > n ? want - n : 0) + (1u << 20);
+            unsigned char *q = realloc(*buf, nc);
+            if (!q) { close(fd); return KSSD_HOST_ERR_NOMEM; }
+            *buf = q;
+            *cap = nc;
+        }
+        ssize_t r = read(fd, *buf + n, *cap - n);
+        if (r < 0) { close(fd); return KSSD_HOST_ERR_IO; }
+        if (r == 0) break;
+        n += (size_t)r;
+        if (n >= want) want = n + (1u << 20);
+    }
+    close(fd);
     *len = n;
     return KSSD_HOST_OK;
 }

@@ -82,6 +82,9 @@ int kssd_batch_append(kssd_batch *dst, const kssd_batch *src);
 
 /* whole file into memory through zlib; caller frees *buf */
 int kssd_slurp(const char *path, unsigned char **buf, size_t *len);
+/* the same into a malloc'd buffer the caller keeps from file to file: *buf / *cap are grown (realloc) when the file
+ * does not fit, *len receives the bytes read; the caller frees *buf in the end */
+int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t *len);
 
 /* ---- derived constants (seq2co_global_var_initial iseq2comem.c:54-77, get_hashsz command_dist.c:217-236) */
 typedef struct kssd_derived {
@@ -169,6 +172,12 @@ typedef struct kssd_print_opt {
 } kssd_print_opt;
 int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_sketchset *ref, const kssd_sketchset *qry,
                         const kssd_print_opt *opt);
+/* the same report from the pairs a device-side selection left (kssd_gpu_dist_select): row q's candidates are
+ * pair_ref / pair_shared [pair_off[q], pair_off[q+1]), references ascending.  The selection must be a superset of what
+ * the options print (every pair with a positive metric for -N, every pair within -D otherwise); the exact -N ranking
+ * and the exact -D test are applied here, on the host's libm, so the text equals the dense report's byte for byte. */
+int kssd_distance_print_pairs(const char *path, const uint64_t *pair_off, const uint32_t *pair_ref, const uint32_t *pair_shared,
+                              const kssd_sketchset *ref, const kssd_sketchset *qry, const kssd_print_opt *opt);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,21 @@
 """torch.distributed plumbing of the multi-GPU path (one process per GPU, RCCL over xGMI on the GPU box, gloo in
-the CPU tests).  The path shards by genome (sketching) and by query row block (distances); its ONE exchange step
-is an all-gather of every rank's packed sketches so that each rank can index all references.
+the CPU tests).  The path shards by genome (sketching: no communication) and by block of the distance matrix; its
+ONE exchange step is an all-gather of every rank's packed sketches.
 
-Everything here is static-shape tensor code on the caller's device: no size ever visits the host, so the step
-stays free of host synchronisation.
+Two partitions of the distance matrix (reference: one owner per output row,
+command_dist.c:774-785):
+
+  "query"      the north_star partition, valid for any query set: every rank gathers ALL reference sketches, builds
+               the full index, and computes the rows of ITS OWN query block against all references.  Rank r writes
+               rows [r*Q, (r+1)*Q) x all columns.  Per-rank cost at N ranks: index over N x the ids, Q probes rows.
+  "transpose"  all-pairs only (queries = references, every metric of the path is symmetric): every rank indexes
+               only ITS OWN sketches and uses all gathered sketches as query rows; the [all] x [own] block it writes
+               is the transpose of its query block.  The index build, the part "query" repeats on every rank, stays
+               constant per rank; the price is N x the probes, most of which miss.
+
+Everything is static-shape tensor code on the caller's device: no size ever visits the host, so a step stays free
+of host synchronisation.  The compute calls go through an `engine` with the two device-level entry points of the
+C ABI (public_kssd_amd.GpuCtx: index_build_device / dist_device); the CPU tests plug in an oracle-backed engine.
 """
 import torch
 
@@ -47,5 +59,95 @@ class SketchGather:
 
 
 def query_block(rank, G):
-    """rows of the global all-pairs matrix this rank computes: its own genomes"""
+    """rows of the global matrix rank `rank` owns when every rank holds G queries"""
     return rank * G, (rank + 1) * G
+
+
+class ShardedSearch:
+    """One rank's share of the distance matrix between `world` x G reference sketches (G contributed by every rank)
+    and the queries, in either partition (see the module docstring).
+
+        s = ShardedSearch(world, rank, G, cap, device, engine, partition="query")
+        s.step(off_l, ids_l, shared, planes, max_ids)                      # all-pairs: the rank's queries = its refs
+        s.step(off_l, ids_l, shared, planes, max_ids, q=(qoff, qids, Q))   # "query" only: any local query block
+        rows, cols, transposed = s.block(Q)     # where `shared` sits in the global matrix
+
+    `shared` (and each plane) is a flat tensor the caller preallocates with s.cells(Q) elements.
+    """
+
+    def __init__(self, world, rank, G, cap, device, engine, partition="query"):
+        if partition not in ("query", "transpose"):
+            raise ValueError("partition must be 'query' or 'transpose'")
+        self.world, self.rank, self.G, self.cap = world, rank, G, cap
+        self.engine, self.partition = engine, partition
+        self.gather = SketchGather(world, G, cap, device) if world > 1 else None
+
+    def cells(self, Q=None):
+        Q = self.G if Q is None else Q
+        return Q * self.G * self.world if self.partition == "query" else self.G * self.world * self.G
+
+    def block(self, Q=None):
+        """(row range, column range, transposed) of this rank's output in the global [world*Q] x [world*G] matrix.
+        transposed: `shared` holds the block as [columns-of-the-block-as-rows]: shared.view(world*G, G) is the
+        transpose of rows [rank*G, (rank+1)*G) (all-pairs, symmetric)."""
+        Q = self.G if Q is None else Q
+        if self.partition == "query":
+            return (self.rank * Q, (self.rank + 1) * Q), (0, self.world * self.G), False
+        return (self.rank * self.G, (self.rank + 1) * self.G), (0, self.world * self.G), True
+
+    def index(self, off_l, ids_l, max_ids, stream=None, tstream=None, group=None):
+        """the exchange (N > 1) and the index build of one step; nothing is synchronised.
+        max_ids: upper bound of the ids one rank holds (sizes the index).  tstream: the torch stream object that
+        wraps `stream` (the collective is issued under it)."""
+        w, G = self.world, self.G
+        if w == 1:
+            roff, rids = off_l, ids_l
+        elif tstream is not None:
+            with torch.cuda.stream(tstream):
+                roff, rids = self.gather(off_l, ids_l, group=group)
+        else:
+            roff, rids = self.gather(off_l, ids_l, group=group)
+        self._gathered = (roff, rids)
+        if self.partition == "query":   # full index on every rank
+            self.engine.index_build_device(roff, rids, w * G, max_ids * w, stream)
+        else:                           # own index only
+            self.engine.index_build_device(off_l, ids_l, G, max_ids, stream)
+        return roff, rids
+
+    def rows(self, off_l, ids_l, shared, planes, q=None, stream=None):
+        """the rank's block of the matrix against the index of the last index() call"""
+        w, G = self.world, self.G
+        if q is not None and self.partition != "query":
+            raise ValueError("a separate query set needs the 'query' partition (the transpose trick is all-pairs only)")
+        pl = list(planes) if planes is not None else [None] * 4
+        if self.partition == "query":   # own query block as rows
+            qoff, qids, Q = (off_l, ids_l, G) if q is None else q
+            self.engine.dist_device(qoff, qids, Q, 0, Q, shared, *pl, stream=stream)
+        else:                           # everybody's sketches as rows: the [w*G] x [G] block = transpose of the own query block
+            roff, rids = self._gathered
+            self.engine.dist_device(roff, rids, w * G, 0, w * G, shared, *pl, stream=stream)
+
+    def step(self, off_l, ids_l, shared, planes, max_ids, q=None, stream=None, tstream=None, group=None):
+        """index() + rows(): the exchange, the index build and the rows of one step; nothing is synchronised"""
+        if q is not None and self.partition != "query":
+            raise ValueError("a separate query set needs the 'query' partition (the transpose trick is all-pairs only)")
+        out = self.index(off_l, ids_l, max_ids, stream=stream, tstream=tstream, group=group)
+        self.rows(off_l, ids_l, shared, planes, q=q, stream=stream)
+        return out
+
+
+def assemble(world, G, blocks, Q=None):
+    """global [world*Q] x [world*G] matrix from the ranks' outputs: blocks[rank] = (flat array, (rows, cols, transposed))
+    as ShardedSearch.block describes them.  numpy in, numpy out (used by the tests and by single-host gathers)."""
+    import numpy as np
+    Q = G if Q is None else Q
+    first = np.asarray(blocks[0][0])
+    full = np.zeros((world * Q, world * G), dtype=first.dtype)
+    for rank in range(world):
+        flat, ((r0, r1), (c0, c1), transposed) = blocks[rank]
+        a = np.asarray(flat)
+        if transposed:
+            full[r0:r1, c0:c1] = a.reshape(c1 - c0, r1 - r0).T
+        else:
+            full[r0:r1, c0:c1] = a.reshape(r1 - r0, c1 - c0)
+    return full

@@ -36,6 +36,23 @@ static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mas
                 if ((bloom[kssd_bloom_word(h)] & bits) != bits) continue;
                 n_cand[1]++;
                 uint32_t dr;
+                if (kssd_carry_ok(P)) {
+                    // what the scanning lane hands over (the neighbouring lane's last word in front of its own) must give
+                    // the k-mer the packed stream holds
+                    const uint32_t Wm1 = (c * 256 + lane * 4) ? packed[c * 256 + lane * 4 - 1] : 0u;
+                    uint32_t top32, front;
+                    kssd_extract_carry<SUBK>(W, Wm1, (uint32_t)b, top32, front);
+                    if ((top32 >> (32 - 4 * SUBK)) != kssd_extract_m<SUBK>(W, (uint32_t)b)) { n_cand[0] = ~0ull; return; }
+                    const int64_t b0 = cbeg + lane * 64 + b - P.out;
+                    if (b0 >= 0) {
+                        const uint64_t pw = (uint64_t)b0 >> 4;
+                        uint64_t u1, u2;
+                        uint32_t d1, d2;
+                        kssd_s2_decode(P, packed[pw], packed[pw + 1], packed[pw + 2], ~0u, ~0u, (uint32_t)b0, u1, d1);
+                        kssd_s2_canon(P, kssd_carry_fwd(P, kssd_carry_payload(top32, front)), u2, d2);
+                        if (u1 != u2 || d1 != d2) { n_cand[0] = ~0ull; return; }
+                    }
+                }
                 if (kssd_stage2(P, cbeg + lane * 64 + b, lo, hi, packed, mask, G, dr)) {
                     out.push_back(((uint64_t)gid[c] << 32) | dr);
                     if (where) where->push_back((uint64_t)(cbeg + lane * 64 + b));  // position of the sub-context start

@@ -68,6 +68,7 @@ def test_stage1_stage2_match_oracle(emu, k, subk, dr, gw):
     for t in tx:
         b.add_fasta(t)
     got, ncand = run_emu(emu, shuf, b, gw=gw)
+    assert ncand[0] != 2 ** 64 - 1, "the k-mer carried from the scanning lane differs from the packed stream's"
     sk = ko.Sketcher(shuf.table, k, subk, dr)
     for g, t in enumerate(tx):
         ids, comps = sk.fasta(t, with_comps=True)

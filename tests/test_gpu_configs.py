@@ -211,7 +211,7 @@ def test_config4_fastq_reads_to_containment(refs_10k, shuf_l3k10):
         want = np.sort(sk.fastq(fq, Q=0, M=M))
         qoff, qids = ctx.sketch_batch(b, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY, min_occ=M)
         assert np.array_equal(qids, want), (M, len(qids), len(want))
-        assert len(qids) > (12_000 if M == 1 else 5_000)
+        assert len(qids) > (5_000 if M == 1 else 2_500)   # 16 clade mates share most of their k-mers
         # containment of the read set in every reference
         d_qoff = torch.from_numpy(qoff.astype(np.int64)).to(dev)
         d_qids = torch.from_numpy(qids.view(np.int32)).to(dev)

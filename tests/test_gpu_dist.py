@@ -109,3 +109,123 @@ def test_more_references_than_one_lds_row(gpu_ctx):
     assert shared.shape == (2, R)
     assert np.array_equal(shared, ko.shared_counts(roff, rids, qoff, qids, threads=4))
     assert shared[0, 39_999] >= 1 and shared[:, ::3].min() >= 1
+
+
+def test_query_rows_sharded_over_a_device_list(gpu_ctx):
+    """kssd_gpu_dist_multi: contiguous blocks of query rows, one per entry of the device list, every entry indexes all
+    references (command_dist.c:774-785: one owner per row).  On a one-GPU box the entries name device 0 repeatedly;
+    the blocks must assemble into exactly what one device computes -- counts and all four planes bit for bit."""
+    rng = np.random.default_rng(77)
+    roff, rids = random_sketches(rng, 57, 300, 900, 1 << 28, clades=6)
+    qoff, qids = random_sketches(rng, 41, 0, 700, 1 << 28, clades=6)
+    one = gpu_ctx.dist(roff, rids, qoff, qids)
+    assert np.array_equal(one[0], ko.shared_counts(roff, rids, qoff, qids, threads=4))
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 7):
+        got = K.dist_multi(devs, 20, roff, rids, qoff, qids)
+        for a, b in zip(one, got):
+            assert np.array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
+                                  b.view(np.int64) if b.dtype == np.float64 else b), devs
+    # more entries than query rows, counts only, and an empty query set
+    got = K.dist_multi([0] * 5, 20, roff, rids, qoff[:3], qids[:int(qoff[2])], planes=False)
+    assert np.array_equal(got, one[0][:2])
+    got = K.dist_multi([0, 0], 20, roff, rids, np.zeros(1, np.uint64), np.zeros(0, np.uint32), planes=False)
+    assert got.shape == (0, 57)
+    with pytest.raises(K.KssdError) as e:                   # a device that does not exist is an error, not a fallback
+        K.dist_multi([0, 99], 20, roff, rids, qoff, qids, planes=False)
+    assert e.value.code == K.capi.ERR_NO_DEVICE
+
+
+def test_host_level_search_tiles_its_rows(gpu_ctx):
+    """Q x R larger than one device tile (512 MiB of rows): the host-level call works the rows off in tiles with two
+    buffers; 6 000 x 30 000 counts + one plane = 2.1 GB of output"""
+    rng = np.random.default_rng(5)
+    R, Q = 30_000, 6_000
+    rsz = rng.integers(1, 4, R)
+    roff = np.concatenate([[0], np.cumsum(rsz)]).astype(np.uint64)
+    rids = rng.integers(1, 5000, int(roff[-1])).astype(np.uint32)      # small universe: long postings
+    for g in range(R):                                                   # distinct inside a sketch
+        s, e = int(roff[g]), int(roff[g + 1])
+        rids[s:e] = np.sort(rids[s] + np.arange(e - s, dtype=np.uint32))
+    qsz = rng.integers(0, 5, Q)
+    qoff = np.concatenate([[0], np.cumsum(qsz)]).astype(np.uint64)
+    qids = rng.integers(1, 5000, int(qoff[-1])).astype(np.uint32)
+    for g in range(Q):
+        s, e = int(qoff[g]), int(qoff[g + 1])
+        qids[s:e] = np.sort(qids[s] + np.arange(e - s, dtype=np.uint32)) if e > s else qids[s:e]
+    shared = np.zeros((Q, R), dtype=np.uint32)
+    cont = np.zeros((Q, R), dtype=np.float64)
+    K.capi._gck(K.gpu_lib().kssd_gpu_dist(gpu_ctx.h, roff.ctypes.data, rids.ctypes.data, R, qoff.ctypes.data, qids.ctypes.data, Q,
+                                          shared.ctypes.data, None, None, cont.ctypes.data, None))
+    want = ko.shared_counts(roff, rids, qoff, qids, threads=8)
+    assert np.array_equal(shared, want)
+    den = np.minimum(np.diff(roff)[None, :], np.diff(qoff)[:, None]).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wc = want / den
+    assert np.array_equal(np.isnan(cont), np.isnan(wc)) and np.array_equal(cont[~np.isnan(wc)], wc[~np.isnan(wc)])
+
+
+def test_index_buckets_too_large_for_lds(gpu_ctx):
+    """the index is built bucket by bucket (top bits of id * 0x9E3779B1); ids crafted to fall into ONE bucket make it
+    larger than a workgroup's LDS table and send it down the in-HBM build -- same counts"""
+    rng = np.random.default_rng(31)
+    pool = rng.choice(1 << 28, size=400_000, replace=False).astype(np.uint64)
+    mix = (pool * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    crowd = pool[(mix >> np.uint64(29)) == 0].astype(np.uint32)      # top 3 bits zero: bucket 0 of 8 (and of 2, 4)
+    assert len(crowd) > 40_000
+    R = 12
+    off, ids = [0], []
+    for g in range(R):                                               # 12 references x 500 ids, heavy sharing, 6 000 entries
+        own = np.sort(rng.choice(crowd[:900], size=500, replace=False))
+        ids.append(own)
+        off.append(off[-1] + len(own))
+    roff, rids = np.array(off, np.uint64), np.concatenate(ids)
+    qoff = np.array([0, 700, 700, 1500], np.uint64)
+    qids = np.concatenate([np.sort(rng.choice(crowd[:1200], 700, replace=False)), np.sort(rng.choice(crowd, 800, replace=False))]).astype(np.uint32)
+    shared = gpu_ctx.dist(roff, rids, qoff, qids, planes=False)
+    assert np.array_equal(shared, ko.shared_counts(roff, rids, qoff, qids))
+    assert shared[0].min() > 100 and shared[1].sum() == 0
+    # and a reference set of ONE huge sketch (a read set as reference): several workgroups walk one genome
+    big = np.sort(rng.choice(1 << 28, size=300_000, replace=False)).astype(np.uint32)
+    roff1 = np.array([0, len(big)], np.uint64)
+    q = np.sort(np.concatenate([big[::7], rng.choice(1 << 28, 1000)])).astype(np.uint32)
+    q = np.unique(q)
+    got = gpu_ctx.dist(roff1, big, np.array([0, len(q)], np.uint64), q, planes=False)
+    assert int(got[0, 0]) == len(np.intersect1d(q, big))
+
+
+def _sketchset(names, off, ids, kmerlen=20, dim_rd_len=6):
+    return K.SketchSet(123, kmerlen, dim_rd_len, 1, names, off, ids)
+
+
+@pytest.mark.parametrize("opts", [dict(metric=0, n_max=3), dict(metric=1, n_max=1), dict(metric=0, dthreshold=0.05),
+                                  dict(metric=1, dthreshold=0.02, correction=1), dict(metric=0, n_max=5, dthreshold=0.03),
+                                  dict(metric=1, dthreshold=0.2, pfield=0), dict(metric=0, correction=1, n_max=4, pfield=1)])
+def test_report_selection_on_the_device_leaves_the_same_text(gpu_ctx, tmp_path, opts):
+    """kssd_gpu_dist_select + kssd_distance_print_pairs against the dense report (whose text the golden tests pin to the
+    reference's): byte-identical distance.out for -N, -D, --correction, both metrics, and far fewer pairs formatted"""
+    rng = np.random.default_rng(hash(str(sorted(opts.items()))) % (2 ** 32))
+    roff, rids = random_sketches(rng, 60, 800, 1300, 1 << 28, clades=6)
+    qoff, qids = random_sketches(rng, 25, 0, 1200, 1 << 28, clades=6)
+    n = len(qids) // 3
+    qids[:n] = rng.choice(rids, size=n)                                   # relatives among the references
+    for i in range(len(qoff) - 1):
+        s, e = int(qoff[i]), int(qoff[i + 1])
+        u = np.unique(qids[s:e])
+        fill = rng.choice(1 << 28, size=(e - s) - len(u), replace=False).astype(np.uint32)
+        qids[s:e] = np.sort(np.concatenate([u, fill]))
+    ref = _sketchset(["ref/r%03d.fa" % i for i in range(60)], roff, rids)
+    qry = _sketchset(["qry/q%03d.fa" % i for i in range(25)], qoff, qids)
+    poff, pref, psh, dense = gpu_ctx.dist_select(roff, rids, qoff, qids, metric=opts.get("metric", 0), correction=opts.get("correction", 0),
+                                                 dim_rd_len=6, dthreshold=opts.get("dthreshold", 1.0), n_max=opts.get("n_max", 0), dense=True)
+    want_shared = ko.shared_counts(roff, rids, qoff, qids)
+    assert np.array_equal(dense, want_shared)
+    for q in range(25):                                                       # the candidates carry the right counts, ascending
+        r = pref[int(poff[q]):int(poff[q + 1])]
+        assert np.all(np.diff(r.astype(np.int64)) > 0)
+        assert np.array_equal(psh[int(poff[q]):int(poff[q + 1])], want_shared[q, r])
+    assert int(poff[-1]) < 25 * 60 // 2                                      # a real selection
+    a, b = str(tmp_path / "dense.out"), str(tmp_path / "pairs.out")
+    K.distance_print(a, want_shared, ref, qry, threads=2, **opts)
+    K.distance_print_pairs(b, poff, pref, psh, ref, qry, threads=2, **opts)
+    ta, tb = open(a, "rb").read(), open(b, "rb").read()
+    assert ta == tb and ta.count(b"\n") > 1

@@ -79,3 +79,89 @@ def test_all_gather_and_compaction(world):
                                 rids[:roff[-1]].astype(np.uint32))
         assert np.array_equal(np.diag(full)[qb:qe], np.diff(roff)[qb:qe])
     assert sorted(blocks) == [(r * G, (r + 1) * G) for r in range(world)]   # the blocks tile the query axis
+
+
+class OracleEngine:
+    """the two device-level entry points ShardedSearch needs, computed by the CPU oracle on CPU tensors (test
+    infrastructure: lets the sharding logic run under gloo without a GPU)"""
+
+    def index_build_device(self, roff, rids, n_ref, max_ids, stream=None):
+        self.roff = roff.numpy()[:n_ref + 1].astype(np.uint64)
+        self.rids = rids.numpy()[:int(self.roff[-1])].astype(np.uint32)
+        assert int(self.roff[-1]) <= max_ids
+
+    def dist_device(self, qoff, qids, n_qry, q_begin, q_end, shared, *planes, stream=None):
+        qo = qoff.numpy()[:n_qry + 1].astype(np.uint64)
+        qi = qids.numpy()[:int(qo[-1])].astype(np.uint32)
+        full = ko.shared_counts(self.roff, self.rids, qo, qi)
+        shared.view(-1)[:(q_end - q_begin) * full.shape[1]] = torch.from_numpy(full[q_begin:q_end].astype(np.int32).reshape(-1))
+
+
+def _search_worker(rank, world, port, G, cap, Qn, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from public_kssd_amd.shard import ShardedSearch
+        off, ids = make_rank_data(rank, G, cap)
+        qoff, qids = make_rank_data(1000 + rank, Qn, cap)
+        out = {}
+        for part in ("query", "transpose"):
+            s = ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition=part)
+            shared = torch.zeros(s.cells(), dtype=torch.int32)
+            s.step(torch.from_numpy(off), torch.from_numpy(ids), shared, None, cap)
+            out[part] = (shared.numpy().copy(), s.block())
+        # a query set of its own (Q != R): only the north_star partition can do it
+        s = ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition="query")
+        shared = torch.zeros(s.cells(Qn), dtype=torch.int32)
+        s.step(torch.from_numpy(off), torch.from_numpy(ids), shared, None, cap,
+               q=(torch.from_numpy(qoff), torch.from_numpy(qids), Qn))
+        out["search"] = (shared.numpy().copy(), s.block(Qn))
+        try:
+            ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition="transpose").step(
+                torch.from_numpy(off), torch.from_numpy(ids), shared, None, cap, q=(torch.from_numpy(qoff), torch.from_numpy(qids), Qn))
+            out["refused"] = False
+        except ValueError:
+            out["refused"] = True
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _csr_of(seed0, world, G, cap):
+    offs, idl = [0], []
+    for r in range(world):
+        off, ids = make_rank_data(seed0 + r, G, cap)
+        for g in range(G):
+            idl.append(ids[off[g]:off[g + 1]])
+            offs.append(offs[-1] + int(off[g + 1] - off[g]))
+    return np.array(offs, dtype=np.uint64), np.concatenate(idl).astype(np.uint32)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_blocks_of_both_partitions_assemble_into_the_oracle_matrix(world):
+    """every rank computes its block (north_star partition: own query rows x gathered full index; transpose partition:
+    all gathered rows x own index); the blocks put together must be the oracle's full matrix -- for all-pairs in
+    both partitions, and for a query set of its own (Q != R) in the north_star partition"""
+    from public_kssd_amd.shard import assemble
+    G, cap, Qn = 13, 700, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_search_worker, args=(r, world, port, G, cap, Qn, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    roff, rids = _csr_of(0, world, G, cap)
+    want = ko.shared_counts(roff, rids, roff, rids)
+    for part in ("query", "transpose"):
+        full = assemble(world, G, [res[r][part] for r in range(world)])
+        assert np.array_equal(full.astype(np.uint32), want), part
+    qoff, qids = _csr_of(1000, world, Qn, cap)
+    want_q = ko.shared_counts(roff, rids, qoff, qids)
+    full = assemble(world, G, [res[r]["search"] for r in range(world)], Q=Qn)
+    assert full.shape == (world * Qn, world * G) and np.array_equal(full.astype(np.uint32), want_q)
+    assert all(res[r]["refused"] for r in range(world))
