@@ -46,6 +46,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_cores():
+    """host threads worth starting: the machine's processors, but not more than the CPU time the container may use
+    (cgroup cpu.max): on the measurement box 256 processors are visible under a quota of 16"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 # ------------------------------------------------------------------------------------------------------
 # synthetic batch, generated and packed on the device (setup, untimed)
 # ------------------------------------------------------------------------------------------------------
@@ -190,13 +209,16 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
                                 "sample": fa_desc + ", `oracle/_ref/kssd dist -p %d -L L3K10.shuf` wall time incl. process start "
                                           "and the 64 MiB .shuf load" % p_ref,
                                 "mbase_per_s": nb * reps / 1e6 / t_ref}
+            # stage II and the search of the reference get slower with very many threads (an omp region per query row,
+            # command_dist.c:1238; measured on a 256-thread box: 118 s at -p 256): they run with at most 16
+            p_srch = max(1, min(p_ref, 16))
             t0 = time.time()
-            ko.run_ref(["dist", "-p", p_ref, "-o", "ref_idx", "ref_sk"], cwd=d, timeout=1800)
+            ko.run_ref(["dist", "-p", p_srch, "-o", "ref_idx", "ref_sk"], cwd=d, timeout=1800)
             t_idx = time.time() - t0
             t0 = time.time()
-            ko.run_ref(["dist", "-p", p_ref, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", "ref_sk"], cwd=d, timeout=1800)
+            ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", "ref_sk"], cwd=d, timeout=1800)
             t_srch = time.time() - t0
-            out["dist_reference"] = {"value": nf * nf / t_srch, "unit": "pairs/s", "cores": p_ref, "kind": "reference",
+            out["dist_reference"] = {"value": nf * nf / t_srch, "unit": "pairs/s", "cores": p_srch, "kind": "reference",
                                      "sample": "%d x %d all-pairs of the reference's own sketches of those files: `kssd dist -r <mco> "
                                                "--keepskf <co>` wall time incl. distance.out text; its stage II (2 GiB mco.index, "
                                                "co2mco.c:57-62) took %.1f s on top and is not in the figure" % (nf, nf, t_idx),
@@ -321,7 +343,7 @@ def run_fastq(a, shuf, dev):
                 ctx.sketch_phase(ph, None)
             if ev:
                 ev[4].record()
-            ctx.dist_device(qoff, qids, 1, 0, 1, shared, None, None, cont, aaf)
+            ctx.dist_device(qoff, qids, 1, 0, 1, shared, None, None, cont, aaf, max_row_ids=qcap)
             if ev:
                 ev[5].record()
                 timed.append(ev)
@@ -386,7 +408,7 @@ def run_fastq(a, shuf, dev):
     for M in (1, 2):
         r = res_m[M]
         qo = np.array([0, r["qtotal"]], dtype=np.uint64)
-        want = ko.shared_counts(oh, ih, qo, r["qids"], threads=os.cpu_count() or 1)
+        want = ko.shared_counts(oh, ih, qo, r["qids"], threads=host_cores())
         assert np.array_equal(r["shared"][None, :], want), "containment row -n %d: shared counts != oracle" % M
         oJ, oMD, oC, oAD = ko.metrics_batch(szh[None, :], np.array([[r["qtotal"]]], dtype=np.uint32), want, 20)
         assert np.array_equal(r["cont"][None, :].view(np.int64), oC.view(np.int64))
@@ -684,7 +706,7 @@ def main():
             ol = off_l.cpu().numpy()
             il = ids_l.cpu().numpy().view(np.uint32)
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
-            cores = os.cpu_count() or 1
+            cores = host_cores()
             cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files)
             res["cpu_baseline"] = cb.get("reference", cb["port"])
             res["cpu_baseline_port"] = cb["port"]

@@ -200,6 +200,16 @@ int kssd_gpu_dist_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32
                          double *d_jaccard, double *d_mashd, double *d_contain, double *d_aafd,
                          void *stream);
 
+/*
+ * The same for query rows that may be very long (a read set sketched as ONE genome holds hundreds of thousands of ids):
+ * max_row_ids = an upper bound of the ids of the longest row in [q_begin, q_end); beyond 16 384 the row's ids are shared
+ * by several workgroups (the rows are zeroed and summed with atomics, the workgroup that arrives last computes the
+ * metrics).  The results are the same.
+ */
+int kssd_gpu_dist_device_long(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32_t *d_qids, uint32_t n_qry,
+                              uint32_t q_begin, uint32_t q_end, uint64_t max_row_ids, uint32_t *d_shared,
+                              double *d_jaccard, double *d_mashd, double *d_contain, double *d_aafd, void *stream);
+
 /* host-level convenience: HOST CSR in, HOST matrices out (caller-allocated, Q x R; planes may be NULL) */
 int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref,
                   const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,

@@ -40,7 +40,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
-    "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select",
+    "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
 ]
 
 
@@ -121,6 +121,7 @@ def gpu_lib():
         L.kssd_gpu_index_build_device.argtypes = [vp, vp, vp, u32, u64, vp]
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
+        L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
         L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
         L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
@@ -642,7 +643,12 @@ class GpuCtx:
         _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
 
     def dist_device(self, d_qoff, d_qids, n_qry, q_begin, q_end, d_shared, d_j=None, d_m=None, d_c=None, d_a=None,
-                    stream=None):
+                    stream=None, max_row_ids=0):
+        """max_row_ids: an upper bound of the longest query row's ids (0 = rows of ordinary sketch size)"""
+        if max_row_ids:
+            _gck(gpu_lib().kssd_gpu_dist_device_long(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, max_row_ids,
+                                                     _ptr(d_shared), _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
+            return
         _gck(gpu_lib().kssd_gpu_dist_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_shared),
                                             _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
 

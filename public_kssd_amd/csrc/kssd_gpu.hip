@@ -138,6 +138,8 @@ struct kssd_gpu_ctx {
     uint32_t h_log2;        // log2 of the number of buckets
     uint32_t *d_bkt;        // per bucket: counters | starts | cursors | descriptors (kssd_dist.inc)
     size_t cap_bkt;
+    uint32_t *d_arrive;     // long query rows: arrival counters of the workgroups that share a row
+    size_t cap_arrive;
     uint32_t *d_sel_cnt, *d_sel_out;  // report selection (kssd_gpu_dist_select): per-row counts / starts, candidate pairs
     size_t cap_sel_cnt, cap_sel_out;
     size_t cap_hash;
@@ -253,7 +255,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -356,13 +358,15 @@ __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_of
                                            uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
                                            uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid = (genomes or more, parts): workgroup (g, y) writes every gridDim.y-th run of 256 chunks of genome g
+    const uint64_t t = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
     if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
-    for (uint64_t i = t; i < n_genomes; i += (uint64_t)gridDim.x * blockDim.x) cursor[i] = 0;
-    for (uint64_t i = t; i < n_slices; i += (uint64_t)gridDim.x * blockDim.x) cand_count[i] = 0;
+    for (uint64_t i = t; i < n_genomes; i += nt) cursor[i] = 0;
+    for (uint64_t i = t; i < n_slices; i += nt) cand_count[i] = 0;
     if (blockIdx.x >= n_genomes) return;
     const uint32_t g = blockIdx.x;
-    for (uint64_t c = chunk_off[g] + threadIdx.x; c < chunk_off[g + 1]; c += blockDim.x) chunk_gid[c] = g;
+    for (uint64_t c = chunk_off[g] + (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; c < chunk_off[g + 1]; c += (uint64_t)gridDim.y * blockDim.x)
+        chunk_gid[c] = g;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -640,10 +644,13 @@ struct ExactArgs {
     SketchStatus *status;
 };
 
+#define EXACT_PER 4  // candidates per thread: the kernel is a chain of dependent memory round trips (record -> genome of the chunk ->
+                     // cuckoo slots -> cursor -> staging region), so every thread keeps four chains in flight
 template <typename K>
 __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactArgs x)
 {
-    // grid = (blocks per slice, slices): block (bx, w) takes candidates [256 bx, 256 bx + 256) of scan wave w
+    // grid = (blocks per slice, slices): block (bx, w) takes candidates [1024 bx, 1024 bx + 1024) of scan wave w,
+    // thread t the candidates 1024 bx + 256 j + t
     const uint32_t lane = lane_id();
     const uint32_t w = blockIdx.y;
     const uint32_t want = x.cand_count[w];
@@ -652,64 +659,118 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         atomicMax(&x.status->cand_need, want);
     }
     const uint32_t n = want < x.cand_cap ? want : (uint32_t)x.cand_cap;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x >= n) return;  // whole block past the end of the slice
-    bool ok = false;
-    uint32_t dr = 0, gid = 0, gpos = 0;
-    if (i < n) {
-        // same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases out of the scanning
-        // lane's registers (kssd_extract_carry) and whether all of them are known to be bases, so this stage is a
-        // streaming read of 16-byte records plus two probes of the L2-resident cuckoo table; the packed stream is read
-        // again only for parameter sets whose k-mer is longer than the 20 carried bases, the mask only for the ~2 % of the
-        // candidates near an invalid position.  Out-of-genome k-mers are rejected at the end; their reads stay inside the
-        // batch (position clamped at 0, slack words after the last chunk).
-        const ulonglong2 cd = x.cand[(unsigned long long)w * x.cand_cap + i];
-        const long long s = (long long)cd.x;
-        const long long b0 = s - P.out;
-        const unsigned long long b0c = b0 < 0 ? 0ull : (unsigned long long)b0;
-        gid = x.chunk_gid[(unsigned long long)s >> 12];
-        const bool known = (cd.y >> 63) != 0;
-        uint64_t u;
-        uint32_t dim;
-        bool valid = true;
-        if (x.carry) {
-            kssd_s2_canon(P, kssd_carry_fwd(P, cd.y & 0xFFFFFFFFFFull), u, dim);
-            if (!known) {
-                const uint32_t *mp = x.mask + (b0c >> 5);
-                const uint64_t m64 = (uint64_t)mp[0] | ((uint64_t)mp[1] << 32), need = (1ull << P.nb) - 1ull;
-                valid = ((m64 >> (b0c & 31ull)) & need) == need;
-            }
-        } else {
-            const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
-            const uint32_t p0 = __builtin_nontemporal_load(pp), p1 = __builtin_nontemporal_load(pp + 1), p2 = __builtin_nontemporal_load(pp + 2);
-            uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
-            if (!known) { m0 = mp[0]; m1 = mp[1]; }
-            valid = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u, dim);
-        }
-        const KssdG e1 = x.G[kssd_g_slot(dim, P.g_mul[0], P.g_log2)];
-        const KssdG e2 = x.G[(1u << P.g_log2) + kssd_g_slot(dim, P.g_mul[1], P.g_log2)];
-        const long long glo = (long long)(x.chunk_off[gid] * KSSD_CHUNK), ghi = (long long)(x.chunk_off[gid + 1] * KSSD_CHUNK);
-        const bool h1 = e1.key == dim, h2 = e2.key == dim;
-        ok = valid && (h1 || h2) && b0 >= glo && b0 + P.nb <= ghi;
-        gpos = (uint32_t)(s - glo);  // first-position mode: genomes are < 2^32 positions there (checked on the host)
-        dr = kssd_s2_tuple(P, u, h1 ? e1.rank : e2.rank);
+    const uint32_t i0 = blockIdx.x * (256u * EXACT_PER) + threadIdx.x;
+    if (blockIdx.x * (256u * EXACT_PER) >= n) return;  // whole block past the end of the slice
+    // Same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases out of the scanning
+    // lane's registers (kssd_extract_carry) and whether all of them are known to be bases, so this stage is a streaming
+    // read of 16-byte records plus two probes of the L2-resident cuckoo table; the packed stream is read again only for
+    // parameter sets whose k-mer is longer than the 20 carried bases, the mask only for the ~2 % of the candidates near an
+    // invalid position.  Out-of-genome k-mers are rejected at the end; their reads stay inside the batch (position clamped
+    // at 0, slack words after the last chunk).
+    bool ok[EXACT_PER];
+    uint32_t dr[EXACT_PER], gid[EXACT_PER], gpos[EXACT_PER], dim[EXACT_PER];
+    ulonglong2 cd[EXACT_PER];
+    uint64_t u[EXACT_PER];
+    bool valid[EXACT_PER];
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) {
+        const uint32_t i = i0 + 256u * j;
+        ok[j] = i < n;
+        cd[j] = ok[j] ? x.cand[(unsigned long long)w * x.cand_cap + i] : make_ulonglong2(0ull, 0ull);
     }
-    // group the wave's survivors by genome (candidates arrive in stream order: almost always one genome)
-    uint64_t todo = __ballot(ok);
-    while (todo) {
-        const uint32_t leader = __builtin_ctzll(todo);
-        const uint32_t g = __builtin_amdgcn_readlane(gid, leader);
-        const bool mine = ok && gid == g;
-        const uint64_t grp = __ballot(mine);
-        uint32_t at = 0;
-        if (lane == leader) at = atomicAdd(&x.cursor[g], (uint32_t)__builtin_popcountll(grp));
-        at = __builtin_amdgcn_readlane(at, leader);
-        if (mine) {
-            const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
-            const unsigned long long pos = (unsigned long long)at + rank_in(grp);
-            if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = x.by_pos ? KeyOps<K>::make(gpos, dr) : KeyOps<K>::make(dr, gpos);
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) gid[j] = ok[j] ? x.chunk_gid[cd[j].x >> 12] : 0u;
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) {
+        const long long b0 = (long long)cd[j].x - P.out;
+        const unsigned long long b0c = b0 < 0 ? 0ull : (unsigned long long)b0;
+        const bool known = (cd[j].y >> 63) != 0;
+        valid[j] = true;
+        u[j] = 0;
+        dim[j] = 0;
+        if (ok[j]) {
+            if (x.carry) {
+                kssd_s2_canon(P, kssd_carry_fwd(P, cd[j].y & 0xFFFFFFFFFFull), u[j], dim[j]);
+                if (!known) {
+                    const uint32_t *mp = x.mask + (b0c >> 5);
+                    const uint64_t m64 = (uint64_t)mp[0] | ((uint64_t)mp[1] << 32), need = (1ull << P.nb) - 1ull;
+                    valid[j] = ((m64 >> (b0c & 31ull)) & need) == need;
+                }
+            } else {
+                const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
+                const uint32_t p0 = __builtin_nontemporal_load(pp), p1 = __builtin_nontemporal_load(pp + 1), p2 = __builtin_nontemporal_load(pp + 2);
+                uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+                if (!known) { m0 = mp[0]; m1 = mp[1]; }
+                valid[j] = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u[j], dim[j]);
+            }
         }
-        todo &= ~grp;
+    }
+    KssdG e1[EXACT_PER], e2[EXACT_PER];
+    unsigned long long glo[EXACT_PER], ghi[EXACT_PER];
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) {
+        e1[j] = x.G[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
+        e2[j] = x.G[(1u << P.g_log2) + kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)];
+        glo[j] = x.chunk_off[gid[j]] * KSSD_CHUNK;
+        ghi[j] = x.chunk_off[gid[j] + 1] * KSSD_CHUNK;
+    }
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) {
+        const long long s = (long long)cd[j].x, b0 = s - P.out;
+        const bool h1 = e1[j].key == dim[j], h2 = e2[j].key == dim[j];
+        ok[j] = ok[j] && valid[j] && (h1 || h2) && b0 >= (long long)glo[j] && b0 + P.nb <= (long long)ghi[j];
+        gpos[j] = (uint32_t)(s - (long long)glo[j]);  // first-position mode: genomes are < 2^32 positions there (checked on the host)
+        dr[j] = kssd_s2_tuple(P, u[j], h1 ? e1[j].rank : e2[j].rank);
+    }
+    // Survivors go to their genome's staging region.  Candidates arrive in stream order, so a wave's survivors almost
+    // always belong to ONE genome: then one returning atomic reserves room for all of them.
+    uint64_t bal[EXACT_PER];
+    uint32_t total = 0, g0 = 0;
+    bool have = false, same = true;
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) {
+        bal[j] = __ballot(ok[j]);
+        if (bal[j]) {
+            const uint32_t g = __builtin_amdgcn_readlane(gid[j], __builtin_ctzll(bal[j]));
+            if (!have) { g0 = g; have = true; }
+            same = same && (__ballot(ok[j] && gid[j] != g0) == 0);
+            total += (uint32_t)__builtin_popcountll(bal[j]);
+        }
+    }
+    if (!have) return;
+    if (same) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&x.cursor[g0], total);
+        at = __builtin_amdgcn_readfirstlane(at);
+        const unsigned long long r0 = x.reg_off[g0], cap = x.reg_off[g0 + 1] - r0;
+#pragma unroll
+        for (int j = 0; j < EXACT_PER; j++) {
+            if (ok[j]) {
+                const unsigned long long pos = (unsigned long long)at + rank_in(bal[j]);
+                if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = x.by_pos ? KeyOps<K>::make(gpos[j], dr[j]) : KeyOps<K>::make(dr[j], gpos[j]);
+            }
+            at += (uint32_t)__builtin_popcountll(bal[j]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < EXACT_PER; j++) {  // a genome boundary inside the wave's candidates: group by genome
+        uint64_t todo = bal[j];
+        while (todo) {
+            const uint32_t leader = __builtin_ctzll(todo);
+            const uint32_t g = __builtin_amdgcn_readlane(gid[j], leader);
+            const bool mine = ok[j] && gid[j] == g;
+            const uint64_t grp = __ballot(mine);
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(&x.cursor[g], (uint32_t)__builtin_popcountll(grp));
+            at = __builtin_amdgcn_readlane(at, leader);
+            if (mine) {
+                const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
+                const unsigned long long pos = (unsigned long long)at + rank_in(grp);
+                if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = x.by_pos ? KeyOps<K>::make(gpos[j], dr[j]) : KeyOps<K>::make(dr[j], gpos[j]);
+            }
+            todo &= ~grp;
+        }
     }
 }
 
@@ -1256,7 +1317,10 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
     if (init_n < pl.n_slices) init_n = pl.n_slices;
     if (init_n < sizeof(SketchStatus) / 4) init_n = sizeof(SketchStatus) / 4;
     if (pl.n_chunks >= 64ull * pl.n_genomes) {  // long genomes: fill the map genome by genome
-        hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64), dim3(256), 0, s,
+        // enough workgroups per genome that a single huge one (a read set, a chromosome) is not written by one of them
+        uint64_t parts = (pl.n_chunks / pl.n_genomes + 16 * 256 - 1) / (16 * 256);
+        if (parts > 1024) parts = 1024;
+        hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64, (unsigned)(parts ? parts : 1)), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
                            reinterpret_cast<uint32_t *>(c->d_status));
         HIPCK(hipGetLastError());
@@ -1317,7 +1381,7 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
     x.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
     x.status = c->d_status;
-    const dim3 grid((unsigned)((pl.cand_cap + 255) / 256), pl.n_slices);
+    const dim3 grid((unsigned)((pl.cand_cap + 256 * EXACT_PER - 1) / (256 * EXACT_PER)), pl.n_slices);
     if (pl.with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), grid, dim3(256), 0, s, c->P, x);
     else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), grid, dim3(256), 0, s, c->P, x);
     HIPCK(hipGetLastError());

@@ -167,6 +167,36 @@ static void collect_inputs(filelist *f, int nargs, char **args, const char *list
     }
 }
 
+/* default -p: the processors of the machine like the reference (omp_get_num_procs, command_dist_wrapper.c:284-287), but
+ * not more than the CPU time the container is allowed (cgroup cpu.max / cfs quota): 256 threads on a 16-CPU quota
+ * only take turns */
+static int default_threads(void)
+{
+    int n = 1;
+#ifdef _OPENMP
+    n = omp_get_num_procs();
+#endif
+    long long quota = -1, period = 100000;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[64];
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != NULL) {
+        if (fscanf(f, "%lld", &quota) != 1) quota = -1;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) != NULL) {
+            if (fscanf(f, "%lld", &period) != 1) period = 100000;
+            fclose(f);
+        }
+    }
+    if (quota > 0 && period > 0) {
+        long long c = (quota + period - 1) / period;
+        if (c >= 1 && c < n) n = (int)c;
+    }
+    return n < 1 ? 1 : n;
+}
+
 /* ---------------------------------------------------------------------------------------------------
  * dist options (command_dist_wrapper.c:41-100)
  * ------------------------------------------------------------------------------------------------- */
@@ -234,6 +264,10 @@ typedef struct job {
     struct job *next;
 } job;
 
+/* host threads a device worker uses for its own post-processing (file order of the ids): small teams, so that they do not
+ * fight the tokenisers' team for the cores (each pthread has its own OpenMP pool, idle pools spin) */
+#define WORKER_OMP 4
+
 static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, double *t_call)
 {
     const double tc0 = now_s();
@@ -255,6 +289,15 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     const uint64_t *co = kssd_batch_chunk_off(b);
     for (uint32_t g = 0; g < n; g++)
         if (co[g + 1] - co[g] >= (1ull << 20)) with_pos = 0;
+    /* fastq -n >= 2 and -u drop ids at dump time that sit in the reference's table all the same (and shift the probes of
+     * later ids): for a byte-identical file the replay needs ALL distinct ids with their first positions, and which of
+     * them are kept -- a pass without the keep rule, and a pass for the occurrences */
+    const int replay_all = with_pos && !o->abundance && ((is_fq && min_occ > 1) || (!is_fq && o->u));
+    const uint32_t keep_rule_occ = min_occ;
+    if (replay_all) {
+        flags &= ~KSSD_SKETCH_UNIQ;
+        min_occ = 1;
+    }
     int rc = with_pos ? kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
                                                   min_occ, &off, &ids, &pos, &bad)
                       : kssd_gpu_sketch_batch(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
@@ -262,6 +305,37 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
+    if (replay_all) {
+        uint64_t *coff = NULL;
+        uint32_t *cids = NULL, *ccnt = NULL;
+        gck(kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS,
+                                      1u, &coff, &cids, &ccnt, &bad), "sketch (occurrences)");
+        if (coff[n] != off[n]) die(EIO, "sketch (occurrences): %llu ids against %llu", (unsigned long long)coff[n], (unsigned long long)off[n]);
+        uint64_t *koff = calloc((size_t)n + 1, sizeof *koff);
+        if (!koff) die(ENOMEM, "out of memory");
+#pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 16)
+        for (uint32_t g = 0; g < n; g++) {
+            const uint64_t m = off[g + 1] - off[g];
+            uint8_t *keep = malloc(m ? m : 1);
+            for (uint64_t i = 0; i < m; i++) /* both passes list a genome's distinct ids ascending */
+                keep[i] = is_fq ? ccnt[coff[g] + i] >= keep_rule_occ : ccnt[coff[g] + i] == 1;
+            koff[g + 1] = kssd_slot_order_pos_keep(ids + off[g], pos + off[g], keep, m, hashsize); /* kept ids to the front, file order */
+            free(keep);
+        }
+        uint64_t at = 0;
+        for (uint32_t g = 0; g < n; g++) { /* close the gaps the dropped ids leave */
+            const uint64_t m = koff[g + 1];
+            memmove(ids + at, ids + off[g], (size_t)m * 4);
+            koff[g + 1] = at + m;
+            at += m;
+        }
+        memcpy(off, koff, ((size_t)n + 1) * sizeof *off);
+        free(koff);
+        kssd_gpu_free(coff);
+        kssd_gpu_free(cids);
+        kssd_gpu_free(ccnt);
+        with_pos = -1; /* already in file order */
+    }
     *t_call += now_s() - tc0;
     /* -A: a second pass over the same batch returns the occurrences of every id (ids ascending inside a genome,
      * the same set as above) */
@@ -276,16 +350,16 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     }
     /* file order inside a genome = the reference's hash-slot order, insertions replayed in sequence order (or, for
      * a genome of 2^32 positions and more, in ascending id order: exact unless two of its ids probe the same slot) */
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 16)
     for (uint32_t g = 0; g < n; g++) {
-        if (with_pos) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], hashsize);
-        else kssd_slot_order(ids + off[g], off[g + 1] - off[g], hashsize);
+        if (with_pos > 0) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], hashsize);
+        else if (with_pos == 0) kssd_slot_order(ids + off[g], off[g + 1] - off[g], hashsize);
     }
     if (o->abundance) {
         uint16_t *counts = malloc((size_t)(off[n] ? off[n] : 1) * 2);
         if (!counts) die(ENOMEM, "out of memory");
         int bad_follow = 0;
-#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad_follow)
+#pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 16) reduction(| : bad_follow)
         for (uint32_t g = 0; g < n; g++) {
             const uint64_t m = off[g + 1] - off[g];
             if (aoff[g + 1] - aoff[g] != m) { bad_follow |= 1; continue; }
@@ -806,13 +880,7 @@ static int cmd_dist(int argc, char **argv)
         }
     }
     if (o.gpus < 1) die(EINVAL, "--gpus: at least one device");
-    if (o.p == 0) {
-#ifdef _OPENMP
-        o.p = omp_get_num_procs();
-#else
-        o.p = 1;
-#endif
-    }
+    if (o.p == 0) o.p = default_threads();
     o.nargs = argc - optind;
     o.args = argv + optind;
 

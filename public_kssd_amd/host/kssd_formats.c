@@ -80,13 +80,18 @@ static int cmp_pos(const void *a, const void *b)
 
 /* replay the reference's insertions, in the order given, into a sparse image of its table; ids come back in
  * ascending slot order */
-static void slot_order_replay(uint32_t *ids, uint64_t n, uint32_t hashsize)
+static uint64_t slot_order_replay_keep(uint32_t *ids, const uint8_t *keep, uint64_t n, uint32_t hashsize);
+static void slot_order_replay(uint32_t *ids, uint64_t n, uint32_t hashsize) { slot_order_replay_keep(ids, NULL, n, hashsize); }
+
+/* keep != NULL: every id takes its slot, only the ids with keep[i] != 0 come back (their number is returned) */
+static uint64_t slot_order_replay_keep(uint32_t *ids, const uint8_t *keep, uint64_t n, uint32_t hashsize)
 {
     uint64_t cap = 16;
     while (cap < 4 * n) cap <<= 1;
     uint32_t *occ = malloc(cap * sizeof(uint32_t)); /* open-addressing set of occupied slots, 0xFFFFFFFF = free */
-    slot_id *sl = malloc(n * sizeof(slot_id));
-    if (!occ || !sl) { free(occ); free(sl); return; }
+    slot_id *sl = malloc((n ? n : 1) * sizeof(slot_id));
+    if (!occ || !sl) { free(occ); free(sl); return n; }
+    uint64_t m = 0;
     memset(occ, 0xFF, cap * sizeof(uint32_t));
     const uint64_t S = hashsize;
     for (uint64_t i = 0; i < n; i++) {
@@ -102,16 +107,20 @@ static void slot_order_replay(uint32_t *ids, uint64_t n, uint32_t hashsize)
             }
             if (!taken) {
                 occ[p] = slot;
-                sl[i].slot = slot;
-                sl[i].id = ids[i];
+                if (!keep || keep[i]) {
+                    sl[m].slot = slot;
+                    sl[m].id = ids[i];
+                    m++;
+                }
                 break;
             }
         }
     }
-    qsort(sl, n, sizeof(slot_id), cmp_slot);
-    for (uint64_t i = 0; i < n; i++) ids[i] = sl[i].id;
+    qsort(sl, m, sizeof(slot_id), cmp_slot);
+    for (uint64_t i = 0; i < m; i++) ids[i] = sl[i].id;
     free(occ);
     free(sl);
+    return m;
 }
 
 void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
@@ -130,6 +139,29 @@ void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, u
     for (uint64_t i = 0; i < n; i++) ids[i] = pi[i].id;
     free(pi);
     slot_order_replay(ids, n, hashsize); /* insertions in sequence order, as fasta2co makes them */
+}
+
+/* all distinct ids of a genome with their first positions, and which of them the dump keeps: the dropped ones (fastq
+ * -n: fewer than n occurrences, iseq2comem.c:336-345,516-518; -u: seen twice, :694-696,540-541) sit in the reference's
+ * table all the same and shift the probes of later ids.  ids come back as the kept ones in the reference's file order. */
+uint64_t kssd_slot_order_pos_keep(uint32_t *ids, const uint32_t *first_pos, const uint8_t *keep, uint64_t n, uint32_t hashsize)
+{
+    if (n == 0) return 0;
+    pos_id *pi = malloc(n * sizeof(pos_id));
+    uint8_t *kk = malloc(n);
+    if (!pi || !kk) { free(pi); free(kk); return 0; }
+    /* sort (position, index) so that the flags follow the ids */
+    for (uint64_t i = 0; i < n; i++) { pi[i].pos = first_pos[i]; pi[i].id = (uint32_t)i; }
+    qsort(pi, n, sizeof(pos_id), cmp_pos);
+    uint32_t *tmp = malloc(n * sizeof(uint32_t));
+    if (!tmp) { free(pi); free(kk); return 0; }
+    for (uint64_t i = 0; i < n; i++) { tmp[i] = ids[pi[i].id]; kk[i] = keep[pi[i].id]; }
+    memcpy(ids, tmp, n * sizeof(uint32_t));
+    free(tmp);
+    free(pi);
+    const uint64_t m = slot_order_replay_keep(ids, kk, n, hashsize);
+    free(kk);
+    return m;
 }
 
 typedef struct {
@@ -221,6 +253,11 @@ static int read_stat(kssd_sketchset *s, const char *dir, int mco, uint32_t **siz
         s->kmerlen = v[0]; s->dim_rd_len = v[1]; s->comp_num = v[2]; s->n = (uint32_t)v[3];
     }
     if (!ok || s->comp_num < 1 || s->comp_num > 65536) { fclose(f); return KSSD_HOST_ERR_FORMAT; }
+    {   /* n comes from the file: it must agree with the file's size before anything is sized by it */
+        struct stat st;
+        const size_t hdr = mco ? 20 : 32;
+        if (fstat(fileno(f), &st) != 0 || (uint64_t)st.st_size < hdr + (uint64_t)s->n * (4 + KSSD_PATHLEN)) { fclose(f); return KSSD_HOST_ERR_FORMAT; }
+    }
     *sizes = malloc(((size_t)s->n + 1) * 4);
     s->names = malloc(((size_t)s->n + 1) * KSSD_PATHLEN);
     if (!*sizes || !s->names) { fclose(f); return KSSD_HOST_ERR_NOMEM; }
@@ -497,11 +534,13 @@ int kssd_index_read(kssd_sketchset *s, const char *dir)
     int rc = read_stat(s, dir, 1, &sizes);
     if (rc) { free(sizes); kssd_sketchset_release(s); return rc; }
     s->off = malloc(((size_t)s->n + 1) * sizeof(uint64_t));
+    if (!s->off) { free(sizes); kssd_sketchset_release(s); return KSSD_HOST_ERR_NOMEM; }
     s->off[0] = 0;
     for (uint32_t g = 0; g < s->n; g++) s->off[g + 1] = s->off[g] + sizes[g];
     free(sizes);
     s->ids = malloc((size_t)(s->off[s->n] ? s->off[s->n] : 1) * 4);
     uint64_t *fill = calloc((size_t)s->n + 1, sizeof(uint64_t));
+    if (!s->ids || !fill) { free(fill); kssd_sketchset_release(s); return KSSD_HOST_ERR_NOMEM; }
     const int cb = comp_bits_of(s->comp_num);
     const uint64_t comp_sz = 1ull << (4 * COMPONENT_SZ);
     char path[4096];
@@ -554,23 +593,28 @@ static int format_line(char *buf, size_t cap, const char *qn, const char *rn, ui
     if (d > 1) d = 1;
     if (d > o->dthreshold) return 0;
     int len = snprintf(buf, cap, "%s\t%s\t%u-%u|%u|%u\t%.6lf\t%.6lf", qn, rn, s, (uint32_t)rs, X, Y, m, d);
+    if ((size_t)len >= cap) len = (int)cap - 1;
     if (o->pfield > 0) {
         double sd = pow(m * (1 - m) / den, 0.5);
         double pv = 0.5 * erfc(m / sd * pow(0.5, 0.5));
         len += snprintf(buf + len, cap - (size_t)len, "\t%E\t%E", pv, pv * cmprsn);
+        if ((size_t)len >= cap) len = (int)cap - 1; /* truncated (names of 255 bytes each leave room; guard anyway) */
         if (o->pfield > 1) {
             double m1 = m - 1.96 * sd, m2 = m + 1.96 * sd;
             double d1 = log(dist_arg(o->metric, m2)) / kmerlen, d2 = log(dist_arg(o->metric, m1)) / kmerlen;
             len += snprintf(buf + len, cap - (size_t)len, "\t[%.6lf,%.6lf]\t[%.6lf,%.6lf]", m1, m2, d1, d2);
+            if ((size_t)len >= cap) len = (int)cap - 1;
         }
     }
     len += snprintf(buf + len, cap - (size_t)len, "\n");
+    if ((size_t)len >= cap) len = (int)cap - 1;
     return len;
 }
 
 typedef struct {
     char *p;
     size_t n, cap;
+    int failed; /* out of memory while growing */
 } strbuf;
 
 static void sb_add(strbuf *b, const char *s, size_t n)
@@ -578,7 +622,9 @@ static void sb_add(strbuf *b, const char *s, size_t n)
     if (b->n + n > b->cap) {
         size_t nc = b->cap ? b->cap * 2 : 1 << 16;
         while (nc < b->n + n) nc *= 2;
-        b->p = realloc(b->p, nc);
+        char *q = realloc(b->p, nc);
+        if (!q) { b->failed = 1; return; }
+        b->p = q;
         b->cap = nc;
     }
     memcpy(b->p + b->n, s, n);
@@ -620,6 +666,8 @@ static int print_rows(const char *path, const uint32_t *shared, const uint64_t *
     int threads = o->threads > 0 ? o->threads : 1;
     const uint32_t QB = 64; /* queries formatted per parallel batch, written back in order */
     strbuf *sb = calloc(QB, sizeof(strbuf));
+    int nomem = 0;
+    if (!sb) { fclose(f); return KSSD_HOST_ERR_NOMEM; }
     for (uint32_t q0 = 0; q0 < Q; q0 += QB) {
         const uint32_t q1 = q0 + QB < Q ? q0 + QB : Q;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
@@ -665,11 +713,14 @@ static int print_rows(const char *path, const uint32_t *shared, const uint64_t *
 #undef ROW_REF
 #undef ROW_SHARED
         }
-        for (uint32_t q = q0; q < q1; q++)
+        for (uint32_t q = q0; q < q1; q++) {
+            if (sb[q - q0].failed) nomem = 1;
             if (sb[q - q0].n) fwrite(sb[q - q0].p, 1, sb[q - q0].n, f);
+        }
     }
     for (uint32_t i = 0; i < QB; i++) free(sb[i].p);
     free(sb);
+    if (nomem) { fclose(f); return KSSD_HOST_ERR_NOMEM; }
     return fclose(f) == 0 ? KSSD_HOST_OK : KSSD_HOST_ERR_IO;
 }
 

@@ -144,3 +144,46 @@ def test_errors_match_the_reference(tmp_path):
     assert r.returncode != 0 and b"subk shoud smaller than 8" in r.stderr
     r = subprocess.run([BIN, "dist", "-k", "10", "-L", "5", "-o", "o", os.path.join(G, "ref_fa")], cwd=d, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"subk shoud smaller than 8" in r.stderr     # auto -L 5 is rejected
+
+
+def test_config1_tutorial_on_real_test_fna_genomes(tmp_path):
+    """BASELINE configs[0] through the HIP command line on real sequence: two of the reference's own test_fna genomes
+    (B. cereus AE016877 and a mutated copy; tests/golden/test_fna, goldens written by the reference binary:
+    make_golden_testfna.py), the README quick-tutorial flow.  combco.0 of both sketch directories, sharedk_ct.dat and
+    distance.out must be the reference's byte for byte."""
+    d = str(tmp_path)
+    F = os.path.join(G, "test_fna")
+    want = np.load(os.path.join(G, "test_fna.npz"))
+    run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
+    run(["dist", "-L", "L3K10.shuf", "-r", os.path.join(F, "seqs1"), "-o", "refdb"], d)      # sketch + index files
+    run(["dist", "-L", "L3K10.shuf", "-o", "qry", os.path.join(F, "seqs2")], d)
+    run(["dist", "-r", "refdb", "-o", "out", "--keepskf", "qry"], d)
+    assert np.array_equal(np.fromfile(os.path.join(d, "refdb", "combco.0"), np.uint32), want["ref_combco"])
+    assert np.array_equal(np.fromfile(os.path.join(d, "qry", "combco.0"), np.uint32), want["qry_combco"])
+    assert np.array_equal(np.fromfile(os.path.join(d, "out", "sharedk_ct.dat"), np.uint32), want["shared"])
+    got = open(os.path.join(d, "out", "distance.out")).read().replace(os.path.join(F, "seqs1"), "REF").replace(os.path.join(F, "seqs2"), "QRY")
+    assert got == bytes(want["distance_out"]).decode()
+    assert os.path.getsize(os.path.join(d, "refdb", "mco.index.0")) == 8 << 28      # the reference's dense index file
+
+
+def test_file_order_of_uniq_and_min_occ_modes(tmp_path):
+    """`kssd dist -u` and `kssd dist -n 2` write combco.0 in the reference's order even where kept ids collide with ids
+    the dump drops (those keep their slots in the reference's table): small table, hundreds of collisions; the oracle's
+    dump order is pinned against the real binary on the same inputs in tests/test_interop_ref.py"""
+    from test_interop_ref import _collision_inputs
+    d = str(tmp_path)
+    shuf = K.Shuf.generate(8, 5, 2, seed=3)
+    shuf.write(os.path.join(d, "s.shuf"))
+    fa, fq = _collision_inputs()
+    open(os.path.join(d, "rep.fasta"), "wb").write(fa)
+    open(os.path.join(d, "reads.fastq"), "wb").write(fq)
+    sk = ko.Sketcher(shuf.table, 8, 5, 2)
+    hs = K.derive(8, 5, 2).hashsize
+    run(["dist", "-u", "-L", "s.shuf", "-o", "u", "rep.fasta"], d)
+    want = sk.fasta(fa, uniq=True)
+    got = np.fromfile(os.path.join(d, "u", "combco.0"), np.uint32)
+    assert np.array_equal(got, want)
+    assert not np.array_equal(K.slot_order(np.sort(want), hs), want)       # the naive replay of the kept ids alone is NOT this order
+    run(["dist", "-n", 2, "-L", "s.shuf", "-o", "n2", "reads.fastq"], d)
+    want = sk.fastq(fq, Q=0, M=2)
+    assert np.array_equal(np.fromfile(os.path.join(d, "n2", "combco.0"), np.uint32), want)

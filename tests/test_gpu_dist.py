@@ -197,9 +197,9 @@ def _sketchset(names, off, ids, kmerlen=20, dim_rd_len=6):
     return K.SketchSet(123, kmerlen, dim_rd_len, 1, names, off, ids)
 
 
-@pytest.mark.parametrize("opts", [dict(metric=0, n_max=3), dict(metric=1, n_max=1), dict(metric=0, dthreshold=0.05),
-                                  dict(metric=1, dthreshold=0.02, correction=1), dict(metric=0, n_max=5, dthreshold=0.03),
-                                  dict(metric=1, dthreshold=0.2, pfield=0), dict(metric=0, correction=1, n_max=4, pfield=1)])
+@pytest.mark.parametrize("opts", [dict(metric=0, n_max=3), dict(metric=1, n_max=1), dict(metric=0, dthreshold="q30"),
+                                  dict(metric=1, dthreshold="q20", correction=1), dict(metric=0, n_max=5, dthreshold="q50"),
+                                  dict(metric=1, dthreshold="q40", pfield=0), dict(metric=0, correction=1, n_max=4, pfield=1)])
 def test_report_selection_on_the_device_leaves_the_same_text(gpu_ctx, tmp_path, opts):
     """kssd_gpu_dist_select + kssd_distance_print_pairs against the dense report (whose text the golden tests pin to the
     reference's): byte-identical distance.out for -N, -D, --correction, both metrics, and far fewer pairs formatted"""
@@ -215,6 +215,12 @@ def test_report_selection_on_the_device_leaves_the_same_text(gpu_ctx, tmp_path, 
         qids[s:e] = np.sort(np.concatenate([u, fill]))
     ref = _sketchset(["ref/r%03d.fa" % i for i in range(60)], roff, rids)
     qry = _sketchset(["qry/q%03d.fa" % i for i in range(25)], qoff, qids)
+    opts = dict(opts)
+    if isinstance(opts.get("dthreshold"), str):       # a threshold that cuts through the related pairs: a quantile of their distances
+        sh0 = ko.shared_counts(roff, rids, qoff, qids)
+        _, md, _, ad = ko.metrics_batch(np.diff(roff).astype(np.uint32)[None, :], np.diff(qoff).astype(np.uint32)[:, None], sh0, 20)
+        dd = (ad if opts.get("metric") else md)[sh0 > 0]
+        opts["dthreshold"] = float(np.quantile(dd[np.isfinite(dd)], int(opts["dthreshold"][1:]) / 100.0))
     poff, pref, psh, dense = gpu_ctx.dist_select(roff, rids, qoff, qids, metric=opts.get("metric", 0), correction=opts.get("correction", 0),
                                                  dim_rd_len=6, dthreshold=opts.get("dthreshold", 1.0), n_max=opts.get("n_max", 0), dense=True)
     want_shared = ko.shared_counts(roff, rids, qoff, qids)
@@ -223,9 +229,47 @@ def test_report_selection_on_the_device_leaves_the_same_text(gpu_ctx, tmp_path, 
         r = pref[int(poff[q]):int(poff[q + 1])]
         assert np.all(np.diff(r.astype(np.int64)) > 0)
         assert np.array_equal(psh[int(poff[q]):int(poff[q + 1])], want_shared[q, r])
-    assert int(poff[-1]) < 25 * 60 // 2                                      # a real selection
+    if not (opts.get("correction") and not opts.get("n_max")):
+        assert int(poff[-1]) < 25 * 60 // 2                                  # a real selection
+    # (with --correction and no -N the unrelated pairs stay: shared = 0 gives a negative corrected metric, its distance is
+    # NaN, NaN compares false against -D and the reference prints the line, command_dist.c:1262-1267)
     a, b = str(tmp_path / "dense.out"), str(tmp_path / "pairs.out")
     K.distance_print(a, want_shared, ref, qry, threads=2, **opts)
     K.distance_print_pairs(b, poff, pref, psh, ref, qry, threads=2, **opts)
     ta, tb = open(a, "rb").read(), open(b, "rb").read()
     assert ta == tb and ta.count(b"\n") > 1
+
+
+def test_long_query_rows_are_shared_by_several_workgroups(gpu_ctx):
+    """a read set sketched as one genome is ONE query row of hundreds of thousands of ids: beyond 16 384 ids the row is
+    split over workgroups (atomic sums in the output row, the last one computes the metrics) -- same counts, same planes"""
+    rng = np.random.default_rng(101)
+    roff, rids = random_sketches(rng, 300, 900, 1300, 1 << 28, clades=10)
+    long_q = np.unique(np.concatenate([rng.choice(rids, 60_000), rng.choice(1 << 28, 140_000)])).astype(np.uint32)
+    short_q = np.sort(rng.choice(rids, 700, replace=False)).astype(np.uint32)
+    short_q = np.unique(short_q)
+    qoff = np.array([0, len(long_q), len(long_q), len(long_q) + len(short_q)], dtype=np.uint64)   # long, empty, short
+    qids = np.concatenate([long_q, short_q])
+    shared, J, MD, Cc, AD = gpu_ctx.dist(roff, rids, qoff, qids)
+    want = ko.shared_counts(roff, rids, qoff, qids, threads=4)
+    assert np.array_equal(shared, want) and want[0].min() > 20
+    X = np.diff(roff).astype(np.uint32)[None, :]
+    Y = np.diff(qoff).astype(np.uint32)[:, None]
+    oJ, oMD, oC, oAD = ko.metrics_batch(X, Y, want, 20)
+    ok = Y[:, 0] > 0                                                        # (the empty row: 0/0 everywhere, NaN on both sides)
+    assert ulp_diff(J[ok], oJ[ok]).max() == 0 and ulp_diff(Cc[ok], oC[ok]).max() == 0
+    assert ulp_diff(MD[ok], oMD[ok]).max() <= 1 and ulp_diff(AD[ok], oAD[ok]).max() <= 1
+    # device-level entry with the hint, counts only, against the one-workgroup-per-row kernel
+    import torch
+    dev = torch.device("cuda", 0)
+    d_roff = torch.from_numpy(roff.astype(np.int64)).to(dev)
+    d_rids = torch.from_numpy(rids.view(np.int32)).to(dev)
+    d_qoff = torch.from_numpy(qoff.astype(np.int64)).to(dev)
+    d_qids = torch.from_numpy(qids.view(np.int32)).to(dev)
+    gpu_ctx.index_build_device(d_roff, d_rids, 300, len(rids))
+    a = torch.zeros(3 * 300, dtype=torch.int32, device=dev)
+    b = torch.full((3 * 300,), -1, dtype=torch.int32, device=dev)
+    gpu_ctx.dist_device(d_qoff, d_qids, 3, 0, 3, a)
+    gpu_ctx.dist_device(d_qoff, d_qids, 3, 0, 3, b, max_row_ids=len(long_q))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and np.array_equal(a.cpu().numpy().view(np.uint32).reshape(3, 300), want)

@@ -192,3 +192,37 @@ def test_abundance_sketch_oracle_vs_reference_on_deep_reads(tmp_path, shuf_l3k10
     assert np.array_equal(ids, wi) and np.array_equal(cnt, wc) and cnt.max() >= 20
     s = K.SketchSet.read(str(tmp_path / "koc"))
     assert np.array_equal(s.ids, ids) and np.array_equal(s.counts, cnt)
+
+
+def _collision_inputs():
+    """inputs for the file-order tests of -u and fastq -n 2 on a small table (k = 8, level 2: 131 071 slots): a genome
+    with a repeated stretch (ids seen twice: dropped by -u, but they keep their slots) and a deep read set"""
+    from synth import fasta_text, fastq_records, sample_reads
+    rng = np.random.default_rng(17)
+    unit = rng.integers(0, 4, 900_000, dtype=np.uint8)
+    g = np.concatenate([unit, rng.integers(0, 4, 400_000, dtype=np.uint8), unit[:500_000]])
+    fa = fasta_text(g, b"repeats")
+    reads = sample_reads([rng.integers(0, 4, 600_000, dtype=np.uint8)], 12_000, 150, seed=5)   # ~3x: many k-mers once, many twice
+    return fa, fastq_records(reads)
+
+
+@pytest.mark.skipif(not ko.have_ref(), reason="oracle/_ref/kssd not built (dev container only)")
+def test_oracle_file_order_of_uniq_and_min_occ_modes_equals_the_reference(tmp_path):
+    """-u and fastq -n 2: ids dropped at dump time still occupy slots of the reference's table, so the order of the kept
+    ids depends on them.  The oracle's dump order against the real binary, on a table small enough for hundreds of
+    collisions (pins what tests/test_gpu_cli.py checks the HIP command line against)."""
+    d = str(tmp_path)
+    shuf = K.Shuf.generate(8, 5, 2, seed=3)
+    shuf.write(os.path.join(d, "s.shuf"))
+    fa, fq = _collision_inputs()
+    open(os.path.join(d, "rep.fasta"), "wb").write(fa)
+    open(os.path.join(d, "reads.fastq"), "wb").write(fq)
+    sk = ko.Sketcher(shuf.table, 8, 5, 2)
+    ko.run_ref(["dist", "-p", 1, "-u", "-L", "s.shuf", "-o", "u", "rep.fasta"], cwd=d)
+    ref_u = np.fromfile(os.path.join(d, "u", "combco.0"), np.uint32)
+    assert np.array_equal(sk.fasta(fa, uniq=True), ref_u)
+    assert len(ref_u) < len(sk.fasta(fa)) - 1000                       # the repeat really drops ids
+    ko.run_ref(["dist", "-p", 1, "-n", 2, "-L", "s.shuf", "-o", "n2", "reads.fastq"], cwd=d)
+    ref_n2 = np.fromfile(os.path.join(d, "n2", "combco.0"), np.uint32)
+    assert np.array_equal(sk.fastq(fq, Q=0, M=2), ref_n2)
+    assert 500 < len(ref_n2) < len(sk.fastq(fq, Q=0, M=1)) - 500
