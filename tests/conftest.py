@@ -28,6 +28,14 @@ def _native_built():
     if not _have("oracle/libkssd_oracle.so"):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"),
                                os.path.join(ROOT, "oracle", "libkssd_oracle.so")])
+    # torch brings its own HIP runtime; where tests use both it and libkssd_gpu.so (the system's runtime) in one
+    # process, torch has to see the device first -- initialised after the other runtime it reports "No HIP GPUs"
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     yield
 
 
