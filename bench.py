@@ -186,9 +186,9 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
             for i in range(n):
                 assert np.array_equal(ours["r00_g%04d.fasta" % i], gpu_sets[i]), "kssd CLI sketch != device-level sketch"
             e2e = {"value": nf / dt, "unit": "genomes/s", "mbase_per_s": nb * reps / 1e6 / dt, "seconds": dt, "host_threads": cores,
-                   "what": "`kssd dist -L L3K10.shuf -o <dir> <fasta dir>`: process start, .shuf load, read + tokenise on all host "
-                           "threads into page-locked batches, H2D, kernels, D2H, slot order, combco.* written -- wall time of the "
-                           "command", "sample": fa_desc, "stages": tm}
+                   "what": "`kssd dist -L L3K10.shuf -o <dir> <fasta dir>`: process start, .shuf load, files read into page-locked "
+                           "buffers on the host threads, raw text H2D, tokenised on the device, sketch kernels, D2H, slot order, "
+                           "combco.* written -- wall time of the command", "sample": fa_desc, "stages": tm}
             dt2, _ = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist", "--keepskf", "our_sk"], d)
             e2e["search"] = {"value": nf * nf / dt2, "unit": "pairs/s", "seconds": dt2,
                              "what": "`kssd dist -r <sketches> -o <dir> <sketches>`: %d x %d all-pairs incl. reading the sketches, the device "

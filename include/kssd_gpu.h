@@ -30,6 +30,8 @@ extern "C" {
 #define KSSD_ERR_UNSUPPORTED (-5) /* valid for the reference, not implemented on the device yet        */
 #define KSSD_ERR_NOMEM (-6)
 #define KSSD_ERR_NO_DEVICE (-7)   /* no usable gfx950 device: there is NO CPU fallback                 */
+#define KSSD_ERR_INPUT (-8)       /* a FASTA header is not closed before the end of the file            */
+                                  /*   ("fasta header not closed", iseq2comem.c:233)                    */
 
 /* ---- geometry of a packed batch -------------------------------------------------------------- */
 #define KSSD_CHUNK_BASES 4096u   /* positions per chunk; every genome starts on a chunk boundary      */
@@ -168,6 +170,30 @@ int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *ctx, const uint32_t *packed, const u
                               uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos,
                               int64_t *bad_genome);
 void kssd_gpu_free(void *p);
+
+/*
+ * The FASTA tokeniser on the device: the byte rules of fasta2co (iseq2comem.c:213-242: bases, transparent line ends,
+ * headers skipped to their line end, every other byte breaks the run) applied to raw file bytes in HBM.
+ *   d_text      DEVICE bytes; file f occupies [h_text_off[f], h_text_off[f] + h_text_len[f]), offsets multiples of 16
+ *   h_chunk_off HOST u64[n_files + 1]: genome f gets chunks [h_chunk_off[f], h_chunk_off[f+1]), at least
+ *               ceil(h_text_len[f] / 4096) of them (an input of B bytes never emits more than B positions)
+ *   d_packed / d_mask   DEVICE, the batch layout above (+ KSSD_PACK_SLACK_WORDS); zeroed and written here
+ * Nothing is synchronised.  kssd_gpu_tokenise_status synchronises `stream` and returns KSSD_ERR_INPUT with the index of
+ * the first file whose last header is not closed (the host tokeniser's KSSD_HOST_ERR_HEADER), else KSSD_OK;
+ * h_positions (HOST u64[n_files], may be NULL) receives every file's positions (bases + run breaks).
+ * The batch is bit for bit what libkssd_host.so's kssd_batch_fill_text writes for the same bytes.
+ */
+int kssd_gpu_tokenise_fasta_device(kssd_gpu_ctx *ctx, const uint8_t *d_text, const uint64_t *h_text_off, const uint64_t *h_text_len,
+                                   uint32_t n_files, uint32_t *d_packed, uint32_t *d_mask, const uint64_t *h_chunk_off, void *stream);
+int kssd_gpu_tokenise_status(kssd_gpu_ctx *ctx, int64_t *bad_file, uint64_t *h_positions, void *stream);
+/*
+ * host-level: FASTA texts in HOST memory (page-locked for full PCIe speed) -> sketches, tokenised on the device.  One
+ * genome per file, layout as above; out_pos may be NULL (then no first positions / counts / stream positions are
+ * returned), otherwise as kssd_gpu_sketch_batch_pos.  KSSD_ERR_INPUT: *bad_genome = the file with the unclosed header.
+ */
+int kssd_gpu_sketch_fasta_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
+                               uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                               uint32_t **out_pos, int64_t *bad_genome);
 
 /*
  * Page-locked host memory (hipHostMalloc): a batch tokenised into it (kssd_batch_create_ex of the host library takes

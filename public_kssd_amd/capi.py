@@ -30,7 +30,7 @@ SKETCH_COUNTS = 16
 SKETCH_BY_POS = 32
 PHASE_PREP, PHASE_SCAN, PHASE_EXACT, PHASE_FINISH = 0, 1, 2, 3
 
-OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE, ERR_INPUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 GPU_SYMBOLS = [
     "kssd_gpu_strerror", "kssd_gpu_last_hip_error", "kssd_gpu_create", "kssd_gpu_create_compact",
@@ -41,6 +41,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
     "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
+    "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
 ]
 
 
@@ -122,6 +123,10 @@ def gpu_lib():
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
+        L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
+        L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
+        L.kssd_gpu_sketch_fasta_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                                 C.POINTER(C.c_int64)]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
         L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
         L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
@@ -580,6 +585,56 @@ class GpuCtx:
             gpu_lib().kssd_gpu_free(po)
             gpu_lib().kssd_gpu_free(pi)
         return off, ids
+
+    @staticmethod
+    def _text_layout(texts):
+        """the files one after the other, each on a 16-byte boundary: (buffer uint8, off uint64, len uint64)"""
+        lens = np.array([len(t) for t in texts], dtype=np.uint64)
+        offs = np.zeros(len(texts), dtype=np.uint64)
+        at = 0
+        for i, t in enumerate(texts):
+            offs[i] = at
+            at += (len(t) + 15) // 16 * 16
+        buf = np.zeros(max(at, 16), dtype=np.uint8)
+        for i, t in enumerate(texts):
+            buf[int(offs[i]):int(offs[i]) + len(t)] = np.frombuffer(bytes(t), dtype=np.uint8)
+        return buf, offs, lens
+
+    def sketch_fasta_texts(self, texts, flags=SKETCH_FASTA, min_occ=1, with_pos=False):
+        """FASTA texts tokenised ON THE DEVICE and sketched: (off, ids[, pos]); one genome per text"""
+        buf, offs, lens = self._text_layout(texts)
+        n = len(texts)
+        po, pi, pp, bad = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+        rc = gpu_lib().kssd_gpu_sketch_fasta_text(self.h, buf.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, flags, min_occ,
+                                                  C.byref(po), C.byref(pi), C.byref(pp) if with_pos else None, C.byref(bad))
+        if rc != 0:
+            e = KssdError(rc, gpu_lib().kssd_gpu_strerror(rc).decode())
+            e.bad_genome = bad.value
+            raise e
+        try:
+            off = np.frombuffer((C.c_char * (8 * (n + 1))).from_address(po.value), dtype=np.uint64).copy()
+            tot = int(off[-1])
+            ids = (np.frombuffer((C.c_char * (4 * tot)).from_address(pi.value), dtype=np.uint32).copy() if tot else np.zeros(0, np.uint32))
+            pos = None
+            if with_pos:
+                pos = (np.frombuffer((C.c_char * (4 * tot)).from_address(pp.value), dtype=np.uint32).copy() if tot else np.zeros(0, np.uint32))
+        finally:
+            for q in (po, pi, pp):
+                if q.value:
+                    gpu_lib().kssd_gpu_free(q)
+        return (off, ids, pos) if with_pos else (off, ids)
+
+    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None):
+        """device-level: raw FASTA bytes in HBM -> packed batch in HBM; returns (rc, bad_file, positions per file)"""
+        to = np.ascontiguousarray(text_off, dtype=np.uint64)
+        tl = np.ascontiguousarray(text_len, dtype=np.uint64)
+        co = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        _gck(gpu_lib().kssd_gpu_tokenise_fasta_device(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed),
+                                                      _ptr(d_mask), co.ctypes.data, stream))
+        bad = C.c_int64(-1)
+        npos = np.zeros(max(len(tl), 1), dtype=np.uint64)
+        rc = gpu_lib().kssd_gpu_tokenise_status(self.h, C.byref(bad), npos.ctypes.data, stream)
+        return rc, bad.value, npos[:len(tl)]
 
     def dist(self, roff, rids, qoff, qids, planes=True):
         """shared uint32[Q,R] (+ J, MashD, C, AafD float64[Q,R] when planes)"""

@@ -47,6 +47,7 @@ extern "C" const char *kssd_gpu_strerror(int code)
     case KSSD_ERR_UNSUPPORTED: return "parameters accepted by the reference but not by the device path";
     case KSSD_ERR_NOMEM: return "out of memory";
     case KSSD_ERR_NO_DEVICE: return "no gfx950 device available (there is no CPU fallback)";
+    case KSSD_ERR_INPUT: return "malformed input: a FASTA header is not closed before the end of the file";
     default: return "unknown kssd_gpu error";
     }
 }
@@ -138,6 +139,13 @@ struct kssd_gpu_ctx {
     uint32_t h_log2;        // log2 of the number of buckets
     uint32_t *d_bkt;        // per bucket: counters | starts | cursors | descriptors (kssd_dist.inc)
     size_t cap_bkt;
+    // device tokeniser (kssd_tok.inc)
+    unsigned long long *d_tok_tab, *d_tok_pos;
+    uint32_t *d_tok_sum;
+    uint8_t *d_tok_state, *d_text;
+    size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text;
+    uint32_t tok_files;
+    std::vector<unsigned long long> h_tok_tab;
     uint32_t *d_arrive;     // long query rows: arrival counters of the workgroups that share a row
     size_t cap_arrive;
     uint32_t *d_sel_cnt, *d_sel_out;  // report selection (kssd_gpu_dist_select): per-row counts / starts, candidate pairs
@@ -255,7 +263,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -1499,31 +1507,14 @@ extern "C" int kssd_gpu_scan_stats(kssd_gpu_ctx *c, uint64_t *stage1, uint64_t *
     return KSSD_OK;
 }
 
-// Host-level sketch call.  The device-side input and output buffers belong to the context and only ever grow, the
-// work runs on the context's own stream, and a caller that keeps its batch in page-locked memory (kssd_gpu_host_alloc)
-// gets plain DMA transfers: a sequence of calls then costs transfers and kernels, not allocations.
-static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask, const uint64_t *chunk_off,
-                             uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
-                             uint32_t **out_pos, int64_t *bad_genome)
+// the batch is in the context's input buffers (d_in_packed / d_in_mask): sketch it and bring the CSR to the host
+static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
+                                uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome)
 {
-    if (!c || !chunk_off || !out_off || !out_ids) return KSSD_ERR_PARAM;
-    HIPCK(hipSetDevice(c->device));
-    *out_off = nullptr;
-    *out_ids = nullptr;
-    if (out_pos) *out_pos = nullptr;
     hipStream_t s = c->own_stream;
     const uint64_t n_chunks = chunk_off[n_genomes];
-    const size_t pw = (size_t)n_chunks * KSSD_CHUNK_WORDS, mw = (size_t)n_chunks * KSSD_CHUNK_MASKW;
     int rc;
-    if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, pw + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
-    if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, mw + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_b_off, &c->cap_b_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
-    if (n_chunks) {
-        HIPCK(hipMemcpyAsync(c->d_in_packed, packed, pw * 4, hipMemcpyHostToDevice, s));
-        HIPCK(hipMemcpyAsync(c->d_in_mask, mask, mw * 4, hipMemcpyHostToDevice, s));
-    }
-    HIPCK(hipMemsetAsync(c->d_in_packed + pw, 0, KSSD_PACK_SLACK_WORDS * 4, s));  // the slack behind the last chunk: no bases
-    HIPCK(hipMemsetAsync(c->d_in_mask + mw, 0, KSSD_PACK_SLACK_WORDS * 4, s));
     if (out_pos && !(flags & (KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS))) flags |= KSSD_SKETCH_FIRST_POS;
     if (!out_pos) flags &= ~(KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS);
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
@@ -1557,6 +1548,34 @@ static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint
     *out_ids = h_ids;
     if (out_pos) *out_pos = h_pos;
     return KSSD_OK;
+}
+
+
+// Host-level sketch call.  The device-side input and output buffers belong to the context and only ever grow, the
+// work runs on the context's own stream, and a caller that keeps its batch in page-locked memory (kssd_gpu_host_alloc)
+// gets plain DMA transfers: a sequence of calls then costs transfers and kernels, not allocations.
+static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint32_t *mask, const uint64_t *chunk_off,
+                             uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                             uint32_t **out_pos, int64_t *bad_genome)
+{
+    if (!c || !chunk_off || !out_off || !out_ids) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    *out_off = nullptr;
+    *out_ids = nullptr;
+    if (out_pos) *out_pos = nullptr;
+    hipStream_t s = c->own_stream;
+    const uint64_t n_chunks = chunk_off[n_genomes];
+    const size_t pw = (size_t)n_chunks * KSSD_CHUNK_WORDS, mw = (size_t)n_chunks * KSSD_CHUNK_MASKW;
+    int rc;
+    if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, pw + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, mw + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
+    if (n_chunks) {
+        HIPCK(hipMemcpyAsync(c->d_in_packed, packed, pw * 4, hipMemcpyHostToDevice, s));
+        HIPCK(hipMemcpyAsync(c->d_in_mask, mask, mw * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCK(hipMemsetAsync(c->d_in_packed + pw, 0, KSSD_PACK_SLACK_WORDS * 4, s));  // the slack behind the last chunk: no bases
+    HIPCK(hipMemsetAsync(c->d_in_mask + mw, 0, KSSD_PACK_SLACK_WORDS * 4, s));
+    return sketch_resident_impl(c, chunk_off, n_genomes, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
 }
 
 // page-locked host memory for batches that travel by DMA (hipHostMalloc); NULL when it cannot be had
@@ -1603,6 +1622,48 @@ extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float
     if (launches) *launches = n;
     if (reset) c->ev_n[which] = 0;
     return KSSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the FASTA tokeniser on the device lives in kssd_tok.inc
+// ---------------------------------------------------------------------------------------------------
+#include "kssd_tok.inc"
+
+// host-level: FASTA texts (HOST bytes, ideally page-locked) in, sketches out -- text to the device, tokenised there
+static int sketch_text_impl(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len, uint32_t n_files,
+                            uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome)
+{
+    if (!c || !out_off || !out_ids || (n_files && (!text || !text_off || !text_len))) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    *out_off = nullptr;
+    *out_ids = nullptr;
+    if (out_pos) *out_pos = nullptr;
+    if (bad_genome) *bad_genome = -1;
+    hipStream_t s = c->own_stream;
+    std::vector<uint64_t> chunk_off((size_t)n_files + 1, 0);
+    uint64_t text_end = 0;
+    for (uint32_t f = 0; f < n_files; f++) {
+        chunk_off[f + 1] = chunk_off[f] + (text_len[f] + KSSD_CHUNK - 1) / KSSD_CHUNK;
+        if (text_off[f] + text_len[f] > text_end) text_end = text_off[f] + text_len[f];
+    }
+    const uint64_t n_chunks = chunk_off[n_files];
+    int rc;
+    if ((rc = ensure(&c->d_text, &c->cap_text, (size_t)text_end + 64)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, (size_t)n_chunks * KSSD_CHUNK_WORDS + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, (size_t)n_chunks * KSSD_CHUNK_MASKW + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
+    if (text_end) HIPCK(hipMemcpyAsync(c->d_text, text, (size_t)text_end, hipMemcpyHostToDevice, s));
+    rc = kssd_gpu_tokenise_fasta_device(c, c->d_text, text_off, text_len, n_files, c->d_in_packed, c->d_in_mask, chunk_off.data(), s);
+    if (rc != KSSD_OK) return rc;
+    rc = kssd_gpu_tokenise_status(c, bad_genome, nullptr, s);
+    if (rc != KSSD_OK) return rc;
+    return sketch_resident_impl(c, chunk_off.data(), n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
+}
+
+extern "C" int kssd_gpu_sketch_fasta_text(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
+                                          uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                                          uint32_t **out_pos, int64_t *bad_genome)
+{
+    return sketch_text_impl(c, text, text_off, text_len, n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
 }
 
 // ---------------------------------------------------------------------------------------------------

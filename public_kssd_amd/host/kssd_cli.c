@@ -255,8 +255,15 @@ static void load_shuf(const dist_opt *o, kssd_shuf *s)
 
 /* One unit of stage-I work: a run of consecutive input files of one kind (FASTA or FASTQ), tokenised into one packed
  * batch in page-locked memory; a device worker sketches it and leaves the genomes' ids in the reference's file order. */
+typedef struct textbuf { /* FASTA bytes of a job in page-locked memory, every file on a 16-byte boundary */
+    unsigned char *p;
+    size_t cap;
+} textbuf;
+
 typedef struct job {
-    kssd_batch *b;
+    kssd_batch *b;      /* FASTQ / -A: tokenised on the host */
+    textbuf *tx;        /* FASTA: the raw bytes, tokenised on the device (kssd_gpu_sketch_fasta_text) */
+    uint64_t *toff, *tlen;
     int is_fq, first_file, n_files;
     uint64_t *off;    /* n_files + 1 */
     uint32_t *ids;    /* slot order per genome */
@@ -268,13 +275,24 @@ typedef struct job {
  * fight the tokenisers' team for the cores (each pthread has its own OpenMP pool, idle pools spin) */
 #define WORKER_OMP 4
 
+/* the job's genomes through the device: FASTA text is tokenised there, FASTQ batches arrive tokenised; pos may be NULL */
+static int job_sketch(kssd_gpu_ctx *ctx, const job *j, uint32_t flags, uint32_t min_occ, uint64_t **off, uint32_t **ids, uint32_t **pos,
+                      int64_t *bad)
+{
+    if (j->tx) return kssd_gpu_sketch_fasta_text(ctx, j->tx->p, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, bad);
+    kssd_batch *b = j->b;
+    if (pos) return kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), kssd_batch_n_genomes(b),
+                                              flags, min_occ, off, ids, pos, bad);
+    return kssd_gpu_sketch_batch(ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), kssd_batch_n_genomes(b), flags,
+                                 min_occ, off, ids, bad);
+}
+
 static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, double *t_call)
 {
     const double tc0 = now_s();
-    kssd_batch *b = j->b;
     const int is_fq = j->is_fq;
     const uint32_t first_file = (uint32_t)j->first_file;
-    uint32_t n = kssd_batch_n_genomes(b);
+    uint32_t n = (uint32_t)j->n_files;
     uint32_t flags = is_fq ? (KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY) : (o->u ? KSSD_SKETCH_UNIQ : KSSD_SKETCH_FASTA);
     uint32_t min_occ = is_fq ? (uint32_t)o->kmerocrs : 1u;
     if (o->abundance) { /* mt_shortreads2koc (iseq2comem.c:554-615): every k-mer kept, -n not looked at, crowding is fatal */
@@ -286,9 +304,11 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     int64_t bad = -1;
     /* first positions (for the reference's exact file order) need genomes below 2^32 positions */
     int with_pos = 1;
-    const uint64_t *co = kssd_batch_chunk_off(b);
-    for (uint32_t g = 0; g < n; g++)
-        if (co[g + 1] - co[g] >= (1ull << 20)) with_pos = 0;
+    for (uint32_t g = 0; g < n; g++) {
+        const uint64_t chunks = j->tx ? (j->tlen[g] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES
+                                      : kssd_batch_chunk_off(j->b)[g + 1] - kssd_batch_chunk_off(j->b)[g];
+        if (chunks >= (1ull << 20)) with_pos = 0;
+    }
     /* fastq -n >= 2 and -u drop ids at dump time that sit in the reference's table all the same (and shift the probes of
      * later ids): for a byte-identical file the replay needs ALL distinct ids with their first positions, and which of
      * them are kept -- a pass without the keep rule, and a pass for the occurrences */
@@ -298,18 +318,16 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
         flags &= ~KSSD_SKETCH_UNIQ;
         min_occ = 1;
     }
-    int rc = with_pos ? kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
-                                                  min_occ, &off, &ids, &pos, &bad)
-                      : kssd_gpu_sketch_batch(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags,
-                                              min_occ, &off, &ids, &bad);
+    int rc = job_sketch(ctx, j, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
+    if (rc == KSSD_ERR_INPUT) /* the host tokeniser's KSSD_HOST_ERR_HEADER (iseq2comem.c:233) */
+        die(EIO, "%s: %s", fl->path[first_file + (bad >= 0 ? bad : 0)], kssd_host_strerror(KSSD_HOST_ERR_HEADER));
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
     if (replay_all) {
         uint64_t *coff = NULL;
         uint32_t *cids = NULL, *ccnt = NULL;
-        gck(kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n, flags | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS,
-                                      1u, &coff, &cids, &ccnt, &bad), "sketch (occurrences)");
+        gck(job_sketch(ctx, j, flags | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &coff, &cids, &ccnt, &bad), "sketch (occurrences)");
         if (coff[n] != off[n]) die(EIO, "sketch (occurrences): %llu ids against %llu", (unsigned long long)coff[n], (unsigned long long)off[n]);
         uint64_t *koff = calloc((size_t)n + 1, sizeof *koff);
         if (!koff) die(ENOMEM, "out of memory");
@@ -342,9 +360,7 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     uint64_t *aoff = NULL;
     uint32_t *aids = NULL, *acnt = NULL;
     if (o->abundance) {
-        gck(kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), co, n,
-                                      KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &aoff, &aids,
-                                      &acnt, &bad),
+        gck(job_sketch(ctx, j, KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &aoff, &aids, &acnt, &bad),
             "sketch (abundances)");
         if (aoff[n] != off[n]) die(EIO, "sketch (abundances): %llu ids against %llu", (unsigned long long)aoff[n], (unsigned long long)off[n]);
     }
@@ -388,7 +404,8 @@ typedef struct {
     job *todo_head, *todo_tail; /* tokenised, waiting for a device */
     job *done;                  /* sketched */
     kssd_batch **pool;          /* free batches */
-    int n_pool, closed;
+    textbuf **tpool;            /* free text buffers */
+    int n_pool, n_tpool, closed;
     const dist_opt *o;
     filelist *fl;
     uint32_t hashsize;
@@ -424,10 +441,15 @@ static void *worker_main(void *arg)
         double tcall = 0;
         process_job(ctx, j, pl->o, pl->fl, pl->hashsize, &tcall);
         const double dt = now_s() - t0;
-        kssd_batch_clear(j->b);
+        if (j->b) kssd_batch_clear(j->b);
         pthread_mutex_lock(&pl->mu);
-        pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
+        if (j->b) pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
+        if (j->tx) pl->tpool[pl->n_tpool++] = j->tx;
         j->b = NULL;
+        j->tx = NULL;
+        free(j->toff);
+        free(j->tlen);
+        j->toff = j->tlen = NULL;
         j->next = pl->done;
         pl->done = j;
         pl->t_gpu += dt;
@@ -546,6 +568,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         if (!pl.pool[i]) die(ENOMEM, "out of memory");
     }
     pl.n_pool = n_batches;
+    pl.tpool = calloc((size_t)n_batches, sizeof *pl.tpool);
+    for (int i = 0; i < n_batches; i++) pl.tpool[i] = calloc(1, sizeof(textbuf));
+    pl.n_tpool = n_batches;
     worker *ws = calloc((size_t)n_workers, sizeof *ws);
     for (int i = 0; i < n_workers; i++) {
         ws[i].pl = &pl;
@@ -564,16 +589,30 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     size_t *len = calloc((size_t)threads, sizeof *len);
     int *trc = calloc((size_t)threads, sizeof *trc);
     uint64_t *lines = calloc((size_t)threads, sizeof *lines);
+    int *direct = calloc((size_t)threads, sizeof *direct); /* plain FASTA file: read straight into the job's text buffer */
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
         const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
         double t0 = now_s();
+        /* read + gunzip, one file each.  FASTQ files and gzip'ed files go into the wave's scratch buffers; a plain FASTA
+         * file is only measured here and read straight into page-locked memory below */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-        for (int i = 0; i < nw; i++) trc[i] = kssd_slurp_reuse(fl->path[i0 + i], &txt[i], &txt_cap[i], &len[i]); /* read + gunzip, one file each */
-        t_read += now_s() - t0;
         for (int i = 0; i < nw; i++) {
-            if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
-            n_bytes += len[i];
+            const char *path = fl->path[i0 + i];
+            int gz = 0;
+            uint64_t sz = 0;
+            direct[i] = 0;
+            trc[i] = kssd_file_probe(path, &gz, &sz);
+            if (trc[i]) continue;
+            if (!gz && !has_fmt(path, fq_fmt)) {
+                direct[i] = 1;
+                len[i] = (size_t)sz;
+            } else {
+                trc[i] = kssd_slurp_reuse(path, &txt[i], &txt_cap[i], &len[i]);
+            }
         }
+        t_read += now_s() - t0;
+        for (int i = 0; i < nw; i++)
+            if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
         /* runs of one kind that fit a device batch */
         for (int r0 = 0; r0 < nw;) {
             const int fq = has_fmt(fl->path[i0 + r0], fq_fmt);
@@ -585,33 +624,75 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                 chunks += c;
                 r1++;
             }
-            pthread_mutex_lock(&pl.mu);
-            while (pl.n_pool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
-            kssd_batch *b = pl.pool[--pl.n_pool];
-            pthread_mutex_unlock(&pl.mu);
-            uint64_t *maxpos = malloc((size_t)(r1 - r0) * sizeof *maxpos);
-            for (int i = r0; i < r1; i++) maxpos[i - r0] = len[i];
-            uint32_t first = 0;
-            if (kssd_batch_reserve(b, (uint32_t)(r1 - r0), maxpos, &first)) die(ENOMEM, "out of memory");
-            free(maxpos);
-            t0 = now_s();
-            /* -A reads the bases only: no quality filter (iseq2comem.c:566-573) */
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-            for (int i = r0; i < r1; i++) {
-                trc[i] = kssd_batch_fill_text(b, first + (uint32_t)(i - r0), fq && o->abundance ? 2 : fq, txt[i], len[i], o->kmerqlty, &lines[i]);
-                if (trc[i] == KSSD_HOST_ERR_EMPTY) trc[i] = 0; /* an empty file is an empty genome here */
-            }
-            t_tok += now_s() - t0;
-            for (int i = r0; i < r1; i++) {
-                if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
-                if (fq && !o->abundance) printf("%llu reads detected\n", (unsigned long long)lines[i]);
-                printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + i]);
-            }
             job *j = calloc(1, sizeof *j);
-            j->b = b;
             j->is_fq = fq;
             j->first_file = i0 + r0;
             j->n_files = r1 - r0;
+            if (!fq) {
+                /* FASTA: the raw bytes go to the device, which tokenises them (csrc/kssd_tok.inc) */
+                j->toff = calloc((size_t)(r1 - r0) + 1, sizeof(uint64_t));
+                j->tlen = calloc((size_t)(r1 - r0) + 1, sizeof(uint64_t));
+                uint64_t at = 0;
+                for (int i = r0; i < r1; i++) {
+                    j->toff[i - r0] = at;
+                    j->tlen[i - r0] = len[i];
+                    at += (len[i] + 15) / 16 * 16;
+                }
+                pthread_mutex_lock(&pl.mu);
+                while (pl.n_tpool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
+                textbuf *tx = pl.tpool[--pl.n_tpool];
+                pthread_mutex_unlock(&pl.mu);
+                if (tx->cap < at + 64) {
+                    if (tx->p) kssd_gpu_host_free(tx->p);
+                    tx->cap = at + at / 4 + 64;
+                    tx->p = kssd_gpu_host_alloc(tx->cap);
+                    if (!tx->p) die(ENOMEM, "out of page-locked memory (%zu bytes)", tx->cap);
+                }
+                t0 = now_s();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+                for (int i = r0; i < r1; i++) {
+                    unsigned char *dst = tx->p + j->toff[i - r0];
+                    if (direct[i]) {
+                        size_t got = 0;
+                        trc[i] = kssd_read_into(fl->path[i0 + i], dst, len[i], &got);
+                        j->tlen[i - r0] = got; /* (a file that shrank meanwhile) */
+                    } else {
+                        memcpy(dst, txt[i], len[i]);
+                    }
+                }
+                t_read += now_s() - t0;
+                for (int i = r0; i < r1; i++) {
+                    if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
+                    n_bytes += j->tlen[i - r0];
+                    printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + i]);
+                }
+                j->tx = tx;
+            } else {
+                pthread_mutex_lock(&pl.mu);
+                while (pl.n_pool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
+                kssd_batch *b = pl.pool[--pl.n_pool];
+                pthread_mutex_unlock(&pl.mu);
+                uint64_t *maxpos = malloc((size_t)(r1 - r0) * sizeof *maxpos);
+                for (int i = r0; i < r1; i++) maxpos[i - r0] = len[i];
+                uint32_t first = 0;
+                if (kssd_batch_reserve(b, (uint32_t)(r1 - r0), maxpos, &first)) die(ENOMEM, "out of memory");
+                free(maxpos);
+                t0 = now_s();
+                /* -A reads the bases only: no quality filter (iseq2comem.c:566-573) */
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+                for (int i = r0; i < r1; i++) {
+                    trc[i] = kssd_batch_fill_text(b, first + (uint32_t)(i - r0), o->abundance ? 2 : 1, txt[i], len[i], o->kmerqlty, &lines[i]);
+                    if (trc[i] == KSSD_HOST_ERR_EMPTY) trc[i] = 0; /* an empty file is an empty genome here */
+                }
+                t_tok += now_s() - t0;
+                for (int i = r0; i < r1; i++) {
+                    if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
+                    n_bytes += len[i];
+                    if (!o->abundance) printf("%llu reads detected\n", (unsigned long long)lines[i]);
+                    printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + i]);
+                }
+                j->b = b;
+            }
             pthread_mutex_lock(&pl.mu);
             if (pl.todo_tail) pl.todo_tail->next = j;
             else pl.todo_head = j;
@@ -622,6 +703,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             r0 = r1;
         }
     }
+    free(direct);
     for (int i = 0; i < threads; i++) free(txt[i]);
     free(txt);
     free(txt_cap);
@@ -666,6 +748,11 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     free(jl);
     for (int i = 0; i < pl.n_pool; i++) kssd_batch_destroy(pl.pool[i]);
     free(pl.pool);
+    for (int i = 0; i < pl.n_tpool; i++) {
+        if (pl.tpool[i]->p) kssd_gpu_host_free(pl.tpool[i]->p);
+        free(pl.tpool[i]);
+    }
+    free(pl.tpool);
     free(ws);
     s.shuf_id = (uint32_t)hdr.id;
     s.kmerlen = d.kmerlen;

@@ -710,6 +710,39 @@ int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t 
     return KSSD_HOST_OK;
 }
 
+/* is the file gzip'ed (magic 1f 8b), and how many bytes does it hold on disk */
+int kssd_file_probe(const char *path, int *is_gz, uint64_t *size)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return KSSD_HOST_ERR_IO;
+    unsigned char magic[2];
+    struct stat st;
+    const ssize_t got = pread(fd, magic, 2, 0);
+    const int rc = fstat(fd, &st);
+    close(fd);
+    if (rc != 0) return KSSD_HOST_ERR_IO;
+    *is_gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    *size = (uint64_t)st.st_size;
+    return KSSD_HOST_OK;
+}
+
+/* a plain file's bytes straight into memory of the caller's (e.g. a page-locked buffer): at most cap bytes */
+int kssd_read_into(const char *path, unsigned char *dst, size_t cap, size_t *len)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return KSSD_HOST_ERR_IO;
+    size_t n = 0;
+    while (n < cap) {
+        const ssize_t r = read(fd, dst + n, cap - n);
+        if (r < 0) { close(fd); return KSSD_HOST_ERR_IO; }
+        if (r == 0) break;
+        n += (size_t)r;
+    }
+    close(fd);
+    *len = n;
+    return KSSD_HOST_OK;
+}
+
 int kssd_batch_add_file(kssd_batch *b, const char *path, int is_fastq, int Q, uint64_t *n_lines)
 {
     unsigned char *txt = NULL;

@@ -85,6 +85,10 @@ int kssd_slurp(const char *path, unsigned char **buf, size_t *len);
 /* the same into a malloc'd buffer the caller keeps from file to file: *buf / *cap are grown (realloc) when the file
  * does not fit, *len receives the bytes read; the caller frees *buf in the end */
 int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t *len);
+/* is the file gzip'ed (magic 1f 8b), and its size on disk; kssd_read_into copies a plain file's bytes (at most cap) into
+ * memory of the caller's choice -- e.g. a page-locked buffer the device tokeniser reads from */
+int kssd_file_probe(const char *path, int *is_gz, uint64_t *size);
+int kssd_read_into(const char *path, unsigned char *dst, size_t cap, size_t *len);
 
 /* ---- derived constants (seq2co_global_var_initial iseq2comem.c:54-77, get_hashsz command_dist.c:217-236) */
 typedef struct kssd_derived {

@@ -1,0 +1,95 @@
+"""-m gpu: the FASTA tokeniser on the device (kssd_gpu_tokenise_fasta_device, csrc/kssd_tok.inc) against the host
+tokeniser (libkssd_host.so, itself pinned against the reference's sketches by the golden tests): the packed words, the
+mask words and the position counts must be bit for bit what kssd_batch_fill_text writes for the same bytes, and the
+sketches of device-tokenised text must equal the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+import kssd_oracle as ko
+import public_kssd_amd as K
+from synth import fasta_text
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def rnd(n):
+        return bytes(acgt[rng.integers(0, 4, n, dtype=np.uint8)])
+    edge = open(os.path.join(G, "qry_fa", "edge.fa"), "rb").read()   # lower case, IUPAC, CRLF, '>' mid-line, a 70 KB header ...
+    return [
+        fasta_text(rng.integers(0, 4, 300_000, dtype=np.uint8), n_mask=rng.random(300_000) < 1e-3),
+        edge,
+        b">only a header\n",
+        b"ACGT",                                                       # no header, no newline, one word
+        b"",                                                           # empty file: an empty genome
+        b">h\n" + rnd(4095) + b"\n",                                   # one position short of a chunk
+        b">h\n" + rnd(4096) + b"\n" + b"N" * 5000 + rnd(17) + b"\n",   # a break stretch longer than a tile
+        rnd(10_000).lower() + b"\n>x" + b"y" * 9000 + b"\n" + rnd(33) + b">tail header\n",   # header longer than two tiles; file ends after a header
+        b"\n\n\r\n" + rnd(50) + b"\r\n\r\n" + rnd(50) + b"-*" + rnd(4) + b"\n",
+        b"N" * 70 + b"\n" + rnd(100) + b"\n",                          # breaks BEFORE the first base: no leading invalid position
+        b">" + b"A" * 5000 + b"\n" + rnd(20_000) + b"\n",              # bases inside a header are not bases
+        bytes(rng.integers(0, 256, 60_000, dtype=np.uint8)).replace(b">", b"#") + b"\n",   # arbitrary bytes incl. >= 128
+    ]
+
+
+def test_device_tokeniser_writes_what_the_host_tokeniser_writes(shuf_l3k10):
+    import torch
+    dev = torch.device("cuda", 0)
+    texts = _cases()
+    hb = K.Batch()
+    first = hb.reserve([len(t) for t in texts])
+    for i, t in enumerate(texts):
+        if len(t):
+            hb.fill_text(first + i, t)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        buf, offs, lens = ctx._text_layout(texts)
+        co = hb.chunk_off()
+        d_text = torch.from_numpy(buf).to(dev)
+        nchunks = int(co[-1])
+        d_packed = torch.full((nchunks * K.CHUNK_WORDS + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)   # zeroed by the call
+        d_mask = torch.full((nchunks * K.CHUNK_MASKW + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        rc, bad, npos = ctx.tokenise_fasta_device(d_text, offs, lens, d_packed, d_mask, co)
+        assert rc == 0 and bad == -1
+        assert np.array_equal(npos, np.array([hb.n_positions(first + i) for i in range(len(texts))], dtype=np.uint64))
+        gp = d_packed.cpu().numpy().view(np.uint32)
+        gm = d_mask.cpu().numpy().view(np.uint32)
+        assert np.array_equal(gp, hb.packed()[:len(gp)])
+        assert np.array_equal(gm, hb.mask()[:len(gm)])
+        # a header that is not closed: the file index comes back, like the host tokeniser's error
+        bad_texts = [texts[0], b">never ends", texts[5], b"ACGT>also open"]
+        b2, o2, l2 = ctx._text_layout(bad_texts)
+        co2 = np.concatenate([[0], np.cumsum([(len(t) + 4095) // 4096 for t in bad_texts])]).astype(np.uint64)
+        rc, bad, _ = ctx.tokenise_fasta_device(torch.from_numpy(b2).to(dev), o2, l2, d_packed, d_mask, co2)
+        assert rc == K.capi.ERR_INPUT and bad == 1
+        with pytest.raises(K.KssdError) as e:
+            ctx.sketch_fasta_texts(bad_texts)
+        assert e.value.code == K.capi.ERR_INPUT and e.value.bad_genome == 1
+    finally:
+        ctx.close()
+
+
+def test_sketches_of_device_tokenised_text_equal_the_oracle(shuf_l3k10):
+    rng = np.random.default_rng(5)
+    texts = [t for t in _cases() if t not in (b"",)]
+    texts += [fasta_text(rng.integers(0, 4, n, dtype=np.uint8), b"g%d" % n, n_mask=rng.random(n) < 1e-4) for n in (5_000_000, 1_234_567)]
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        off, ids = ctx.sketch_fasta_texts(texts)
+        sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+        for g, t in enumerate(texts):
+            assert np.array_equal(ids[int(off[g]):int(off[g + 1])], np.sort(sk.fasta(t))), g
+        # with first positions: the reference's file order comes out of the same call
+        off2, ids2, pos2 = ctx.sketch_fasta_texts(texts, with_pos=True)
+        assert np.array_equal(off, off2) and np.array_equal(ids, ids2)
+        g = len(texts) - 2
+        lo, hi = int(off[g]), int(off[g + 1])
+        assert np.array_equal(K.slot_order_pos(ids2[lo:hi], pos2[lo:hi], sk.p.hashsize), sk.fasta(texts[g]))
+    finally:
+        ctx.close()
