@@ -240,10 +240,19 @@ template <int SUBK>
 KSSD_HD void kssd_extract_carry(const uint32_t (&W)[5], uint32_t Wm1, uint32_t b, uint32_t &top32, uint32_t &front)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // two select levels on the 96-bit window instead of three 4-way selects (7 v_cndmask / v_bfi instead of 9): bit 5 of b
+    // picks four consecutive words, bit 4 three of those; then one 64-bit shift each for the 16 bases and for the 4 bases
+    // in front (a v_bfe_u32 at offset 32 - sh would be cheaper but wraps to offset 0 when sh = 0)
     const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 4, 1), s2 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 5, 1);
+#define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
+    const uint32_t x0 = KSSD_BSEL(s2, W[1], Wm1), x1 = KSSD_BSEL(s2, W[2], W[0]), x2 = KSSD_BSEL(s2, W[3], W[1]), x3 = KSSD_BSEL(s2, W[4], W[2]);
+    const uint32_t pre = KSSD_BSEL(s1, x1, x0), hi = KSSD_BSEL(s1, x2, x1), lo = KSSD_BSEL(s1, x3, x2);
+#undef KSSD_BSEL
+    const uint32_t sh = (b & 15u) * 2u;
+    top32 = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
+    front = (uint32_t)(((((uint64_t)pre << 32) | hi) << sh) >> 32);  // low 8 bits: the 4 bases before position b
 #else
     const uint32_t s1 = 0u - ((b >> 4) & 1u), s2 = 0u - ((b >> 5) & 1u);
-#endif
 #define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
     const uint32_t pre = KSSD_BSEL(s2, KSSD_BSEL(s1, W[2], W[1]), KSSD_BSEL(s1, W[0], Wm1));
     const uint32_t hi = KSSD_BSEL(s2, KSSD_BSEL(s1, W[3], W[2]), KSSD_BSEL(s1, W[1], W[0]));
@@ -252,6 +261,7 @@ KSSD_HD void kssd_extract_carry(const uint32_t (&W)[5], uint32_t Wm1, uint32_t b
     const uint32_t sh = (b & 15u) * 2u;
     top32 = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
     front = (uint32_t)(((((uint64_t)pre << 32) | hi) << sh) >> 32);  // low 8 bits: the 4 bases before position b
+#endif
 }
 
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank
