@@ -870,12 +870,29 @@ __device__ __forceinline__ void sort_in_registers(K *a, const K *__restrict__ sr
     __syncthreads();
 }
 
-template <typename K>
-__global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
+// FUSED: the workgroup takes its genome's candidates straight from the scan's candidate list (the slices of the scan
+// waves whose chunk runs overlap the genome), evaluates them (stage 2, as sketch_exact_kernel does) and collects the
+// survivors in LDS, where the sort needs them anyway: no staging region is written and read back, no cursor atomics, no
+// chunk -> genome map, one kernel less.  Used whenever no genome of the batch needs the global-memory path.
+struct FuseArgs {
+    const ulonglong2 *cand;
+    unsigned long long cand_cap;
+    const uint32_t *cand_count;
+    unsigned long long per;          // chunks per scan wave (slice w covers chunks [w * per, (w + 1) * per))
+    uint32_t n_slices;
+    const unsigned long long *chunk_off;
+    const uint32_t *packed, *mask;
+    const KssdG *G;
+    uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
+};
+#define FUSE_PER 4  // candidates a thread evaluates at a time (six spill at 64 VGPRs)
+
+template <typename K, bool FUSED>
+__global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
                                                                       const uint32_t *__restrict__ cursor,
                                                                       K *__restrict__ regions, uint32_t *__restrict__ kept,
                                                                       uint32_t flags, uint32_t min_occ, uint32_t big_min,
-                                                                      SketchStatus *st)
+                                                                      SketchStatus *st, FuseArgs fx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K *a = reinterpret_cast<K *>(smem);
@@ -885,7 +902,106 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
     const unsigned long long r0 = reg_off[g];
     const uint32_t cap = (uint32_t)(reg_off[g + 1] - r0);
-    uint32_t n = cursor[g];
+    uint32_t n;
+    if (FUSED) {
+        __shared__ uint32_t s_n, s_pref[DEDUP_THREADS];
+        const uint32_t lane = lane_id();
+        if (tid == 0) s_n = 0;
+        const unsigned long long cb = fx.chunk_off[g], ce = fx.chunk_off[g + 1];
+        const long long glo = (long long)(cb * KSSD_CHUNK), ghi = (long long)(ce * KSSD_CHUNK);
+        const unsigned long long w0 = ce > cb ? cb / fx.per : 1, w1 = ce > cb ? (ce - 1) / fx.per : 0;  // empty genome: no slice
+        __syncthreads();
+        for (unsigned long long wbase = w0; wbase <= w1; wbase += DEDUP_THREADS) {
+            // candidates of up to 512 slices, flattened: prefix of their counts in LDS, then FUSE_PER per thread and round
+            const unsigned long long w = wbase + tid;
+            uint32_t cw = 0;
+            if (w <= w1 && w < fx.n_slices) {
+                cw = fx.cand_count[w];
+                if (cw > fx.cand_cap) {  // the scan wave wanted to list more than its slice holds: the call is repeated larger
+                    atomicOr(&st->cand_overflow, 1u);
+                    atomicMax(&st->cand_need, cw);
+                    cw = (uint32_t)fx.cand_cap;
+                }
+            }
+            uint32_t total;
+            const uint32_t before = block_excl_scan(cw, wsum, total);
+            s_pref[tid] = before;
+            __syncthreads();
+            for (uint32_t f0 = 0; f0 < total; f0 += DEDUP_THREADS * FUSE_PER) {
+                bool ok[FUSE_PER];
+                ulonglong2 cd[FUSE_PER];
+                uint32_t dim[FUSE_PER];
+                uint64_t u[FUSE_PER];
+#pragma unroll
+                for (int j = 0; j < FUSE_PER; j++) {
+                    const uint32_t f = f0 + (uint32_t)j * DEDUP_THREADS + tid;
+                    ok[j] = f < total;
+                    cd[j] = make_ulonglong2(0ull, 0ull);
+                    if (ok[j]) {
+                        uint32_t lo = 0, hi = DEDUP_THREADS - 1;  // last slice s with s_pref[s] <= f
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi + 1) >> 1;
+                            if (s_pref[mid] <= f) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        cd[j] = fx.cand[(wbase + lo) * fx.cand_cap + (f - s_pref[lo])];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FUSE_PER; j++) {
+                    const long long sp = (long long)cd[j].x, b0 = sp - P.out;
+                    ok[j] = ok[j] && sp >= glo && sp < ghi && b0 >= glo && b0 + P.nb <= ghi;  // this genome's, and inside it
+                    u[j] = 0;
+                    dim[j] = 0;
+                    if (ok[j]) {
+                        const unsigned long long b0c = (unsigned long long)b0;
+                        const bool known = (cd[j].y >> 63) != 0;
+                        if (fx.carry) {
+                            kssd_s2_canon(P, kssd_carry_fwd(P, cd[j].y & 0xFFFFFFFFFFull), u[j], dim[j]);
+                            if (!known) {
+                                const uint32_t *mp = fx.mask + (b0c >> 5);
+                                const uint64_t m64 = (uint64_t)mp[0] | ((uint64_t)mp[1] << 32), need = (1ull << P.nb) - 1ull;
+                                ok[j] = ((m64 >> (b0c & 31ull)) & need) == need;
+                            }
+                        } else {
+                            const uint32_t *pp = fx.packed + (b0c >> 4), *mp = fx.mask + (b0c >> 5);
+                            uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+                            if (!known) { m0 = mp[0]; m1 = mp[1]; }
+                            ok[j] = kssd_s2_decode(P, pp[0], pp[1], pp[2], m0, m1, (uint32_t)b0c, u[j], dim[j]);
+                        }
+                    }
+                }
+                KssdG e1[FUSE_PER], e2[FUSE_PER];
+#pragma unroll
+                for (int j = 0; j < FUSE_PER; j++) {
+                    e1[j] = fx.G[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
+                    e2[j] = fx.G[(1u << P.g_log2) + kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)];
+                }
+#pragma unroll
+                for (int j = 0; j < FUSE_PER; j++) {
+                    const bool h1 = e1[j].key == dim[j], h2 = e2[j].key == dim[j];
+                    ok[j] = ok[j] && (h1 || h2);
+                    const uint64_t bal = __ballot(ok[j]);
+                    if (bal) {  // one LDS atomic per wave reserves room for its survivors
+                        uint32_t at = 0;
+                        if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__builtin_popcountll(bal));
+                        at = __builtin_amdgcn_readfirstlane(at) + rank_in(bal);
+                        if (ok[j] && at < fx.lds_keys) {
+                            const uint32_t dr = kssd_s2_tuple(P, u[j], h1 ? e1[j].rank : e2[j].rank);
+                            const uint32_t gpos = (uint32_t)((long long)cd[j].x - glo);
+                            a[at] = fx.by_pos ? KeyOps<K>::make(gpos, dr) : KeyOps<K>::make(dr, gpos);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // s_pref is rewritten by the next round of slices
+        }
+        __syncthreads();
+        n = s_n;
+    } else {
+        n = cursor[g];
+    }
+    const K *src = FUSED ? a : regions + r0;
     if (n > cap) {
         if (tid == 0) {
             atomicOr(&st->region_overflow, 1u);
@@ -900,11 +1016,12 @@ __global__ __launch_bounds__(DEDUP_THREADS) void sketch_dedup_kernel(KssdParams 
     uint32_t np = 1;
     while (np < n) np <<= 1;
     if (tid == 0) { s_distinct = 0; s_zero_occ = 0; }
-    if (np == 2 * DEDUP_THREADS) sort_in_registers<K, 2>(a, regions + r0, n, tid);
-    else if (np == 4 * DEDUP_THREADS) sort_in_registers<K, 4>(a, regions + r0, n, tid);
-    else if (np == 8 * DEDUP_THREADS) sort_in_registers<K, 8>(a, regions + r0, n, tid);
+    if (np == 2 * DEDUP_THREADS) sort_in_registers<K, 2>(a, src, n, tid);
+    else if (np == 4 * DEDUP_THREADS) sort_in_registers<K, 4>(a, src, n, tid);
+    else if (np == 8 * DEDUP_THREADS) sort_in_registers<K, 8>(a, src, n, tid);
     else {
-    for (uint32_t i = tid; i < np; i += DEDUP_THREADS) a[i] = i < n ? regions[r0 + i] : KeyOps<K>::pad();
+    for (uint32_t i = tid; i < np; i += DEDUP_THREADS)
+        if (!FUSED || i >= n) a[i] = i < n ? src[i] : KeyOps<K>::pad();  // (fused: the keys are in place already)
     __syncthreads();
     for (uint32_t k = 2; k <= np; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -1161,11 +1278,36 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     uint32_t np = 1;
     while (np < max_cap) np <<= 1;
     const size_t dlds = (size_t)np * sizeof(K);
-    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
-    hipLaunchKernelGGL((sketch_dedup_kernel<K>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
-                       (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
-                       flags, min_occ, big_min, c->d_status);
+    FuseArgs fx;
+    memset(&fx, 0, sizeof fx);
+    if (c->h_big.empty()) {
+        // no genome needs the global-memory sort: exact stage and per-genome sort in one kernel, straight from the candidate list
+        const auto &pl = c->plan;
+        fx.cand = reinterpret_cast<const ulonglong2 *>(c->d_cand);
+        fx.cand_cap = pl.cand_cap;
+        fx.cand_count = c->d_cand_count;
+        fx.n_slices = pl.n_slices;
+        fx.per = (pl.n_chunks + pl.n_slices - 1) / pl.n_slices;  // the scan kernel's partition of the chunks over its waves
+        if (fx.per == 0) fx.per = 1;
+        fx.chunk_off = (const unsigned long long *)c->d_chunk_off;
+        fx.packed = pl.d_packed;
+        fx.mask = pl.d_mask;
+        fx.G = c->d_G;
+        fx.carry = kssd_carry_ok(c->P) ? 1u : 0u;
+        fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
+        fx.lds_keys = np;
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
+        hipLaunchKernelGGL((sketch_dedup_kernel<K, true>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
+                           (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
+                           flags, min_occ, big_min, c->d_status, fx);
+    } else {
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
+        hipLaunchKernelGGL((sketch_dedup_kernel<K, false>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
+                           (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
+                           flags, min_occ, big_min, c->d_status, fx);
+    }
     if (!c->h_big.empty()) {
         const size_t n_tiles_max = (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
         const size_t kw = sizeof(K) / 4;  // u32 words per key
@@ -1380,6 +1522,7 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
 {
     const auto &pl = c->plan;
     if (pl.n_genomes == 0 || pl.n_chunks == 0) return KSSD_OK;
+    if (c->h_big.empty()) return KSSD_OK;  // the FINISH phase evaluates the candidates itself (sketch_dedup_kernel<K, true>)
     ExactArgs x;
     x.packed = pl.d_packed; x.mask = pl.d_mask; x.chunk_gid = c->d_chunk_gid;
     x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;
