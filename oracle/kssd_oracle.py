@@ -348,8 +348,9 @@ def have_ref():
 def run_ref(args, cwd=None, timeout=600, check=True):
     """Run oracle/_ref/kssd with argv[0]="kssd": the reference's main() writes one byte past a heap
     block when strlen(argv[0]) % 16 == 11 (kssd.c:29-30) and then crashes or hangs at random."""
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}  # (a sanitizer run of OUR host library must not instrument it)
     r = subprocess.run(["kssd"] + [str(a) for a in args], executable=REF_BIN, cwd=cwd, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=timeout)
+                       stderr=subprocess.STDOUT, timeout=timeout, env=env)
     if check and r.returncode != 0:
         raise RuntimeError("reference kssd %s -> %d\n%s" % (args, r.returncode, r.stdout.decode(errors="replace")[-2000:]))
     return r

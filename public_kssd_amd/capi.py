@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GPU_LIB = os.path.join(HERE, "libkssd_gpu.so")
-HOST_LIB = os.path.join(HERE, "libkssd_host.so")
+HOST_LIB = os.environ.get("KSSD_HOST_LIB", os.path.join(HERE, "libkssd_host.so"))  # (the sanitizer run points this at its own build)
 
 CHUNK_BASES = 4096
 CHUNK_WORDS = 256

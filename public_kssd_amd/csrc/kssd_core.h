@@ -152,7 +152,15 @@ KSSD_HD void kssd_grp_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[K
     for (int q = 0; q < Gp::NMAX; q++) {
         if (q < Gp::count(ALN)) {
             const int Q = Gp::first(ALN) + Gp::W * q;
+#if defined(KSSD_SCAN_B64) && defined(__HIP_DEVICE_COMPILE__)
+            // experiment (libkssd_gpu_b64.so, profiles/scanbench_b64): the same byte out of an aligned 8-byte read.  ds_read_b64
+            // banks on (a/4) mod 64, but an 8-byte read occupies TWO of the 64 banks: 32 lanes still fall into 32 bins
+            const uint32_t idx = kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1));
+            const uint2 v8 = *reinterpret_cast<const uint2 *>(&T1[idx & ~7u]);
+            raw[q] = (((idx & 4u) ? v8.y : v8.x) >> ((idx & 3u) * 8u)) & 0xFFu;
+#else
             raw[q] = T1[kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1))];
+#endif
         } else {
             raw[q] = 0;
         }
