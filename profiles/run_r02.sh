@@ -28,7 +28,7 @@ prof) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
     f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_kernel_stats.csv
     rm -rf gpurun_out/${tag}_prof; cat gpurun_out/${tag}_kernel_stats.csv ;;
-pmc) rx='sketch_scan_kernel|sketch_exact_kernel|idx_|dist_rows'
+pmc) rx='sketch_scan_kernel|sketch_exact_kernel|sketch_dedup_kernel|idx_|dist_rows'
     {
     profiles/pmc_pass.sh ${tag}_sq2 "$rx" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE
     profiles/pmc_pass.sh ${tag}_fetch "$rx" FETCH_SIZE
