@@ -267,6 +267,16 @@ int kssd_gpu_dist_select(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t
 int kssd_gpu_dist_multi(const int *devices, int n_devices, int kmerlen, const uint64_t *roff, const uint32_t *rids,
                         uint32_t n_ref, const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,
                         double *jaccard, double *mashd, double *contain, double *aafd);
+/*
+ * The unpacking side of the one exchange step of the multi-GPU path (one process per GPU, an all-gather of every rank's
+ * sketches over RCCL): each of `world` ranks contributed a fixed-size unit -- n_per_unit + 1 offsets (u64, exclusive
+ * prefix of its sketch sizes) and `cap` id slots (u32, the first off[n_per_unit] meaningful).  d_off_all
+ * [world x (n_per_unit + 1)] and d_ids_all [world x cap] are the gathered units; the call writes the CSR of all
+ * world x n_per_unit sketches: d_roff [world * n_per_unit + 1], d_rids [up to world x cap] (genome r * n_per_unit + g of
+ * the result is genome g of rank r).  DEVICE pointers, nothing is synchronised.
+ */
+int kssd_gpu_concat_units_device(kssd_gpu_ctx *ctx, const uint64_t *d_off_all, const uint32_t *d_ids_all, uint32_t world,
+                                 uint32_t n_per_unit, uint64_t cap, uint64_t *d_roff, uint32_t *d_rids, void *stream);
 /* how many gfx950 devices this process sees (0 without any; never an error) */
 int kssd_gpu_device_count(void);
 

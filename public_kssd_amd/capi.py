@@ -41,7 +41,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
     "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
-    "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
+    "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text", "kssd_gpu_concat_units_device",
 ]
 
 
@@ -125,6 +125,7 @@ def gpu_lib():
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
+        L.kssd_gpu_concat_units_device.argtypes = [vp, vp, vp, u32, u32, u64, vp, vp, vp]
         L.kssd_gpu_sketch_fasta_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                  C.POINTER(C.c_int64)]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
@@ -736,6 +737,11 @@ class GpuCtx:
             gpu_lib().kssd_gpu_free(po)
             gpu_lib().kssd_gpu_free(pi)
         return ooff, oids
+
+    def concat_units_device(self, d_off_all, d_ids_all, world, n_per_unit, cap, d_roff, d_rids, stream=None):
+        """the all-gathered sketch units of `world` ranks -> one CSR (device tensors; nothing is synchronised)"""
+        _gck(gpu_lib().kssd_gpu_concat_units_device(self.h, _ptr(d_off_all), _ptr(d_ids_all), world, n_per_unit, cap,
+                                                    _ptr(d_roff), _ptr(d_rids), stream))
 
     def set_lds_sort_limit(self, max_tuples):
         """genomes staging more tuples than this take the global-memory dedup path (0 = default); results unchanged"""

@@ -29,18 +29,24 @@ class SketchGather:
     genome r*G+g of the global numbering is genome g of rank r.
     """
 
-    def __init__(self, world, G, cap, device):
+    def __init__(self, world, G, cap, device, engine=None):
+        """engine: an object with concat_units_device (public_kssd_amd.GpuCtx) does the unpacking with one copy kernel;
+        without it (CPU tests) the same CSR comes out of tensor ops"""
         self.world, self.G, self.cap = world, G, cap
+        self.engine = engine if hasattr(engine, "concat_units_device") else None
         self.off_all = torch.zeros(world * (G + 1), dtype=torch.int64, device=device)
         self.ids_all = torch.zeros(world * cap, dtype=torch.int32, device=device)
         self.roff = torch.zeros(world * G + 1, dtype=torch.int64, device=device)
         self.rids = torch.zeros(world * cap, dtype=torch.int32, device=device)
         self._j = torch.arange(world * cap, device=device, dtype=torch.int64)
 
-    def __call__(self, off_l, ids_l, group=None):
+    def __call__(self, off_l, ids_l, group=None, stream=None):
         import torch.distributed as dist
         dist.all_gather_into_tensor(self.off_all, off_l, group=group)
         dist.all_gather_into_tensor(self.ids_all, ids_l, group=group)
+        if self.engine is not None:
+            self.engine.concat_units_device(self.off_all, self.ids_all, self.world, self.G, self.cap, self.roff, self.rids, stream)
+            return self.roff, self.rids
         return self.compact()
 
     def compact(self):
@@ -80,7 +86,7 @@ class ShardedSearch:
             raise ValueError("partition must be 'query' or 'transpose'")
         self.world, self.rank, self.G, self.cap = world, rank, G, cap
         self.engine, self.partition = engine, partition
-        self.gather = SketchGather(world, G, cap, device) if world > 1 else None
+        self.gather = SketchGather(world, G, cap, device, engine) if world > 1 else None
 
     def cells(self, Q=None):
         Q = self.G if Q is None else Q
@@ -104,9 +110,9 @@ class ShardedSearch:
             roff, rids = off_l, ids_l
         elif tstream is not None:
             with torch.cuda.stream(tstream):
-                roff, rids = self.gather(off_l, ids_l, group=group)
+                roff, rids = self.gather(off_l, ids_l, group=group, stream=stream)
         else:
-            roff, rids = self.gather(off_l, ids_l, group=group)
+            roff, rids = self.gather(off_l, ids_l, group=group, stream=stream)
         self._gathered = (roff, rids)
         if self.partition == "query":   # full index on every rank
             self.engine.index_build_device(roff, rids, w * G, max_ids * w, stream)
