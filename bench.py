@@ -528,6 +528,7 @@ def main():
         sl.tstream = torch.cuda.Stream(device=dev) if NF > 1 else torch.cuda.current_stream()
         sl.stream = sl.tstream.cuda_stream
         sl.scanned, sl.sorted = torch.cuda.Event(), torch.cuda.Event()
+        sl.unit = cap
         sl.search = ShardedSearch(world, rank, G, cap, dev, sl.ctx, partition=a.partition)
         # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
         # status read-back has told the host how many ids this batch really has
@@ -540,11 +541,11 @@ def main():
 
     def index_build(sl):
         # the one exchange step of the path (N > 1): all-gather of every rank's packed sketches (RCCL over xGMI), then the
-        # index in the chosen partition (public_kssd_amd/shard.py)
-        sl.search.index(sl.off_l, sl.ids_l, sl.idx_bound, stream=sl.stream, tstream=sl.tstream if world > 1 else None)
+        # index in the chosen partition (public_kssd_amd/shard.py).  The unit a rank contributes is its first sl.unit ids.
+        sl.search.index(sl.off_l, sl.ids_l[:sl.unit], sl.idx_bound, stream=sl.stream, tstream=sl.tstream if world > 1 else None)
 
     def rows(sl):
-        sl.search.rows(sl.off_l, sl.ids_l, sl.shared, sl.planes, stream=sl.stream)
+        sl.search.rows(sl.off_l, sl.ids_l[:sl.unit], sl.shared, sl.planes, stream=sl.stream)
 
     def run_steps(n_steps):
         """n_steps whole steps, pipelined over the NF slots; everything is enqueued, nothing synchronised"""
@@ -602,6 +603,18 @@ def main():
         else:
             raise SystemExit("sketch kept overflowing")
     sync()
+    if world > 1:
+        # the exchange unit shrinks from the padded capacity to what the fullest rank really holds (+ a margin): setup,
+        # untimed -- every step then gathers 20 % fewer bytes
+        need = torch.tensor([max(sl.idx_bound for sl in slots)], dtype=torch.int64, device=dev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        unit = min(cap, (int(need.item()) + 4096 + 1023) // 1024 * 1024)
+        for sl in slots:
+            sl.unit = unit
+            sl.search = ShardedSearch(world, rank, G, unit, dev, sl.ctx, partition=a.partition)
+            index_build(sl)
+            rows(sl)
+        sync()
     # setup, untimed like the sizing passes above: the clocks of an idle GPU need some tens of milliseconds of work to
     # settle (measured: the scan launch takes 0.54 ms in the first dozen steps after a pause and 0.52 ms from then on)
     run_steps(a.spinup)

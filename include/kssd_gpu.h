@@ -214,6 +214,15 @@ int kssd_gpu_index_build_device(kssd_gpu_ctx *ctx, const uint64_t *d_roff, const
                                 uint32_t n_ref, uint64_t max_ref_ids, void *stream);
 
 /*
+ * Tuning knob for searches whose query rows mostly MISS the index (the foreign rows of the multi-GPU all-pairs
+ * partition: every rank's sketches against the own index): the next kssd_gpu_index_build_device also builds a blocked
+ * Bloom filter of the indexed ids (~2 MB per 1.2 M ids, L2 resident), and kssd_gpu_dist_device consults it before it
+ * walks the table -- except for query rows [skip_row_begin, skip_row_end), which are expected to hit (the rank's own
+ * rows).  The results do not depend on it.  Off by default: on rows that hit it only costs.
+ */
+int kssd_gpu_index_set_filter(kssd_gpu_ctx *ctx, int enable, uint32_t skip_row_begin, uint32_t skip_row_end);
+
+/*
  * Shared-k-mer counts and distances for query rows [q_begin, q_end) against the indexed references:
  * replaces the hot loop of mco_cbdco_nobin_dist (command_dist.c:763-790) and the arithmetic of
  * output_ctrl (command_dist.c:1251-1266, no --correction).  All pointers DEVICE; the five outputs are

@@ -17,12 +17,23 @@ for seed in (1, 2):
 (offA, idsA, tA), (offB, idsB, tB) = sk
 shared = torch.zeros(G * G, dtype=torch.int32, device=dev)
 planes = [torch.zeros(G * G, dtype=torch.float64, device=dev) for _ in range(4)]
-ctx.index_build_device(offA, idsA, G, tA)
-for name, (qo, qi) in (("own", (offA, idsA)), ("foreign", (offB, idsB))):
-    for pl, tag in ((planes, "planes"), ([None] * 4, "counts only")):
-        ctx.kernel_time(1, reset=True)
-        for _ in range(20):
-            ctx.dist_device(qo, qi, G, 0, G, shared, *pl)
-        torch.cuda.synchronize()
-        ms, n = ctx.kernel_time(1)
-        print("rows %-8s %-12s %.1f us (%d launches), shared sum %d" % (name, tag, ms * 1e3, n, int(shared.sum())))
+for filt in (False, True):
+    ctx.index_set_filter(filt)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.index_build_device(offA, idsA, G, tA)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        ctx.index_build_device(offA, idsA, G, tA)
+    e1.record()
+    torch.cuda.synchronize()
+    print("negative filter %s: index build %.1f us" % ("ON" if filt else "off", e0.elapsed_time(e1) / 20 * 1e3))
+    sums = {}
+    for name, (qo, qi) in (("own", (offA, idsA)), ("foreign", (offB, idsB))):
+        for pl, tag in ((planes, "planes"), ([None] * 4, "counts only")):
+            ctx.kernel_time(1, reset=True)
+            for _ in range(20):
+                ctx.dist_device(qo, qi, G, 0, G, shared, *pl)
+            torch.cuda.synchronize()
+            ms, n = ctx.kernel_time(1)
+            print("   rows %-8s %-12s %.1f us (%d launches), shared sum %d" % (name, tag, ms * 1e3, n, int(shared.sum())))

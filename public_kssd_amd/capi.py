@@ -42,6 +42,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
     "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text", "kssd_gpu_concat_units_device",
+    "kssd_gpu_index_set_filter",
 ]
 
 
@@ -126,6 +127,7 @@ def gpu_lib():
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
         L.kssd_gpu_concat_units_device.argtypes = [vp, vp, vp, u32, u32, u64, vp, vp, vp]
+        L.kssd_gpu_index_set_filter.argtypes = [vp, i32, u32, u32]
         L.kssd_gpu_sketch_fasta_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                  C.POINTER(C.c_int64)]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
@@ -742,6 +744,10 @@ class GpuCtx:
         """the all-gathered sketch units of `world` ranks -> one CSR (device tensors; nothing is synchronised)"""
         _gck(gpu_lib().kssd_gpu_concat_units_device(self.h, _ptr(d_off_all), _ptr(d_ids_all), world, n_per_unit, cap,
                                                     _ptr(d_roff), _ptr(d_rids), stream))
+
+    def index_set_filter(self, enable, skip_row_begin=0, skip_row_end=0):
+        """negative filter in front of the index for searches whose rows mostly miss; rows [begin, end) bypass it"""
+        _gck(gpu_lib().kssd_gpu_index_set_filter(self.h, int(bool(enable)), skip_row_begin, skip_row_end))
 
     def set_lds_sort_limit(self, max_tuples):
         """genomes staging more tuples than this take the global-memory dedup path (0 = default); results unchanged"""

@@ -146,6 +146,10 @@ struct kssd_gpu_ctx {
     size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text;
     uint32_t tok_files;
     std::vector<unsigned long long> h_tok_tab;
+    uint32_t *d_filt;       // negative filter of the index (kssd_gpu_index_set_filter): one word per four slots
+    size_t cap_filt;
+    bool idx_filter, idx_has_filter;  // asked for / the index in place was built with it
+    uint32_t nofilt_lo, nofilt_hi;
     uint32_t *d_arrive;     // long query rows: arrival counters of the workgroups that share a row
     size_t cap_arrive;
     uint32_t *d_sel_cnt, *d_sel_out;  // report selection (kssd_gpu_dist_select): per-row counts / starts, candidate pairs
@@ -263,7 +267,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);

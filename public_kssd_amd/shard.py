@@ -87,6 +87,10 @@ class ShardedSearch:
         self.world, self.rank, self.G, self.cap = world, rank, G, cap
         self.engine, self.partition = engine, partition
         self.gather = SketchGather(world, G, cap, device, engine) if world > 1 else None
+        if world > 1 and partition == "transpose" and hasattr(engine, "index_set_filter"):
+            # (world - 1) / world of the query rows are other ranks' sketches and share next to nothing with the own index:
+            # a negative filter in front of the table for them, the own block of rows exempt
+            engine.index_set_filter(True, rank * G, (rank + 1) * G)
 
     def cells(self, Q=None):
         Q = self.G if Q is None else Q

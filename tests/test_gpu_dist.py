@@ -273,3 +273,53 @@ def test_long_query_rows_are_shared_by_several_workgroups(gpu_ctx):
     gpu_ctx.dist_device(d_qoff, d_qids, 3, 0, 3, b, max_row_ids=len(long_q))
     torch.cuda.synchronize()
     assert torch.equal(a, b) and np.array_equal(a.cpu().numpy().view(np.uint32).reshape(3, 300), want)
+
+
+def test_negative_filter_in_front_of_the_index_changes_nothing(shuf_l3k10):
+    """kssd_gpu_index_set_filter: a per-bucket Bloom filter consulted before the table is walked (for searches whose rows
+    mostly miss: the foreign rows of the multi-GPU partition).  Same counts and planes with it, without it, and with a
+    block of rows exempt; also through a bucket built in HBM."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    roff, rids = random_sketches(rng, 200, 900, 1300, 1 << 28, clades=8)
+    qoff, qids = random_sketches(rng, 150, 0, 1300, 1 << 28, clades=8)        # other pools: nearly all ids miss
+    n = len(qids) // 4
+    qids[:n] = rng.choice(rids, size=n)                                        # ... except a quarter
+    for i in range(len(qoff) - 1):
+        s, e = int(qoff[i]), int(qoff[i + 1])
+        u = np.unique(qids[s:e])
+        fill = rng.choice(1 << 28, size=(e - s) - len(u), replace=False).astype(np.uint32)
+        qids[s:e] = np.sort(np.concatenate([u, fill]))
+    want = ko.shared_counts(roff, rids, qoff, qids, threads=4)
+    assert want.sum() > 10_000
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
+        outs = []
+        for enable, lo, hi in ((False, 0, 0), (True, 0, 0), (True, 40, 90), (True, 0, 150)):
+            ctx.index_set_filter(enable, lo, hi)
+            ctx.index_build_device(d[0], d[1], 200, len(rids))
+            shared = torch.full((150 * 200,), -1, dtype=torch.int32, device=dev)
+            planes = [torch.zeros(150 * 200, dtype=torch.float64, device=dev) for _ in range(4)]
+            ctx.dist_device(d[2], d[3], 150, 0, 150, shared, *planes)
+            torch.cuda.synchronize()
+            assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(150, 200), want), (enable, lo, hi)
+            outs.append([p.cpu().numpy().view(np.int64) for p in planes])
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a, b)
+        # ids crafted into one bucket: the bucket (and its filter words) are built in HBM
+        pool = rng.choice(1 << 28, size=400_000, replace=False).astype(np.uint64)
+        mix = (pool * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+        crowd = pool[(mix >> np.uint64(29)) == 0].astype(np.uint32)
+        r2 = np.sort(rng.choice(crowd[:7000], 6000, replace=False))
+        roff2 = np.array([0, 3000, 6000], np.uint64)
+        r2[:3000].sort(); r2[3000:].sort()
+        q2 = np.sort(rng.choice(crowd, 5000, replace=False))
+        qoff2 = np.array([0, 5000], np.uint64)
+        ctx.index_set_filter(True, 0, 0)
+        got = ctx.dist(roff2, r2, qoff2, q2, planes=False)
+        assert np.array_equal(got, ko.shared_counts(roff2, r2, qoff2, q2))
+    finally:
+        ctx.close()
