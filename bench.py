@@ -290,6 +290,47 @@ def make_reads_batch(src_codes, n_reads, seed, dev, err=0.005, keep_reads=0, sli
     return packed, mask, np.array([0, chunks], dtype=np.uint64), kept
 
 
+def fastq_end_to_end(shuf, fq, n_reads, sk, ko):
+    """the slice as ONE .fastq file in tmpfs through the product's command line and through the reference binary: wall
+    times, and combco.0 byte for byte (the oracle's file order / the reference's file)"""
+    out = {}
+    d = tempfile.mkdtemp(prefix="kssd_benchq_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        with open(os.path.join(d, "reads.fastq"), "wb") as f:
+            f.write(fq)
+        shuf.write(os.path.join(d, "L3K10.shuf"))
+        gbase = n_reads * READ_LEN / 1e9
+        desc = "%d reads x %d bp as one %.2f GB .fastq file in tmpfs" % (n_reads, READ_LEN, len(fq) / 1e9)
+        want = None
+        if os.access(KSSD_BIN, os.X_OK):
+            dt, tm = _run_ours(["dist", "-p", host_cores(), "-L", "L3K10.shuf", "-o", "our_sk", "reads.fastq"], d, {"KSSD_TIMING": "1"})
+            want = sk.fastq(fq, Q=0, M=1)     # the reference's file order
+            got = np.fromfile(os.path.join(d, "our_sk", "combco.0"), np.uint32)
+            assert np.array_equal(got, want), "kssd CLI combco.0 of the read set != oracle (file order)"
+            out["end_to_end"] = {"value": gbase / dt, "unit": "Gbase/s", "seconds": dt, "reads_per_s": n_reads / dt, "stages": tm,
+                                 "what": "`kssd dist -L L3K10.shuf -o <dir> reads.fastq`: process start, .shuf load, file read into a "
+                                         "page-locked buffer, raw text H2D, tokenised + sketched on the device, D2H, slot order, combco.* "
+                                         "written -- wall time of the command; combco.0 equals the oracle's ids in file order",
+                                 "sample": desc}
+            dt_h, _ = _run_ours(["dist", "-p", host_cores(), "-L", "L3K10.shuf", "-o", "our_sk_host", "reads.fastq"], d, {"KSSD_HOST_FASTQ": "1"})
+            out["end_to_end"]["seconds_with_host_tokeniser"] = dt_h
+        if ko.have_ref() and shutil.which("zcat"):
+            t0 = time.time()
+            ko.run_ref(["dist", "-L", "L3K10.shuf", "-o", "ref_sk", "reads.fastq"], cwd=d, timeout=1800)
+            t_ref = time.time() - t0
+            ref = np.fromfile(os.path.join(d, "ref_sk", "combco.0"), np.uint32)
+            if want is not None:
+                assert np.array_equal(ref, want), "reference binary combco.0 != oracle"
+            out["cpu_baseline_reference"] = {"value": gbase / t_ref, "unit": "Gbase/s", "cores": 1, "kind": "reference", "seconds": t_ref,
+                                             "sample": desc + ", `oracle/_ref/kssd dist -L L3K10.shuf` wall time (one FASTQ file = one thread, "
+                                                              "command_dist.c:275)"}
+            if "end_to_end" in out:
+                out["end_to_end"]["byte_identical_to_reference"] = "combco.0"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def run_fastq(a, shuf, dev):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -379,7 +420,9 @@ def run_fastq(a, shuf, dev):
         t0 = time.time()
         fq = fastq_records(host_reads)
         hb = K.Batch()
+        t1 = time.time()
         assert hb.add_fastq(fq, Q=0) == 4 * n_par
+        t_host_tok = time.time() - t1
         # the device-side generator writes what the tokeniser writes: same packed words and mask for the slice
         nchk = hb.n_chunks
         whole = (n_par * (READ_LEN + 1)) // K.CHUNK_BASES    # chunks that hold slice reads only
@@ -399,7 +442,28 @@ def run_fastq(a, shuf, dev):
                 cpu = {"value": n_par * READ_LEN / 1e9 / t_or, "unit": "Gbase/s", "cores": 1, "kind": "port",
                        "sample": "%d of the reads (%.0f Mbase) as FASTQ text in memory, oracle/kssd_oracle.c ko_fastq2co on one "
                                  "thread (the reference sketches one FASTQ file on one thread, command_dist.c:275)" % (n_par, n_par * READ_LEN / 1e6)}
+        # ---- the same slice as FASTQ TEXT in HBM through the device tokeniser (csrc/kssd_tok.inc): what the command line does
+        d_text = torch.from_numpy(np.frombuffer(fq, dtype=np.uint8).copy()).to(dev)
+        tco = np.array([0, (len(fq) + K.CHUNK_BASES - 1) // K.CHUNK_BASES], dtype=np.uint64)
+        tp = torch.zeros(int(tco[1]) * K.CHUNK_WORDS + K.SLACK_WORDS, dtype=torch.int32, device=dev)
+        tm = torch.zeros(int(tco[1]) * K.CHUNK_MASKW + K.SLACK_WORDS, dtype=torch.int32, device=dev)
+        tok_ms = []
+        for it in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc, bad, npos_t, nlines_t = ctx.tokenise_fastq_device(d_text, [0], [len(fq)], tp, tm, tco)   # synchronises
+            tok_ms.append((time.perf_counter() - t0) * 1e3)
+            assert rc == 0 and int(nlines_t[0]) == 4 * n_par and int(npos_t[0]) == hb.n_positions(0)
+        nw, nm = nchk * K.CHUNK_WORDS, nchk * K.CHUNK_MASKW
+        assert np.array_equal(tp[:nw].cpu().numpy().view(np.uint32), hb.packed()[:nw]), "device FASTQ tokeniser: packed words != host tokeniser"
+        assert np.array_equal(tm[:nm].cpu().numpy().view(np.uint32), hb.mask()[:nm]), "device FASTQ tokeniser: mask words != host tokeniser"
+        par["device_tokeniser"] = {"text_bytes": len(fq), "ms": min(tok_ms[1:]), "gb_per_s": len(fq) / 1e9 / (min(tok_ms[1:]) * 1e-3),
+                                   "host_tokeniser_s_one_thread": t_host_tok,
+                                   "what": "FASTQ text of the slice resident in HBM -> packed batch, 5 kernels, wall time of the call incl. its "
+                                           "status read-back; output bit-identical to libkssd_host.so's tokeniser"}
+        del d_text, tp, tm
         hb.close()
+        e2e = fastq_end_to_end(shuf, fq, n_par, sk, ko)
         del fq
     # containment rows of the full run against the oracle's posting traversal
     oh = roff.cpu().numpy().astype(np.uint64)
@@ -438,6 +502,8 @@ def run_fastq(a, shuf, dev):
     }
     if cpu:
         res["cpu_baseline"] = cpu
+    if n_par and e2e:
+        res.update(e2e)
     print(json.dumps(res), flush=True)
     ctx.close()
 

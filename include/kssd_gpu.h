@@ -194,6 +194,22 @@ int kssd_gpu_tokenise_status(kssd_gpu_ctx *ctx, int64_t *bad_file, uint64_t *h_p
 int kssd_gpu_sketch_fasta_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
                                uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                                uint32_t **out_pos, int64_t *bad_genome);
+/*
+ * The same two for FASTQ read sets as fastq2co reads them with -Q 0 (iseq2comem.c:274-330: records of four lines, only
+ * the second one scanned, a read never continues the k-mer of the read in front of it, a final record its four lines
+ * do not complete is not scanned).  An input the device cannot do exactly as the reference -- no complete record, a line
+ * of 19 000 bytes or more (the reference's fgets() buffer splits lines at 19 999), a NUL or a byte >= 0x80 -- is handed
+ * back: kssd_gpu_tokenise_fastq_status / kssd_gpu_sketch_fastq_text return KSSD_ERR_UNSUPPORTED with its index, and the
+ * caller runs libkssd_host.so's kssd_batch_add_fastq for it.  h_lines (HOST u64[n_files], may be NULL) receives the
+ * line count the reference reports per file (4 x complete records).  -Q > 0 and dist -A stay on the host tokeniser.
+ */
+int kssd_gpu_tokenise_fastq_device(kssd_gpu_ctx *ctx, const uint8_t *d_text, const uint64_t *h_text_off, const uint64_t *h_text_len,
+                                   uint32_t n_files, uint32_t *d_packed, uint32_t *d_mask, const uint64_t *h_chunk_off, void *stream);
+int kssd_gpu_tokenise_fastq_status(kssd_gpu_ctx *ctx, int64_t *bad_file, uint64_t *h_positions, uint64_t *h_lines, void *stream);
+int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
+                               uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                               uint32_t **out_pos, uint64_t *h_lines, int64_t *bad_genome);
+
 
 /*
  * Page-locked host memory (hipHostMalloc): a batch tokenised into it (kssd_batch_create_ex of the host library takes

@@ -41,7 +41,8 @@ GPU_SYMBOLS = [
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
     "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
-    "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text", "kssd_gpu_concat_units_device",
+    "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
+    "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text", "kssd_gpu_concat_units_device",
     "kssd_gpu_index_set_filter",
 ]
 
@@ -126,6 +127,10 @@ def gpu_lib():
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
+        L.kssd_gpu_tokenise_fastq_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
+        L.kssd_gpu_tokenise_fastq_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp, vp]
+        L.kssd_gpu_sketch_fastq_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp,
+                                                 C.POINTER(C.c_int64)]
         L.kssd_gpu_concat_units_device.argtypes = [vp, vp, vp, u32, u32, u64, vp, vp, vp]
         L.kssd_gpu_index_set_filter.argtypes = [vp, i32, u32, u32]
         L.kssd_gpu_sketch_fasta_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
@@ -603,13 +608,24 @@ class GpuCtx:
             buf[int(offs[i]):int(offs[i]) + len(t)] = np.frombuffer(bytes(t), dtype=np.uint8)
         return buf, offs, lens
 
-    def sketch_fasta_texts(self, texts, flags=SKETCH_FASTA, min_occ=1, with_pos=False):
+    def sketch_fastq_texts(self, texts, flags=SKETCH_FASTA, min_occ=1, with_pos=False):
+        """FASTQ texts (-Q 0) tokenised ON THE DEVICE and sketched: (off, ids[, pos], lines per text).  KssdError with
+        code KSSD_ERR_UNSUPPORTED and .bad_genome when a text needs the host tokeniser."""
+        return self.sketch_fasta_texts(texts, flags, min_occ, with_pos, _fastq=True)
+
+    def sketch_fasta_texts(self, texts, flags=SKETCH_FASTA, min_occ=1, with_pos=False, _fastq=False):
         """FASTA texts tokenised ON THE DEVICE and sketched: (off, ids[, pos]); one genome per text"""
         buf, offs, lens = self._text_layout(texts)
         n = len(texts)
         po, pi, pp, bad = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(-1)
-        rc = gpu_lib().kssd_gpu_sketch_fasta_text(self.h, buf.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, flags, min_occ,
-                                                  C.byref(po), C.byref(pi), C.byref(pp) if with_pos else None, C.byref(bad))
+        lines = np.zeros(max(n, 1), dtype=np.uint64)
+        if _fastq:
+            rc = gpu_lib().kssd_gpu_sketch_fastq_text(self.h, buf.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, flags, min_occ,
+                                                      C.byref(po), C.byref(pi), C.byref(pp) if with_pos else None, lines.ctypes.data,
+                                                      C.byref(bad))
+        else:
+            rc = gpu_lib().kssd_gpu_sketch_fasta_text(self.h, buf.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, flags, min_occ,
+                                                      C.byref(po), C.byref(pi), C.byref(pp) if with_pos else None, C.byref(bad))
         if rc != 0:
             e = KssdError(rc, gpu_lib().kssd_gpu_strerror(rc).decode())
             e.bad_genome = bad.value
@@ -625,19 +641,28 @@ class GpuCtx:
             for q in (po, pi, pp):
                 if q.value:
                     gpu_lib().kssd_gpu_free(q)
-        return (off, ids, pos) if with_pos else (off, ids)
+        res = (off, ids, pos) if with_pos else (off, ids)
+        return res + (lines[:n],) if _fastq else res
 
-    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None):
-        """device-level: raw FASTA bytes in HBM -> packed batch in HBM; returns (rc, bad_file, positions per file)"""
+    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None, fastq=False):
+        """device-level: raw FASTA (or FASTQ) bytes in HBM -> packed batch in HBM; returns (rc, bad_file, positions per
+        file[, lines per file])"""
         to = np.ascontiguousarray(text_off, dtype=np.uint64)
         tl = np.ascontiguousarray(text_len, dtype=np.uint64)
         co = np.ascontiguousarray(chunk_off, dtype=np.uint64)
-        _gck(gpu_lib().kssd_gpu_tokenise_fasta_device(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed),
-                                                      _ptr(d_mask), co.ctypes.data, stream))
+        fn = gpu_lib().kssd_gpu_tokenise_fastq_device if fastq else gpu_lib().kssd_gpu_tokenise_fasta_device
+        _gck(fn(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed), _ptr(d_mask), co.ctypes.data, stream))
         bad = C.c_int64(-1)
         npos = np.zeros(max(len(tl), 1), dtype=np.uint64)
+        if fastq:
+            nlines = np.zeros(max(len(tl), 1), dtype=np.uint64)
+            rc = gpu_lib().kssd_gpu_tokenise_fastq_status(self.h, C.byref(bad), npos.ctypes.data, nlines.ctypes.data, stream)
+            return rc, bad.value, npos[:len(tl)], nlines[:len(tl)]
         rc = gpu_lib().kssd_gpu_tokenise_status(self.h, C.byref(bad), npos.ctypes.data, stream)
         return rc, bad.value, npos[:len(tl)]
+
+    def tokenise_fastq_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None):
+        return self.tokenise_fasta_device(d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream, fastq=True)
 
     def dist(self, roff, rids, qoff, qids, planes=True):
         """shared uint32[Q,R] (+ J, MashD, C, AafD float64[Q,R] when planes)"""

@@ -145,6 +145,7 @@ struct kssd_gpu_ctx {
     uint8_t *d_tok_state, *d_text;
     size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text;
     uint32_t tok_files;
+    bool tok_fastq = false;
     std::vector<unsigned long long> h_tok_tab;
     uint32_t *d_filt;       // negative filter of the index (kssd_gpu_index_set_filter): one word per four slots
     size_t cap_filt;
@@ -1778,7 +1779,8 @@ extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float
 
 // host-level: FASTA texts (HOST bytes, ideally page-locked) in, sketches out -- text to the device, tokenised there
 static int sketch_text_impl(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len, uint32_t n_files,
-                            uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome)
+                            uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome,
+                            bool fq, uint64_t *h_lines)
 {
     if (!c || !out_off || !out_ids || (n_files && (!text || !text_off || !text_len))) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
@@ -1799,9 +1801,9 @@ static int sketch_text_impl(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t
     if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, (size_t)n_chunks * KSSD_CHUNK_WORDS + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, (size_t)n_chunks * KSSD_CHUNK_MASKW + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
     if (text_end) HIPCK(hipMemcpyAsync(c->d_text, text, (size_t)text_end, hipMemcpyHostToDevice, s));
-    rc = kssd_gpu_tokenise_fasta_device(c, c->d_text, text_off, text_len, n_files, c->d_in_packed, c->d_in_mask, chunk_off.data(), s);
+    rc = tokenise_device_impl(c, c->d_text, text_off, text_len, n_files, c->d_in_packed, c->d_in_mask, chunk_off.data(), s, fq);
     if (rc != KSSD_OK) return rc;
-    rc = kssd_gpu_tokenise_status(c, bad_genome, nullptr, s);
+    rc = tokenise_status_impl(c, bad_genome, nullptr, fq ? h_lines : nullptr, s);
     if (rc != KSSD_OK) return rc;
     return sketch_resident_impl(c, chunk_off.data(), n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
 }
@@ -1810,7 +1812,17 @@ extern "C" int kssd_gpu_sketch_fasta_text(kssd_gpu_ctx *c, const uint8_t *text, 
                                           uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                                           uint32_t **out_pos, int64_t *bad_genome)
 {
-    return sketch_text_impl(c, text, text_off, text_len, n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
+    return sketch_text_impl(c, text, text_off, text_len, n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome, false, nullptr);
+}
+
+// The same for FASTQ read sets, one per input (fastq2co with -Q 0).  h_lines (nullable, n_files entries) receives the
+// line count the reference reports per file.  KSSD_ERR_UNSUPPORTED with the input's index in bad_genome when an input needs
+// the host tokeniser (see kssd_gpu_tokenise_fastq_device); nothing has been sketched then.
+extern "C" int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
+                                          uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                                          uint32_t **out_pos, uint64_t *h_lines, int64_t *bad_genome)
+{
+    return sketch_text_impl(c, text, text_off, text_len, n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome, true, h_lines);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -255,15 +255,16 @@ static void load_shuf(const dist_opt *o, kssd_shuf *s)
 
 /* One unit of stage-I work: a run of consecutive input files of one kind (FASTA or FASTQ), tokenised into one packed
  * batch in page-locked memory; a device worker sketches it and leaves the genomes' ids in the reference's file order. */
-typedef struct textbuf { /* FASTA bytes of a job in page-locked memory, every file on a 16-byte boundary */
+typedef struct textbuf { /* the raw bytes of a job's files in page-locked memory, every file on a 16-byte boundary */
     unsigned char *p;
     size_t cap;
 } textbuf;
 
 typedef struct job {
-    kssd_batch *b;      /* FASTQ / -A: tokenised on the host */
-    textbuf *tx;        /* FASTA: the raw bytes, tokenised on the device (kssd_gpu_sketch_fasta_text) */
-    uint64_t *toff, *tlen;
+    kssd_batch *b;      /* FASTQ with -Q > 0, -A: tokenised on the host */
+    textbuf *tx;        /* FASTA, FASTQ with -Q 0: the raw bytes, tokenised on the device (kssd_gpu_sketch_fast[aq]_text) */
+    kssd_batch *own_b;  /* a text job the device handed back: the host tokeniser's batch of it */
+    uint64_t *toff, *tlen, *lines;
     int is_fq, first_file, n_files;
     uint64_t *off;    /* n_files + 1 */
     uint32_t *ids;    /* slot order per genome */
@@ -279,8 +280,12 @@ typedef struct job {
 static int job_sketch(kssd_gpu_ctx *ctx, const job *j, uint32_t flags, uint32_t min_occ, uint64_t **off, uint32_t **ids, uint32_t **pos,
                       int64_t *bad)
 {
-    if (j->tx) return kssd_gpu_sketch_fasta_text(ctx, j->tx->p, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, bad);
-    kssd_batch *b = j->b;
+    if (j->tx && !j->own_b) {
+        if (j->is_fq)
+            return kssd_gpu_sketch_fastq_text(ctx, j->tx->p, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, j->lines, bad);
+        return kssd_gpu_sketch_fasta_text(ctx, j->tx->p, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, bad);
+    }
+    kssd_batch *b = j->own_b ? j->own_b : j->b;
     if (pos) return kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), kssd_batch_n_genomes(b),
                                               flags, min_occ, off, ids, pos, bad);
     return kssd_gpu_sketch_batch(ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), kssd_batch_n_genomes(b), flags,
@@ -319,6 +324,27 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
         min_occ = 1;
     }
     int rc = job_sketch(ctx, j, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
+    if (rc == KSSD_ERR_UNSUPPORTED && j->tx && is_fq) {
+        /* an input the device tokeniser does not do exactly as fastq2co (no complete record, a line its fgets() buffer
+         * splits, NUL or 8-bit bytes): the whole job through the host tokeniser */
+        j->own_b = kssd_batch_create();
+        uint64_t *maxpos = malloc((size_t)n * sizeof *maxpos);
+        if (!j->own_b || !maxpos) die(ENOMEM, "out of memory");
+        for (uint32_t g = 0; g < n; g++) maxpos[g] = j->tlen[g];
+        uint32_t first = 0;
+        if (kssd_batch_reserve(j->own_b, n, maxpos, &first)) die(ENOMEM, "out of memory");
+        free(maxpos);
+        int trc = 0;
+#pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 1) reduction(| : trc)
+        for (uint32_t g = 0; g < n; g++) {
+            const int r = kssd_batch_fill_text(j->own_b, first + g, 1, j->tx->p + j->toff[g], j->tlen[g], 0, &j->lines[g]);
+            if (r && r != KSSD_HOST_ERR_EMPTY) trc |= 1;
+        }
+        if (trc) die(EIO, "%s ...: the host tokeniser failed", fl->path[first_file]);
+        rc = job_sketch(ctx, j, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
+    }
+    if (j->tx && is_fq)
+        for (uint32_t g = 0; g < n; g++) printf("%llu reads detected\n", (unsigned long long)j->lines[g]);
     if (rc == KSSD_ERR_INPUT) /* the host tokeniser's KSSD_HOST_ERR_HEADER (iseq2comem.c:233) */
         die(EIO, "%s: %s", fl->path[first_file + (bad >= 0 ? bad : 0)], kssd_host_strerror(KSSD_HOST_ERR_HEADER));
     if (rc == KSSD_ERR_CAPACITY)
@@ -442,6 +468,10 @@ static void *worker_main(void *arg)
         process_job(ctx, j, pl->o, pl->fl, pl->hashsize, &tcall);
         const double dt = now_s() - t0;
         if (j->b) kssd_batch_clear(j->b);
+        if (j->own_b) kssd_batch_destroy(j->own_b);
+        j->own_b = NULL;
+        free(j->lines);
+        j->lines = NULL;
         pthread_mutex_lock(&pl->mu);
         if (j->b) pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
         if (j->tx) pl->tpool[pl->n_tpool++] = j->tx;
@@ -589,12 +619,14 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     size_t *len = calloc((size_t)threads, sizeof *len);
     int *trc = calloc((size_t)threads, sizeof *trc);
     uint64_t *lines = calloc((size_t)threads, sizeof *lines);
-    int *direct = calloc((size_t)threads, sizeof *direct); /* plain FASTA file: read straight into the job's text buffer */
+    int *direct = calloc((size_t)threads, sizeof *direct); /* plain file for the device tokeniser: read straight into the job's text buffer */
+    /* fastq2co's quality rule (-Q > 0) and the read framing of -A stay with the host tokeniser */
+    const int fq_dev = !o->abundance && o->kmerqlty == 0 && !getenv("KSSD_HOST_FASTQ");
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
         const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
         double t0 = now_s();
-        /* read + gunzip, one file each.  FASTQ files and gzip'ed files go into the wave's scratch buffers; a plain FASTA
-         * file is only measured here and read straight into page-locked memory below */
+        /* read + gunzip, one file each.  gzip'ed files (and FASTQ files the host tokenises) go into the wave's scratch
+         * buffers; a plain file the device tokenises is only measured here and read straight into page-locked memory below */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
         for (int i = 0; i < nw; i++) {
             const char *path = fl->path[i0 + i];
@@ -603,7 +635,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             direct[i] = 0;
             trc[i] = kssd_file_probe(path, &gz, &sz);
             if (trc[i]) continue;
-            if (!gz && !has_fmt(path, fq_fmt)) {
+            if (!gz && (fq_dev || !has_fmt(path, fq_fmt))) {
                 direct[i] = 1;
                 len[i] = (size_t)sz;
             } else {
@@ -628,8 +660,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             j->is_fq = fq;
             j->first_file = i0 + r0;
             j->n_files = r1 - r0;
-            if (!fq) {
-                /* FASTA: the raw bytes go to the device, which tokenises them (csrc/kssd_tok.inc) */
+            if (!fq || fq_dev) {
+                /* FASTA, FASTQ with -Q 0: the raw bytes go to the device, which tokenises them (csrc/kssd_tok.inc) */
+                if (fq) j->lines = calloc((size_t)(r1 - r0) + 1, sizeof(uint64_t));
                 j->toff = calloc((size_t)(r1 - r0) + 1, sizeof(uint64_t));
                 j->tlen = calloc((size_t)(r1 - r0) + 1, sizeof(uint64_t));
                 uint64_t at = 0;

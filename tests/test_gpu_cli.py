@@ -18,8 +18,9 @@ META = json.load(open(os.path.join(G, "golden.json")))
 SK = np.load(os.path.join(G, "sketches.npz"))
 
 
-def run(args, cwd):
-    r = subprocess.run([BIN] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+def run(args, cwd, env=None):
+    r = subprocess.run([BIN] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stdout.decode()
     return r.stdout.decode()
 
@@ -187,3 +188,32 @@ def test_file_order_of_uniq_and_min_occ_modes(tmp_path):
     run(["dist", "-n", 2, "-L", "s.shuf", "-o", "n2", "reads.fastq"], d)
     want = sk.fastq(fq, Q=0, M=2)
     assert np.array_equal(np.fromfile(os.path.join(d, "n2", "combco.0"), np.uint32), want)
+
+
+def test_fastq_inputs_the_device_tokeniser_hands_back(tmp_path):
+    """plain .fastq files go to the device as raw bytes (csrc/kssd_tok.inc); a file it cannot do exactly as fastq2co (here:
+    a truncated first record, a line the reference's 20 000-byte buffer splits) sends its batch through the host
+    tokeniser -- either way combco.0 is the oracle's, and KSSD_HOST_FASTQ=1 (host tokeniser for everything) agrees"""
+    from test_gpu_tokenise import _fastq_cases
+    d = str(tmp_path)
+    rng = np.random.default_rng(4)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    long_line = bytes(acgt[rng.integers(0, 4, 30_000, dtype=np.uint8)])
+    files = {"a.fastq": _fastq_cases()[1], "b.fastq": _fastq_cases()[0],
+             "long.fastq": b"@r\n" + long_line + b"\n+\n" + b"I" * 30_000 + b"\n" + _fastq_cases()[9],
+             "open.fq": b"@r\n" + long_line[:5000]}
+    for name, text in files.items():
+        open(os.path.join(d, name), "wb").write(text)
+    shuf = K.Shuf.generate(10, 6, 3, seed=11)
+    shuf.write(os.path.join(d, "s.shuf"))
+    sk = ko.Sketcher(shuf.table, 10, 6, 3)
+    names = sorted(files)
+    out = run(["dist", "-L", "s.shuf", "-o", "dev"] + names, d)
+    assert "reads detected" in out
+    run(["dist", "-L", "s.shuf", "-o", "host"] + names, d, env={"KSSD_HOST_FASTQ": "1"})
+    _, nm_d, off_d, ids_d = ko.read_sketch_dir(os.path.join(d, "dev"))
+    _, nm_h, off_h, ids_h = ko.read_sketch_dir(os.path.join(d, "host"))
+    assert list(nm_d) == list(nm_h) and len(nm_d) == len(files)
+    assert np.array_equal(off_d, off_h) and np.array_equal(ids_d, ids_h)
+    for g, name in enumerate(nm_d):     # the reference's file order, genome by genome
+        assert np.array_equal(ids_d[int(off_d[g]):int(off_d[g + 1])], sk.fastq(files[os.path.basename(name)], Q=0, M=1)), name

@@ -93,3 +93,100 @@ def test_sketches_of_device_tokenised_text_equal_the_oracle(shuf_l3k10):
         assert np.array_equal(K.slot_order_pos(ids2[lo:hi], pos2[lo:hi], sk.p.hashsize), sk.fasta(texts[g]))
     finally:
         ctx.close()
+
+
+# ---- FASTQ (fastq2co with -Q 0) ----------------------------------------------------------------------------------------
+
+def _fastq_cases():
+    from synth import fastq_records
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def rnd(n):
+        return bytes(acgt[rng.integers(0, 4, n, dtype=np.uint8)])
+
+    def rec(seq, name=b"@r", plus=b"+", qual=None, eol=b"\n"):
+        return name + eol + seq + eol + plus + eol + (b"I" * len(seq) if qual is None else qual) + eol
+    reads = rng.integers(0, 4, (20_000, 150), dtype=np.uint8)
+    long_reads = b"".join(rec(rnd(int(n))) for n in rng.integers(1, 12_000, 60))       # lines that cross tiles
+    return [
+        fastq_records(reads),                                                            # 6.3 MB of equally long reads
+        long_reads,
+        rec(rnd(100)),                                                                   # one record
+        rec(rnd(100)) + rec(rnd(77))[:-1],                                               # the final record lacks its line end: not scanned
+        rec(rnd(100)) + b"@r\n" + rnd(50) + b"\n+\n",                                    # three lines of a second record
+        rec(rnd(100)) + b"@r\n" + rnd(50),                                               # ... two, the second one open
+        rec(rnd(60) + b"N" + rnd(60) + b"nRY-" + rnd(9).lower()) + rec(b"") + rec(b"N" * 40) + rec(rnd(30)),   # breaks, an empty read
+        rec(rnd(90), eol=b"\r\n") + rec(rnd(90), eol=b"\r\n"),                           # CRLF: the \r breaks the run at the line end anyway
+        rec(rnd(80), name=b"@" + b"ACGT" * 2000, plus=b"+" + b"ACGT" * 1500) + rec(rnd(40), qual=b"ACGT" * 10),   # bases in the other lines
+        b"".join(rec(rnd(9)) for _ in range(3000)),                                      # many short records per tile
+        rec(rnd(18_900)) + rec(rnd(4096 - 6)) + rec(rnd(4096)),                          # just under the long-line bound; lines ending on tile edges
+        rec(rnd(100), qual=b"\x01" * 50) + rec(rnd(10), qual=b"!" * 300),                # quality lines of another length
+    ]
+
+
+def _host_fastq(texts):
+    hb = K.Batch()
+    first = hb.reserve([len(t) for t in texts])
+    lines = [hb.fill_text(first + i, t, kind=1, Q=0) if len(t) else 0 for i, t in enumerate(texts)]
+    return hb, first, lines
+
+
+def test_device_fastq_tokeniser_writes_what_the_host_tokeniser_writes(shuf_l3k10):
+    import torch
+    dev = torch.device("cuda", 0)
+    texts = _fastq_cases()
+    hb, first, lines = _host_fastq(texts)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        buf, offs, lens = ctx._text_layout(texts)
+        co = hb.chunk_off()
+        d_text = torch.from_numpy(buf).to(dev)
+        nchunks = int(co[-1])
+        d_packed = torch.full((nchunks * K.CHUNK_WORDS + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        d_mask = torch.full((nchunks * K.CHUNK_MASKW + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        rc, bad, npos, nlines = ctx.tokenise_fastq_device(d_text, offs, lens, d_packed, d_mask, co)
+        assert rc == 0 and bad == -1
+        assert np.array_equal(nlines, np.array(lines, dtype=np.uint64))
+        assert np.array_equal(npos, np.array([hb.n_positions(first + i) for i in range(len(texts))], dtype=np.uint64))
+        gp = d_packed.cpu().numpy().view(np.uint32)
+        gm = d_mask.cpu().numpy().view(np.uint32)
+        assert np.array_equal(gm, hb.mask()[:len(gm)])
+        assert np.array_equal(gp, hb.packed()[:len(gp)])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("text", [
+    b"",                                                        # nothing
+    b"@r\nACGTACGTACGTACGTACGTACGT",                            # no complete record (the reference scans what it has)
+    b"@ACGTACGTACGTACGTACGTACGTACGT",                           # ... not even a line end
+    b"@r\nACGTACGTACGTACGTACGTACGT\n+\nIIII",                   # ... three line ends
+    b"@r\n" + b"ACGT" * 5000 + b"\n+\n" + b"I" * 20000 + b"\n",  # lines the reference's buffer splits
+    b"@r\nACGTACGTACGTAC\x00GTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIII\n",   # NUL ends the reference's strlen()
+    b"@r\nACGTACGTACGTACGTACGT\n+\nIIIIIIIII\xc3IIIIIIIIII\n",    # a negative quality
+    b"@r\nACGT\n+\nIIII\n" + b"x" * 19_500,                     # a long tail without line end
+])
+def test_device_fastq_tokeniser_hands_back_what_only_the_host_does_exactly(shuf_l3k10, text):
+    good = b"@r\nACGTTGCAACGTTGCAACGTTGCAAACCGGTT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        with pytest.raises(K.KssdError) as e:
+            ctx.sketch_fastq_texts([good, good, text, b""])
+        assert e.value.code == K.capi.ERR_UNSUPPORTED and e.value.bad_genome == 2
+        off, ids, lines = ctx.sketch_fastq_texts([good, good])
+        assert list(lines) == [4, 4]
+    finally:
+        ctx.close()
+
+
+def test_sketches_of_device_tokenised_fastq_equal_the_oracle(shuf_l3k10):
+    texts = _fastq_cases()
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        off, ids, lines = ctx.sketch_fastq_texts(texts)
+        sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+        for g, t in enumerate(texts):
+            assert np.array_equal(ids[int(off[g]):int(off[g + 1])], np.sort(sk.fastq(t, Q=0))), g
+    finally:
+        ctx.close()
