@@ -209,6 +209,18 @@ int kssd_gpu_tokenise_fastq_status(kssd_gpu_ctx *ctx, int64_t *bad_file, uint64_
 int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
                                uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                                uint32_t **out_pos, uint64_t *h_lines, int64_t *bad_genome);
+/*
+ * Streaming a long input in without a host buffer of its size: reserve the context's device text buffer once, copy
+ * slices in from page-locked host memory (asynchronous, on the context's own stream; the returned ticket >= 0 tells
+ * kssd_gpu_text_wait which copy to wait for before the slice's memory is refilled -- at most the last eight copies are
+ * tracked one by one), then call kssd_gpu_sketch_fasta_text / _fastq_text with text == NULL: the offsets then address
+ * the device buffer.  (The reference reads a file through a FILE* / zcat pipe line by line, iseq2comem.c:196-330; this is
+ * what replaces that for inputs of many gigabytes.)
+ */
+int kssd_gpu_text_reserve(kssd_gpu_ctx *ctx, uint64_t bytes);
+int64_t kssd_gpu_text_put(kssd_gpu_ctx *ctx, uint64_t dst_off, const void *src, uint64_t n);
+int kssd_gpu_text_wait(kssd_gpu_ctx *ctx, int64_t ticket);
+
 
 
 /*

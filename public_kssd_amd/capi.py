@@ -42,7 +42,8 @@ GPU_SYMBOLS = [
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
     "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
-    "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text", "kssd_gpu_concat_units_device",
+    "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
+    "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
     "kssd_gpu_index_set_filter",
 ]
 
@@ -127,6 +128,10 @@ def gpu_lib():
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
+        L.kssd_gpu_text_reserve.argtypes = [vp, u64]
+        L.kssd_gpu_text_put.argtypes = [vp, u64, vp, u64]
+        L.kssd_gpu_text_put.restype = C.c_int64
+        L.kssd_gpu_text_wait.argtypes = [vp, C.c_int64]
         L.kssd_gpu_tokenise_fastq_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fastq_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp, vp]
         L.kssd_gpu_sketch_fastq_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp,

@@ -140,12 +140,14 @@ struct kssd_gpu_ctx {
     uint32_t *d_bkt;        // per bucket: counters | starts | cursors | descriptors (kssd_dist.inc)
     size_t cap_bkt;
     // device tokeniser (kssd_tok.inc)
-    unsigned long long *d_tok_tab, *d_tok_pos;
+    unsigned long long *d_tok_tab, *d_tok_pos, *d_tok_sup;
     uint32_t *d_tok_sum;
     uint8_t *d_tok_state, *d_text;
-    size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text;
+    size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text, cap_tok_sup;
     uint32_t tok_files;
     bool tok_fastq = false;
+    hipEvent_t text_ev[8];   // kssd_gpu_text_put: the last eight copies
+    uint64_t text_puts;
     std::vector<unsigned long long> h_tok_tab;
     uint32_t *d_filt;       // negative filter of the index (kssd_gpu_index_set_filter): one word per four slots
     size_t cap_filt;
@@ -268,9 +270,11 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    for (hipEvent_t e : c->text_ev)
+        if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     for (int w = 0; w < 2; w++)
         for (int i = 0; i < EV_RING; i++) {
@@ -1782,7 +1786,7 @@ static int sketch_text_impl(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t
                             uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome,
                             bool fq, uint64_t *h_lines)
 {
-    if (!c || !out_off || !out_ids || (n_files && (!text || !text_off || !text_len))) return KSSD_ERR_PARAM;
+    if (!c || !out_off || !out_ids || (n_files && (!text_off || !text_len))) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     *out_off = nullptr;
     *out_ids = nullptr;
@@ -1797,10 +1801,14 @@ static int sketch_text_impl(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t
     }
     const uint64_t n_chunks = chunk_off[n_files];
     int rc;
-    if ((rc = ensure(&c->d_text, &c->cap_text, (size_t)text_end + 64)) != KSSD_OK) return rc;
+    if (text) {
+        if ((rc = ensure(&c->d_text, &c->cap_text, (size_t)text_end + 64)) != KSSD_OK) return rc;
+    } else if (text_end && (!c->d_text || c->cap_text < (size_t)text_end)) {
+        return KSSD_ERR_PARAM;  // text == NULL: the bytes are in the context's buffer already (kssd_gpu_text_put)
+    }
     if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, (size_t)n_chunks * KSSD_CHUNK_WORDS + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, (size_t)n_chunks * KSSD_CHUNK_MASKW + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
-    if (text_end) HIPCK(hipMemcpyAsync(c->d_text, text, (size_t)text_end, hipMemcpyHostToDevice, s));
+    if (text_end && text) HIPCK(hipMemcpyAsync(c->d_text, text, (size_t)text_end, hipMemcpyHostToDevice, s));
     rc = tokenise_device_impl(c, c->d_text, text_off, text_len, n_files, c->d_in_packed, c->d_in_mask, chunk_off.data(), s, fq);
     if (rc != KSSD_OK) return rc;
     rc = tokenise_status_impl(c, bad_genome, nullptr, fq ? h_lines : nullptr, s);
@@ -1823,6 +1831,43 @@ extern "C" int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *c, const uint8_t *text, 
                                           uint32_t **out_pos, uint64_t *h_lines, int64_t *bad_genome)
 {
     return sketch_text_impl(c, text, text_off, text_len, n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome, true, h_lines);
+}
+
+// Streaming a long input in: the context's device text buffer is reserved once, slices are copied in from (page-locked)
+// host memory asynchronously on the context's stream, and kssd_gpu_sketch_fast[aq]_text is called with text == NULL.
+// The host side needs no buffer of the file's size: a few slices that are refilled as soon as their copy has left.
+extern "C" int kssd_gpu_text_reserve(kssd_gpu_ctx *c, uint64_t bytes)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    HIPCK(hipStreamSynchronize(c->own_stream));
+    return ensure(&c->d_text, &c->cap_text, (size_t)bytes + 64);
+}
+
+// returns the copy's ticket (>= 0) for kssd_gpu_text_wait, or an error (< 0)
+extern "C" int64_t kssd_gpu_text_put(kssd_gpu_ctx *c, uint64_t dst_off, const void *src, uint64_t n)
+{
+    if (!c || !src || !c->d_text || dst_off + n > c->cap_text) return KSSD_ERR_PARAM;
+    if (hipSetDevice(c->device) != hipSuccess) return KSSD_ERR_HIP;
+    const uint64_t t = c->text_puts;
+    hipEvent_t &e = c->text_ev[t & 7u];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return KSSD_ERR_HIP;
+    if (n && hipMemcpyAsync(c->d_text + dst_off, src, (size_t)n, hipMemcpyHostToDevice, c->own_stream) != hipSuccess) return KSSD_ERR_HIP;
+    if (hipEventRecord(e, c->own_stream) != hipSuccess) return KSSD_ERR_HIP;
+    c->text_puts = t + 1;
+    return (int64_t)t;
+}
+
+// blocks until the copy with this ticket has read its source (tickets older than the last eight have: the copies of a
+// stream run in order)
+extern "C" int kssd_gpu_text_wait(kssd_gpu_ctx *c, int64_t ticket)
+{
+    if (!c || ticket < 0 || (uint64_t)ticket >= c->text_puts) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    const uint64_t newest = c->text_puts - 1;
+    const uint64_t t = newest - (uint64_t)ticket >= 8 ? newest - 7 : (uint64_t)ticket;  // its slot was reused: wait for the oldest kept
+    HIPCK(hipEventSynchronize(c->text_ev[t & 7u]));
+    return KSSD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

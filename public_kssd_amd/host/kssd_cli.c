@@ -264,6 +264,8 @@ typedef struct job {
     kssd_batch *b;      /* FASTQ with -Q > 0, -A: tokenised on the host */
     textbuf *tx;        /* FASTA, FASTQ with -Q 0: the raw bytes, tokenised on the device (kssd_gpu_sketch_fast[aq]_text) */
     kssd_batch *own_b;  /* a text job the device handed back: the host tokeniser's batch of it */
+    int streamed;       /* one long plain file: the worker streams it into the device's text buffer (stream_file_in) */
+    int uploaded;
     uint64_t *toff, *tlen, *lines;
     int is_fq, first_file, n_files;
     uint64_t *off;    /* n_files + 1 */
@@ -276,14 +278,79 @@ typedef struct job {
  * fight the tokenisers' team for the cores (each pthread has its own OpenMP pool, idle pools spin) */
 #define WORKER_OMP 4
 
-/* the job's genomes through the device: FASTA text is tokenised there, FASTQ batches arrive tokenised; pos may be NULL */
-static int job_sketch(kssd_gpu_ctx *ctx, const job *j, uint32_t flags, uint32_t min_occ, uint64_t **off, uint32_t **ids, uint32_t **pos,
-                      int64_t *bad)
+/* A long plain input is not read into a host buffer of its size: slices of it go through a small ring of page-locked
+ * buffers into the context's device text buffer -- WORKER_OMP slices are read at a time (pread, one thread each) while the
+ * copies of the slices before them run.  What the host holds is STREAM_BUFS x STREAM_SLICE bytes, whatever the file's size. */
+static uint64_t STREAM_MIN = 256ull << 20;  /* files from this size on (KSSD_STREAM_MIN, bytes) */
+static uint64_t STREAM_SLICE = 32ull << 20; /* (KSSD_STREAM_SLICE, bytes; a multiple of 4096) */
+#define STREAM_BUFS 8
+static void stream_env(void)
 {
-    if (j->tx && !j->own_b) {
+    const char *e = getenv("KSSD_STREAM_MIN");
+    if (e) STREAM_MIN = strtoull(e, NULL, 10);
+    e = getenv("KSSD_STREAM_SLICE");
+    if (e && strtoull(e, NULL, 10) >= 4096) STREAM_SLICE = strtoull(e, NULL, 10) / 4096 * 4096;
+}
+typedef struct {
+    unsigned char *buf[STREAM_BUFS];
+} stream_ring;
+
+static uint64_t stream_file_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char *path, uint64_t len)
+{
+    for (int b = 0; b < STREAM_BUFS; b++)
+        if (!ring->buf[b] && !(ring->buf[b] = kssd_gpu_host_alloc(STREAM_SLICE))) die(ENOMEM, "out of page-locked memory");
+    gck(kssd_gpu_text_reserve(ctx, len), "kssd_gpu_text_reserve");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) die(EIO, "%s: %s", path, kssd_host_strerror(KSSD_HOST_ERR_IO));
+    const uint64_t n_slices = (len + STREAM_SLICE - 1) / STREAM_SLICE;
+    int64_t ticket[STREAM_BUFS];
+    uint64_t got[STREAM_BUFS], total = 0;
+    for (int b = 0; b < STREAM_BUFS; b++) ticket[b] = -1;
+    int short_read = 0;
+    for (uint64_t g0 = 0; g0 < n_slices && !short_read; g0 += WORKER_OMP) {
+        const uint64_t g1 = g0 + WORKER_OMP < n_slices ? g0 + WORKER_OMP : n_slices;
+        for (uint64_t k = g0; k < g1; k++) /* the copies that last read these buffers (two groups ago) */
+            if (ticket[k % STREAM_BUFS] >= 0) gck(kssd_gpu_text_wait(ctx, ticket[k % STREAM_BUFS]), "kssd_gpu_text_wait");
+        int io_err = 0;
+#pragma omp parallel for num_threads(WORKER_OMP) schedule(static, 1) reduction(| : io_err)
+        for (uint64_t k = g0; k < g1; k++) {
+            const uint64_t at = k * STREAM_SLICE, want = at + STREAM_SLICE <= len ? STREAM_SLICE : len - at;
+            uint64_t n = 0;
+            while (n < want) {
+                const ssize_t r = pread(fd, ring->buf[k % STREAM_BUFS] + n, (size_t)(want - n), (off_t)(at + n));
+                if (r < 0) { io_err |= 1; break; }
+                if (r == 0) break;
+                n += (uint64_t)r;
+            }
+            got[k % STREAM_BUFS] = n;
+        }
+        if (io_err) die(EIO, "%s: %s", path, kssd_host_strerror(KSSD_HOST_ERR_IO));
+        for (uint64_t k = g0; k < g1 && !short_read; k++) {
+            const int b = (int)(k % STREAM_BUFS);
+            const int64_t t = kssd_gpu_text_put(ctx, k * STREAM_SLICE, ring->buf[b], got[b]);
+            if (t < 0) gck((int)t, "kssd_gpu_text_put");
+            ticket[b] = t;
+            total += got[b];
+            if (k * STREAM_SLICE + got[b] < (k + 1 < n_slices ? (k + 1) * STREAM_SLICE : len)) short_read = 1; /* (a file that shrank meanwhile) */
+        }
+    }
+    close(fd);
+    return total;
+}
+
+/* the job's genomes through the device: FASTA text is tokenised there, FASTQ batches arrive tokenised; pos may be NULL */
+static int job_sketch(kssd_gpu_ctx *ctx, job *j, stream_ring *ring, const filelist *fl, uint32_t flags, uint32_t min_occ, uint64_t **off,
+                      uint32_t **ids, uint32_t **pos, int64_t *bad)
+{
+    if ((j->tx || j->streamed) && !j->own_b) {
+        const unsigned char *text = j->tx ? j->tx->p : NULL; /* NULL: already in the context's device buffer */
+        if (j->streamed && !j->uploaded) {
+            j->tlen[0] = stream_file_in(ctx, ring, fl->path[j->first_file], j->tlen[0]);
+            j->uploaded = 1;
+        }
         if (j->is_fq)
-            return kssd_gpu_sketch_fastq_text(ctx, j->tx->p, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, j->lines, bad);
-        return kssd_gpu_sketch_fasta_text(ctx, j->tx->p, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, bad);
+            return kssd_gpu_sketch_fastq_text(ctx, text, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, j->lines, bad);
+        return kssd_gpu_sketch_fasta_text(ctx, text, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, bad);
     }
     kssd_batch *b = j->own_b ? j->own_b : j->b;
     if (pos) return kssd_gpu_sketch_batch_pos(ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), kssd_batch_n_genomes(b),
@@ -292,7 +359,7 @@ static int job_sketch(kssd_gpu_ctx *ctx, const job *j, uint32_t flags, uint32_t 
                                  min_occ, off, ids, bad);
 }
 
-static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, double *t_call)
+static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, double *t_call)
 {
     const double tc0 = now_s();
     const int is_fq = j->is_fq;
@@ -310,7 +377,7 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     /* first positions (for the reference's exact file order) need genomes below 2^32 positions */
     int with_pos = 1;
     for (uint32_t g = 0; g < n; g++) {
-        const uint64_t chunks = j->tx ? (j->tlen[g] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES
+        const uint64_t chunks = (j->tx || j->streamed) ? (j->tlen[g] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES
                                       : kssd_batch_chunk_off(j->b)[g + 1] - kssd_batch_chunk_off(j->b)[g];
         if (chunks >= (1ull << 20)) with_pos = 0;
     }
@@ -323,8 +390,8 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
         flags &= ~KSSD_SKETCH_UNIQ;
         min_occ = 1;
     }
-    int rc = job_sketch(ctx, j, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
-    if (rc == KSSD_ERR_UNSUPPORTED && j->tx && is_fq) {
+    int rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
+    if (rc == KSSD_ERR_UNSUPPORTED && (j->tx || j->streamed) && is_fq) {
         /* an input the device tokeniser does not do exactly as fastq2co (no complete record, a line its fgets() buffer
          * splits, NUL or 8-bit bytes): the whole job through the host tokeniser */
         j->own_b = kssd_batch_create();
@@ -335,15 +402,24 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
         if (kssd_batch_reserve(j->own_b, n, maxpos, &first)) die(ENOMEM, "out of memory");
         free(maxpos);
         int trc = 0;
+        if (j->streamed) { /* (the bytes are on the device only) */
+            unsigned char *txt = NULL;
+            size_t cap = 0, len = 0;
+            trc = kssd_slurp_reuse(fl->path[first_file], &txt, &cap, &len);
+            if (!trc) trc = kssd_batch_fill_text(j->own_b, first, 1, txt, len, 0, &j->lines[0]);
+            if (trc == KSSD_HOST_ERR_EMPTY) trc = 0;
+            free(txt);
+        } else {
 #pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 1) reduction(| : trc)
-        for (uint32_t g = 0; g < n; g++) {
-            const int r = kssd_batch_fill_text(j->own_b, first + g, 1, j->tx->p + j->toff[g], j->tlen[g], 0, &j->lines[g]);
-            if (r && r != KSSD_HOST_ERR_EMPTY) trc |= 1;
+            for (uint32_t g = 0; g < n; g++) {
+                const int r = kssd_batch_fill_text(j->own_b, first + g, 1, j->tx->p + j->toff[g], j->tlen[g], 0, &j->lines[g]);
+                if (r && r != KSSD_HOST_ERR_EMPTY) trc |= 1;
+            }
         }
         if (trc) die(EIO, "%s ...: the host tokeniser failed", fl->path[first_file]);
-        rc = job_sketch(ctx, j, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
+        rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
     }
-    if (j->tx && is_fq)
+    if ((j->tx || j->streamed) && is_fq)
         for (uint32_t g = 0; g < n; g++) printf("%llu reads detected\n", (unsigned long long)j->lines[g]);
     if (rc == KSSD_ERR_INPUT) /* the host tokeniser's KSSD_HOST_ERR_HEADER (iseq2comem.c:233) */
         die(EIO, "%s: %s", fl->path[first_file + (bad >= 0 ? bad : 0)], kssd_host_strerror(KSSD_HOST_ERR_HEADER));
@@ -353,7 +429,7 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     if (replay_all) {
         uint64_t *coff = NULL;
         uint32_t *cids = NULL, *ccnt = NULL;
-        gck(job_sketch(ctx, j, flags | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &coff, &cids, &ccnt, &bad), "sketch (occurrences)");
+        gck(job_sketch(ctx, j, ring, fl, flags | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &coff, &cids, &ccnt, &bad), "sketch (occurrences)");
         if (coff[n] != off[n]) die(EIO, "sketch (occurrences): %llu ids against %llu", (unsigned long long)coff[n], (unsigned long long)off[n]);
         uint64_t *koff = calloc((size_t)n + 1, sizeof *koff);
         if (!koff) die(ENOMEM, "out of memory");
@@ -386,7 +462,7 @@ static void process_job(kssd_gpu_ctx *ctx, job *j, const dist_opt *o, filelist *
     uint64_t *aoff = NULL;
     uint32_t *aids = NULL, *acnt = NULL;
     if (o->abundance) {
-        gck(job_sketch(ctx, j, KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &aoff, &aids, &acnt, &bad),
+        gck(job_sketch(ctx, j, ring, fl, KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &aoff, &aids, &acnt, &bad),
             "sketch (abundances)");
         if (aoff[n] != off[n]) die(EIO, "sketch (abundances): %llu ids against %llu", (unsigned long long)aoff[n], (unsigned long long)off[n]);
     }
@@ -453,6 +529,7 @@ static void *worker_main(void *arg)
     pipeline *pl = w->pl;
     kssd_gpu_ctx *ctx = NULL;
     gck(kssd_gpu_create(&ctx, &pl->hdr, pl->table, w->device), "kssd_gpu_create");
+    stream_ring ring = {{0}};
     for (;;) {
         pthread_mutex_lock(&pl->mu);
         while (!pl->todo_head && !pl->closed) pthread_cond_wait(&pl->cv, &pl->mu);
@@ -465,7 +542,7 @@ static void *worker_main(void *arg)
         if (!j) break;
         const double t0 = now_s();
         double tcall = 0;
-        process_job(ctx, j, pl->o, pl->fl, pl->hashsize, &tcall);
+        process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, &tcall);
         const double dt = now_s() - t0;
         if (j->b) kssd_batch_clear(j->b);
         if (j->own_b) kssd_batch_destroy(j->own_b);
@@ -487,6 +564,8 @@ static void *worker_main(void *arg)
         pthread_cond_broadcast(&pl->cv);
         pthread_mutex_unlock(&pl->mu);
     }
+    for (int b = 0; b < STREAM_BUFS; b++)
+        if (ring.buf[b]) kssd_gpu_host_free(ring.buf[b]);
     kssd_gpu_destroy(ctx);
     return NULL;
 }
@@ -622,6 +701,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     int *direct = calloc((size_t)threads, sizeof *direct); /* plain file for the device tokeniser: read straight into the job's text buffer */
     /* fastq2co's quality rule (-Q > 0) and the read framing of -A stay with the host tokeniser */
     const int fq_dev = !o->abundance && o->kmerqlty == 0 && !getenv("KSSD_HOST_FASTQ");
+    stream_env();
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
         const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
         double t0 = now_s();
@@ -650,8 +730,10 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             const int fq = has_fmt(fl->path[i0 + r0], fq_fmt);
             uint64_t chunks = 0;
             int r1 = r0;
+            const int stream0 = direct[r0] && len[r0] >= STREAM_MIN; /* a long plain file is a job of its own */
             while (r1 < nw && has_fmt(fl->path[i0 + r1], fq_fmt) == fq) {
                 const uint64_t c = (len[r1] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES;
+                if (r1 > r0 && (stream0 || (direct[r1] && len[r1] >= STREAM_MIN))) break;
                 if (r1 > r0 && chunks + c > max_chunks) break;
                 chunks += c;
                 r1++;
@@ -670,6 +752,12 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     j->toff[i - r0] = at;
                     j->tlen[i - r0] = len[i];
                     at += (len[i] + 15) / 16 * 16;
+                }
+                if (stream0) { /* the worker reads it, slice by slice, on its way to the device */
+                    j->streamed = 1;
+                    n_bytes += len[r0];
+                    printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + r0]);
+                    goto queue_job;
                 }
                 pthread_mutex_lock(&pl.mu);
                 while (pl.n_tpool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
@@ -726,6 +814,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                 }
                 j->b = b;
             }
+        queue_job:
             pthread_mutex_lock(&pl.mu);
             if (pl.todo_tail) pl.todo_tail->next = j;
             else pl.todo_head = j;

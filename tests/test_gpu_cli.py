@@ -217,3 +217,30 @@ def test_fastq_inputs_the_device_tokeniser_hands_back(tmp_path):
     assert np.array_equal(off_d, off_h) and np.array_equal(ids_d, ids_h)
     for g, name in enumerate(nm_d):     # the reference's file order, genome by genome
         assert np.array_equal(ids_d[int(off_d[g]):int(off_d[g + 1])], sk.fastq(files[os.path.basename(name)], Q=0, M=1)), name
+
+
+def test_long_plain_files_are_streamed_to_the_device(tmp_path):
+    """a long plain file is not read into a host buffer of its size: slices of it pass through a ring of eight page-locked
+    buffers (kssd_gpu_text_put) while the worker reads on -- forced here for files of a few megabytes with 64 KiB slices
+    (the ring wraps a dozen times), FASTA and FASTQ, next to a batch of ordinary small files; the result is the same
+    directory, byte for byte, as without streaming"""
+    from test_gpu_tokenise import _fastq_cases
+    from synth import fasta_text
+    d = str(tmp_path)
+    rng = np.random.default_rng(9)
+    fq = _fastq_cases()
+    files = {"a_reads.fastq": fq[0], "b_long.fastq": fq[1], "c_small.fastq": fq[2],
+             "open.fq": b"@r\n" + b"ACGT" * 300_000,      # streamed AND handed back to the host tokeniser
+             "g1.fasta": fasta_text(rng.integers(0, 4, 3_000_000, dtype=np.uint8), n_mask=rng.random(3_000_000) < 1e-4),
+             "g2.fasta": fasta_text(rng.integers(0, 4, 40_000, dtype=np.uint8)),
+             "g3.fasta": fasta_text(rng.integers(0, 4, 1_200_001, dtype=np.uint8))}
+    for name, text in files.items():
+        open(os.path.join(d, name), "wb").write(text)
+    K.Shuf.generate(10, 6, 3, seed=11).write(os.path.join(d, "s.shuf"))
+    names = sorted(files)
+    run(["dist", "-L", "s.shuf", "-o", "plain"] + names, d, env={"KSSD_STREAM_MIN": str(1 << 40)})
+    run(["dist", "-L", "s.shuf", "-o", "streamed"] + names, d, env={"KSSD_STREAM_MIN": str(1 << 20), "KSSD_STREAM_SLICE": str(1 << 16)})
+    for fn in ("combco.0", "combco.index.0", "cofiles.stat"):
+        a = open(os.path.join(d, "plain", fn), "rb").read()
+        b = open(os.path.join(d, "streamed", fn), "rb").read()
+        assert a == b and len(a) > 0, fn
