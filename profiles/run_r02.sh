@@ -13,6 +13,10 @@ quick) ( timeout 1200 python -m pytest tests/test_gpu_dist.py tests/test_gpu_cli
 benchq) timeout 600 python bench.py --cpu-sample 0 > gpurun_out/${tag}_benchq.json 2> gpurun_out/${tag}_benchq.err; tail -2 gpurun_out/${tag}_benchq.err; cut -c1-900 gpurun_out/${tag}_benchq.json ;;
 e2e) timeout 900 python bench.py --steps 5 --warmup 1 --spinup 5 > gpurun_out/${tag}_bench_e2e.json 2> gpurun_out/${tag}_bench_e2e.err; tail -2 gpurun_out/${tag}_bench_e2e.err; python3 -c "import json;r=json.load(open('gpurun_out/${tag}_bench_e2e.json'));print(json.dumps(r.get('end_to_end'))[:1500]);print(r.get('cpu_baseline'));print(r.get('cpu_baseline_dist'))" ;;
 tok) ( timeout 1200 python -m pytest tests/test_gpu_tokenise.py tests/test_gpu_cli.py -m gpu -x -q 2>&1 | tail -40 ) > gpurun_out/${tag}_pytest_tok.log; tail -30 gpurun_out/${tag}_pytest_tok.log ;;
+tokprof) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_tokprof -- python3 profiles/tok_probe.py > gpurun_out/${tag}_tokprof.log 2>&1
+    f=$(find gpurun_out/${tag}_tokprof -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_tok_kernel_stats.csv
+    rm -rf gpurun_out/${tag}_tokprof; grep -v "^W\|^E" gpurun_out/${tag}_tokprof.log | tail -4; cat gpurun_out/${tag}_tok_kernel_stats.csv ;;
 smoke) timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
 inflight) timeout 600 python bench.py --inflight 3 --steps 30 --warmup 3 --cpu-sample 0 > gpurun_out/${tag}_bench_inflight3.json 2> gpurun_out/${tag}_bench_inflight3.err; tail -2 gpurun_out/${tag}_bench_inflight3.err; cut -c1-400 gpurun_out/${tag}_bench_inflight3.json ;;
 info) { nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us /sys/fs/cgroup/cpu/cpu.cfs_period_us 2>/dev/null; grep -c processor /proc/cpuinfo; grep "model name" /proc/cpuinfo | head -1; free -g | head -2; python3 -c "import os;print(len(os.sched_getaffinity(0)))"; } 2>&1 | tee gpurun_out/${tag}_info.txt ;;
