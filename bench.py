@@ -459,7 +459,7 @@ def run_fastq(a, shuf, dev):
         assert np.array_equal(tm[:nm].cpu().numpy().view(np.uint32), hb.mask()[:nm]), "device FASTQ tokeniser: mask words != host tokeniser"
         par["device_tokeniser"] = {"text_bytes": len(fq), "ms": min(tok_ms[1:]), "gb_per_s": len(fq) / 1e9 / (min(tok_ms[1:]) * 1e-3),
                                    "host_tokeniser_s_one_thread": t_host_tok,
-                                   "what": "FASTQ text of the slice resident in HBM -> packed batch, 5 kernels, wall time of the call incl. its "
+                                   "what": "FASTQ text of the slice resident in HBM -> packed batch (csrc/kssd_tok.inc, 9 launches), wall time of the call incl. its "
                                            "status read-back; output bit-identical to libkssd_host.so's tokeniser"}
         del d_text, tp, tm
         hb.close()
