@@ -3,7 +3,7 @@
 # ds_read_b64 + byte select, same random batch, time + LDS / VALU counters of the scan kernel
 tag=${1:-ab}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for v in scanbench scanbench_b64; do
+for v in ${AB_VARIANTS:-scanbench scanbench_b64}; do
   echo "== $v"; timeout 120 profiles/$v 400 5000000 10 | grep -i "variant\|ms"
   out=gpurun_out/pmc_${tag}_$v
   timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-include-regex "sketch_scan" --output-format csv -d $out -- profiles/$v 400 5000000 3 > $out.log 2>&1

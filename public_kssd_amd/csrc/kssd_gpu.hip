@@ -516,7 +516,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // prologue: chunk c0 through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
     kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
+#if defined(KSSD_SCAN_PREDB)
+    kssd_grp_issue_pred<SUBK, KSSD_GW>(r0.W, T1, alo & r0.M[0], ahi & r0.M[1], raw);
+#else
     kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of chunk c0 in flight
+#endif
 
     // one chunk.  The four register sets rotate by name (the loop below is unrolled four times): copying one
     // set into another would make every iteration wait for the reads it has just issued.
@@ -591,7 +595,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 n_rounded += 64;
                 cn -= 64;
             }
+#if defined(KSSD_SCAN_PREDB)
+            kssd_grp_issue_pred<SUBK, KSSD_GW>(nxt.W, T1, alo & nxt.M[0], ahi & nxt.M[1], raw);
+#else
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
+#endif
         }
     };
     for (unsigned long long c = c0; c < c1; c += 4) {
