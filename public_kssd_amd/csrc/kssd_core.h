@@ -196,31 +196,21 @@ KSSD_HD void kssd_grp_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[K
 
 // merge the answers of one alignment into the 64-position masks (bit p <=> lane position p may be sampled)
 #if defined(__HIP_DEVICE_COMPILE__)
-// (n << sh) | acc in ONE instruction.  Left to itself the compiler shifts every answer separately and joins pairs with
-// v_or3_b32: 1.5 instructions per table answer instead of 1 (27 answers per 64 positions).
-template <int SH>
-__device__ __forceinline__ uint32_t kssd_shl_or(uint32_t n, uint32_t acc)
+// One v_alignbit_b32 per answer and mask word: the groups of a word are taken in ascending order and each one is pushed in
+// at the TOP -- acc = ({n, acc} >> k)[31:0] puts the low k bits of n into bits 32-k .. 31 and moves what is there down.
+// The k of a word's groups add up to 32, so the first one ends at bit 0.  A group that starts below the word (alignment B's
+// first group starts at position -3, alignment A's group 6 straddles positions 30 .. 34) is pushed in whole: its bits
+// that belong below the word fall off the bottom on the way.  A group that ends above the word gives its low bits only.
+// Why not (n << Q) | acc: a funnel shift reads only the low k <= 5 bits of n, and the compiler knows it -- the table byte
+// needs no zero extension.  With v_lshl_or_b32 it put a v_and_b32 0xff in front of every answer of alignment A (the
+// extension had been moved away from the ds_read_u8 that does it for free), 13 of ~200 instructions per 64 positions.
+template <int W, int Q, int W0>
+__device__ __forceinline__ void kssd_grp_push(uint32_t n, uint32_t &acc)
 {
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(n), "n"(SH), "v"(acc));  // the shift is an inline constant
-    return r;
-}
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__)
-// one group's answer into the masks; Q0 = the lane position of its first window (compile time)
-template <int W, int Q0>
-__device__ __forceinline__ void kssd_grp_merge_one(uint32_t n, uint32_t &lo, uint32_t &hi)
-{
-    constexpr int Q = Q0 < 0 ? 0 : Q0;
-    if (Q0 < 0) n >>= -Q0;
-    if (Q < 32) {
-        if (Q == 0) lo |= n;
-        else lo = kssd_shl_or<(Q > 0 && Q < 32) ? Q : 1>(n, lo);
-        if (Q + W > 32) hi |= n >> (32 - Q);
-    } else {
-        if (Q == 32) hi |= n;
-        else hi = kssd_shl_or<(Q > 32) ? Q - 32 : 1>(n, hi);  // answers for positions >= 64 fall off the top
+    constexpr int p0 = Q > W0 ? Q : W0, p1 = (Q + W < W0 + 32) ? Q + W : W0 + 32, c = p1 - p0;
+    if (c > 0) {
+        constexpr int k = (Q + W > W0 + 32) ? c : W;
+        acc = __builtin_amdgcn_alignbit(n, acc, k > 0 ? k : 1);
     }
 }
 template <int SUBK, int GW, int ALN, int q>
@@ -229,7 +219,9 @@ struct KssdMergeLoop {
     {
         typedef KssdGrp<SUBK, GW> Gp;
         if (q < Gp::count(ALN)) {
-            kssd_grp_merge_one<Gp::W, Gp::first(ALN) + Gp::W * q>(raw[q < Gp::NMAX ? q : 0], lo, hi);
+            constexpr int Q = Gp::first(ALN) + Gp::W * q;
+            kssd_grp_push<Gp::W, Q, 0>(raw[q < Gp::NMAX ? q : 0], lo);
+            kssd_grp_push<Gp::W, Q, 32>(raw[q < Gp::NMAX ? q : 0], hi);
             KssdMergeLoop<SUBK, GW, ALN, (q + 1 < Gp::NMAX ? q + 1 : -1)>::run(raw, lo, hi);
         }
     }

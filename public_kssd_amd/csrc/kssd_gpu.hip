@@ -557,8 +557,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 const uint32_t ebase = ((crel & 2047u) << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
                 // the neighbouring lane's last packed word (v_mov_b32 wave_shr:1; lane 0 keeps the previous chunk's tail)
                 const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s_tail, (int)cur.W[3], 0x138, 0xf, 0xf, false);
-                for (uint64_t hbal = __ballot((cl | ch) != 0); hbal; hbal = __ballot((cl | ch) != 0)) {
+                for (;;) {
+                    // ONE compare per pass, in uniform control flow, feeds the ballot, the loop exit and the branch below
+                    // (a `has` carried around the loop as a bool came back through v_cndmask + v_cmp, three compares per pass)
                     const bool has = (cl | ch) != 0;
+                    const uint64_t hbal = __ballot(has);
+                    if (hbal == 0) break;
                     if (cn + 64 > CBUF) {  // dense parameter sets only: make room
                         wave_lds_sync();
                         const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
