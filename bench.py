@@ -734,6 +734,21 @@ def main():
         torch.cuda.synchronize()
         scan_alone_ms, _ = sl.ctx.kernel_time(0)
 
+    if world > 1:
+        # size-independent check of the WHOLE distributed result, untimed: every rank's block gathered, the global matrix
+        # assembled as shard.py lays it out -- it must be symmetric and carry every rank's sketch sizes on its diagonal
+        # (the foreign rows of a rank are the transposes of other ranks' foreign rows: any rank computing a wrong block shows)
+        blocks = torch.zeros(world * G * R, dtype=torch.int32, device=dev)
+        sizes_all = torch.zeros(world * G, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(blocks, shared)
+        dist.all_gather_into_tensor(sizes_all, (off_l[1:] - off_l[:-1]).to(torch.int32).contiguous())
+        if a.partition == "query":
+            full = blocks.view(world * G, R)                       # rank r wrote rows [r*G, (r+1)*G) x all columns
+        else:
+            full = blocks.view(world, R, G).permute(1, 0, 2).reshape(R, R)   # rank r wrote [all rows] x its G columns
+        assert torch.equal(full.diagonal(), sizes_all), "N > 1: diagonal of the global matrix != the sketch sizes"
+        assert torch.equal(full, full.t()), "N > 1: the global all-pairs matrix is not symmetric"
+        del blocks, full
     if rank == 0:
         # size-independent sanity on this rank's block of the matrix
         szs = (off_l[1:] - off_l[:-1]).to(torch.int32)

@@ -87,10 +87,17 @@ class ShardedSearch:
         self.world, self.rank, self.G, self.cap = world, rank, G, cap
         self.engine, self.partition = engine, partition
         self.gather = SketchGather(world, G, cap, device, engine) if world > 1 else None
-        if world > 1 and partition == "transpose" and hasattr(engine, "index_set_filter"):
+        self._filter = world > 1 and partition == "transpose" and hasattr(engine, "index_set_filter")
+        if self._filter:
             # (world - 1) / world of the query rows are other ranks' sketches and share next to nothing with the own index:
             # a negative filter in front of the table for them, the own block of rows exempt
             engine.index_set_filter(True, rank * G, (rank + 1) * G)
+        # "transpose" on GPUs: the exchange runs on a stream of its own, under the index build and the rank's OWN block of
+        # rows -- neither needs anybody else's sketches; only the foreign rows wait for it
+        self._overlap = world > 1 and partition == "transpose" and torch.device(device).type == "cuda"
+        if self._overlap:
+            self._cstream = torch.cuda.Stream(device=device)
+            self._ev_ready, self._ev_gathered = torch.cuda.Event(), torch.cuda.Event()
 
     def cells(self, Q=None):
         Q = self.G if Q is None else Q
@@ -110,6 +117,17 @@ class ShardedSearch:
         max_ids: upper bound of the ids one rank holds (sizes the index).  tstream: the torch stream object that
         wraps `stream` (the collective is issued under it)."""
         w, G = self.world, self.G
+        if self._overlap:
+            cur = tstream if tstream is not None else torch.cuda.current_stream()
+            self._ev_ready.record(cur)                 # the rank's sketches are complete
+            self._cstream.wait_event(self._ev_ready)
+            with torch.cuda.stream(self._cstream):
+                roff, rids = self.gather(off_l, ids_l, group=group, stream=self._cstream.cuda_stream)
+                self._ev_gathered.record(self._cstream)
+            self._gathered = (roff, rids)
+            self._cur = cur
+            self.engine.index_build_device(off_l, ids_l, G, max_ids, stream)
+            return roff, rids
         if w == 1:
             roff, rids = off_l, ids_l
         elif tstream is not None:
@@ -133,6 +151,21 @@ class ShardedSearch:
         if self.partition == "query":   # own query block as rows
             qoff, qids, Q = (off_l, ids_l, G) if q is None else q
             self.engine.dist_device(qoff, qids, Q, 0, Q, shared, *pl, stream=stream)
+        elif self._overlap:             # own rows from the own sketches first, the foreign rows once the exchange is in
+            r, blk = self.rank, G * G
+            cut = lambda t, a, b: None if t is None else t[a * blk:b * blk]
+            if self._filter:
+                self.engine.index_set_filter(True, 0, G)                     # (the own block: rows 0 .. G of this call)
+            self.engine.dist_device(off_l, ids_l, G, 0, G, cut(shared, r, r + 1), *[cut(t, r, r + 1) for t in pl], stream=stream)
+            if self._filter:
+                self.engine.index_set_filter(True, r * G, (r + 1) * G)
+            self._cur.wait_event(self._ev_gathered)
+            roff, rids = self._gathered
+            if r > 0:
+                self.engine.dist_device(roff, rids, w * G, 0, r * G, cut(shared, 0, r), *[cut(t, 0, r) for t in pl], stream=stream)
+            if r + 1 < w:
+                self.engine.dist_device(roff, rids, w * G, (r + 1) * G, w * G, cut(shared, r + 1, w), *[cut(t, r + 1, w) for t in pl],
+                                        stream=stream)
         else:                           # everybody's sketches as rows: the [w*G] x [G] block = transpose of the own query block
             roff, rids = self._gathered
             self.engine.dist_device(roff, rids, w * G, 0, w * G, shared, *pl, stream=stream)
