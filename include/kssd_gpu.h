@@ -212,7 +212,7 @@ int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uin
 /*
  * Streaming a long input in without a host buffer of its size: reserve the context's device text buffer once, copy
  * slices in from page-locked host memory (asynchronous, on the context's own stream; the returned ticket >= 0 tells
- * kssd_gpu_text_wait which copy to wait for before the slice's memory is refilled -- at most the last eight copies are
+ * kssd_gpu_text_wait which copy to wait for before the slice's memory is refilled -- at most the last 32 copies are
  * tracked one by one), then call kssd_gpu_sketch_fasta_text / _fastq_text with text == NULL: the offsets then address
  * the device buffer.  (The reference reads a file through a FILE* / zcat pipe line by line, iseq2comem.c:196-330; this is
  * what replaces that for inputs of many gigabytes.)

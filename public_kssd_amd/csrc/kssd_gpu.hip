@@ -146,7 +146,7 @@ struct kssd_gpu_ctx {
     size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text, cap_tok_sup;
     uint32_t tok_files;
     bool tok_fastq = false;
-    hipEvent_t text_ev[8];   // kssd_gpu_text_put: the last eight copies
+    hipEvent_t text_ev[32];  // kssd_gpu_text_put: the last 32 copies
     uint64_t text_puts;
     std::vector<unsigned long long> h_tok_tab;
     uint32_t *d_filt;       // negative filter of the index (kssd_gpu_index_set_filter): one word per four slots
@@ -1862,7 +1862,7 @@ extern "C" int64_t kssd_gpu_text_put(kssd_gpu_ctx *c, uint64_t dst_off, const vo
     if (!c || !src || !c->d_text || dst_off + n > c->cap_text) return KSSD_ERR_PARAM;
     if (hipSetDevice(c->device) != hipSuccess) return KSSD_ERR_HIP;
     const uint64_t t = c->text_puts;
-    hipEvent_t &e = c->text_ev[t & 7u];
+    hipEvent_t &e = c->text_ev[t & 31u];
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return KSSD_ERR_HIP;
     if (n && hipMemcpyAsync(c->d_text + dst_off, src, (size_t)n, hipMemcpyHostToDevice, c->own_stream) != hipSuccess) return KSSD_ERR_HIP;
     if (hipEventRecord(e, c->own_stream) != hipSuccess) return KSSD_ERR_HIP;
@@ -1870,15 +1870,15 @@ extern "C" int64_t kssd_gpu_text_put(kssd_gpu_ctx *c, uint64_t dst_off, const vo
     return (int64_t)t;
 }
 
-// blocks until the copy with this ticket has read its source (tickets older than the last eight have: the copies of a
-// stream run in order)
+// blocks until the copy with this ticket has read its source (for a ticket older than the last 32 it waits for the oldest
+// of those: the copies of a stream run in order)
 extern "C" int kssd_gpu_text_wait(kssd_gpu_ctx *c, int64_t ticket)
 {
     if (!c || ticket < 0 || (uint64_t)ticket >= c->text_puts) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     const uint64_t newest = c->text_puts - 1;
-    const uint64_t t = newest - (uint64_t)ticket >= 8 ? newest - 7 : (uint64_t)ticket;  // its slot was reused: wait for the oldest kept
-    HIPCK(hipEventSynchronize(c->text_ev[t & 7u]));
+    const uint64_t t = newest - (uint64_t)ticket >= 32 ? newest - 31 : (uint64_t)ticket;  // its slot was reused: wait for the oldest kept
+    HIPCK(hipEventSynchronize(c->text_ev[t & 31u]));
     return KSSD_OK;
 }
 

@@ -279,11 +279,13 @@ typedef struct job {
 #define WORKER_OMP 4
 
 /* A long plain input is not read into a host buffer of its size: slices of it go through a small ring of page-locked
- * buffers into the context's device text buffer -- WORKER_OMP slices are read at a time (pread, one thread each) while the
- * copies of the slices before them run.  What the host holds is STREAM_BUFS x STREAM_SLICE bytes, whatever the file's size. */
+ * buffers into the context's device text buffer -- STREAM_READERS slices are read at a time (pread, one thread each) while
+ * the copies of the slices before them run.  What the host holds is STREAM_BUFS x STREAM_SLICE bytes (128 MiB), whatever
+ * the file's size; page-locking memory costs ~0.25 s per GB, which is why the ring is small. */
 static uint64_t STREAM_MIN = 256ull << 20;  /* files from this size on (KSSD_STREAM_MIN, bytes) */
-static uint64_t STREAM_SLICE = 32ull << 20; /* (KSSD_STREAM_SLICE, bytes; a multiple of 4096) */
-#define STREAM_BUFS 8
+static uint64_t STREAM_SLICE = 8ull << 20; /* (KSSD_STREAM_SLICE, bytes; a multiple of 4096) */
+#define STREAM_BUFS 16
+#define STREAM_READERS 8 /* slices read at a time, one thread each (the ring holds two such groups) */
 static void stream_env(void)
 {
     const char *e = getenv("KSSD_STREAM_MIN");
@@ -307,12 +309,16 @@ static uint64_t stream_file_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char 
     uint64_t got[STREAM_BUFS], total = 0;
     for (int b = 0; b < STREAM_BUFS; b++) ticket[b] = -1;
     int short_read = 0;
-    for (uint64_t g0 = 0; g0 < n_slices && !short_read; g0 += WORKER_OMP) {
-        const uint64_t g1 = g0 + WORKER_OMP < n_slices ? g0 + WORKER_OMP : n_slices;
+    double t_wait = 0, t_read = 0, t_put = 0;
+    for (uint64_t g0 = 0; g0 < n_slices && !short_read; g0 += STREAM_READERS) {
+        const uint64_t g1 = g0 + STREAM_READERS < n_slices ? g0 + STREAM_READERS : n_slices;
+        double t0 = now_s();
         for (uint64_t k = g0; k < g1; k++) /* the copies that last read these buffers (two groups ago) */
             if (ticket[k % STREAM_BUFS] >= 0) gck(kssd_gpu_text_wait(ctx, ticket[k % STREAM_BUFS]), "kssd_gpu_text_wait");
+        t_wait += now_s() - t0;
+        t0 = now_s();
         int io_err = 0;
-#pragma omp parallel for num_threads(WORKER_OMP) schedule(static, 1) reduction(| : io_err)
+#pragma omp parallel for num_threads(STREAM_READERS) schedule(static, 1) reduction(| : io_err)
         for (uint64_t k = g0; k < g1; k++) {
             const uint64_t at = k * STREAM_SLICE, want = at + STREAM_SLICE <= len ? STREAM_SLICE : len - at;
             uint64_t n = 0;
@@ -325,6 +331,8 @@ static uint64_t stream_file_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char 
             got[k % STREAM_BUFS] = n;
         }
         if (io_err) die(EIO, "%s: %s", path, kssd_host_strerror(KSSD_HOST_ERR_IO));
+        t_read += now_s() - t0;
+        t0 = now_s();
         for (uint64_t k = g0; k < g1 && !short_read; k++) {
             const int b = (int)(k % STREAM_BUFS);
             const int64_t t = kssd_gpu_text_put(ctx, k * STREAM_SLICE, ring->buf[b], got[b]);
@@ -333,8 +341,12 @@ static uint64_t stream_file_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char 
             total += got[b];
             if (k * STREAM_SLICE + got[b] < (k + 1 < n_slices ? (k + 1) * STREAM_SLICE : len)) short_read = 1; /* (a file that shrank meanwhile) */
         }
+        t_put += now_s() - t0;
     }
     close(fd);
+    if (getenv("KSSD_TIMING"))
+        fprintf(stderr, "{\"kssd_timing\": \"stream\", \"bytes\": %llu, \"slices\": %llu, \"s_wait_copies\": %.6f, \"s_pread\": %.6f, \"s_put\": %.6f}\n",
+                (unsigned long long)total, (unsigned long long)n_slices, t_wait, t_read, t_put);
     return total;
 }
 
@@ -513,6 +525,8 @@ typedef struct {
     uint32_t hashsize;
     kssd_shuf_hdr hdr;
     const int32_t *table;
+    double t_ctx_destroy;
+    double t_ctx;   /* the slowest worker's context creation (HIP initialisation, code object load, table upload) */
     double t_gpu;   /* summed over the workers: seconds inside process_job */
     double t_call;  /* ... of which inside the kssd_gpu_sketch_batch* calls (H2D, kernels, D2H) */
 } pipeline;
@@ -528,7 +542,11 @@ static void *worker_main(void *arg)
     worker *w = arg;
     pipeline *pl = w->pl;
     kssd_gpu_ctx *ctx = NULL;
+    const double tc0 = now_s();
     gck(kssd_gpu_create(&ctx, &pl->hdr, pl->table, w->device), "kssd_gpu_create");
+    pthread_mutex_lock(&pl->mu);
+    if (now_s() - tc0 > pl->t_ctx) pl->t_ctx = now_s() - tc0;
+    pthread_mutex_unlock(&pl->mu);
     stream_ring ring = {{0}};
     for (;;) {
         pthread_mutex_lock(&pl->mu);
@@ -564,9 +582,13 @@ static void *worker_main(void *arg)
         pthread_cond_broadcast(&pl->cv);
         pthread_mutex_unlock(&pl->mu);
     }
+    const double td0 = now_s();
     for (int b = 0; b < STREAM_BUFS; b++)
         if (ring.buf[b]) kssd_gpu_host_free(ring.buf[b]);
     kssd_gpu_destroy(ctx);
+    pthread_mutex_lock(&pl->mu);
+    if (now_s() - td0 > pl->t_ctx_destroy) pl->t_ctx_destroy = now_s() - td0;
+    pthread_mutex_unlock(&pl->mu);
     return NULL;
 }
 
@@ -687,6 +709,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         if (pthread_create(&ws[i].th, NULL, worker_main, &ws[i])) die(EAGAIN, "pthread_create");
     }
 
+    const double t_workers_started = now_s();
     /* a device batch: at most ~0.5 Gbases (so that several are in flight and the transfers hide under the kernels) */
     const uint64_t max_chunks = 1ull << 17;
     double t_read = 0, t_tok = 0;
@@ -890,9 +913,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     free(s.counts);
     if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
         fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
-                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
+                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
                         "\"s_workers_summed\": %.6f, \"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
-                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, t_read, t_tok,
+                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_read, t_tok,
                 pl.t_gpu, pl.t_call, now_s() - t_sketched);
 }
 
