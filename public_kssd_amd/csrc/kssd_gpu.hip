@@ -409,6 +409,46 @@ struct ScanArgs {
 };
 
 // one chunk of the lane's share of the stream: 64 positions + halo, and their validity bits
+#if defined(KSSD_SCAN_ASMLOAD)
+// The chunk loads as inline assembly with hand-placed s_waitcnt vmcnt(N).  Left to the compiler, the first of the four
+// unrolled steps waits with vmcnt(0) -- for the chunks c+2 and c+3 that have only just been requested -- because its
+// wait-count bookkeeping loses the order of the pending loads across the loop's back edge (and flushes in front of a loop
+// that stores and uses loaded registers).  Here the compiler does not know these are loads: the registers are the asm's
+// outputs, and chunk_wait<N> -- "at most N vector memory operations still in flight", the registers passed through it so
+// that no use can move in front of it -- is what makes them valid.  Three operations per chunk, issued in chunk order and
+// completing in order: the chunk requested two steps ago is complete when at most 6 are outstanding (stores the compiler
+// knows about only make that wait conservative).
+typedef uint32_t kssd_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t kssd_u32x2 __attribute__((ext_vector_type(2)));
+struct ChunkRegs {
+    kssd_u32x4 w;
+    uint32_t w4;
+    kssd_u32x2 m;
+};
+__device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long c, uint32_t lane, ChunkRegs &r)
+{
+    const uint32_t *bp = a.packed + c * 256;  // wave-uniform bases in SGPRs, the lane's offset in a VGPR
+    const uint32_t *bm = a.mask + c * 128;
+    const uint32_t o16 = lane * 16u, o8 = lane * 8u;
+    asm volatile("global_load_dword %0, %3, %5 offset:16\n\tglobal_load_dwordx4 %1, %3, %5\n\tglobal_load_dwordx2 %2, %4, %6"
+                 : "=&v"(r.w4), "=&v"(r.w), "=&v"(r.m)
+                 : "v"(o16), "v"(o8), "s"(bp), "s"(bm));
+}
+template <int N>
+__device__ __forceinline__ void chunk_wait(ChunkRegs &r)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.w4), "+v"(r.w), "+v"(r.m) : "n"(N));
+}
+// behind the loop: the last two requests are never used, but they are still going to WRITE their registers -- all four
+// sets stay allocated (the asm "uses" them) until nothing is in flight any more
+__device__ __forceinline__ void chunk_drain(ChunkRegs &a, ChunkRegs &b, ChunkRegs &c, ChunkRegs &d)
+{
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(a.w4), "+v"(a.w), "+v"(a.m), "+v"(b.w4), "+v"(b.w), "+v"(b.m), "+v"(c.w4), "+v"(c.w), "+v"(c.m), "+v"(d.w4), "+v"(d.w),
+                   "+v"(d.m));
+}
+#define KSSD_CHUNK_WORDS_OF(r, WN, MN) const uint32_t WN[5] = {(r).w.x, (r).w.y, (r).w.z, (r).w.w, (r).w4}; const uint32_t MN[2] = {(r).m.x, (r).m.y}
+#else
 struct ChunkRegs {
     uint32_t W[5];
     uint32_t M[2];
@@ -423,6 +463,11 @@ __device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long
     const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + c * 128 + lane * 2);
     r.M[0] = m.x; r.M[1] = m.y;
 }
+template <int N>
+__device__ __forceinline__ void chunk_wait(ChunkRegs &) {}
+__device__ __forceinline__ void chunk_drain(ChunkRegs &, ChunkRegs &, ChunkRegs &, ChunkRegs &) {}
+#define KSSD_CHUNK_WORDS_OF(r, WN, MN) const uint32_t (&WN)[5] = (r).W; const uint32_t (&MN)[2] = (r).M
+#endif
 
 // A buffered stage-1 candidate (8 bytes in LDS):
 //   x  [11:0] position inside its chunk (lane << 6 | b)   [22:12] chunk - c0, modulo 2048 (entries live for a few chunks)
@@ -514,17 +559,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint64_t vb_prev = 0;
 
     // prologue: chunk c0 through both alignments
-    kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
-    kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
+    chunk_wait<6>(r0);
+    {
+        KSSD_CHUNK_WORDS_OF(r0, w0, m0);
+        (void)m0;
+        kssd_grp_issue<SUBK, KSSD_GW, 0>(w0, T1, raw);
+        kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
 #if defined(KSSD_SCAN_PREDB)
-    kssd_grp_issue_pred<SUBK, KSSD_GW>(r0.W, T1, alo & r0.M[0], ahi & r0.M[1], raw);
+        kssd_grp_issue_pred<SUBK, KSSD_GW>(w0, T1, alo & m0[0], ahi & m0[1], raw);
 #else
-    kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of chunk c0 in flight
+        kssd_grp_issue<SUBK, KSSD_GW, 1>(w0, T1, raw);  // alignment B of chunk c0 in flight
 #endif
+    }
 
     // one chunk.  The four register sets rotate by name (the loop below is unrolled four times): copying one
     // set into another would make every iteration wait for the reads it has just issued.
-    auto step = [&](const ChunkRegs &cur, const ChunkRegs &nxt, ChunkRegs &far, const unsigned long long c) {
+    auto step = [&](const ChunkRegs &cur_r, ChunkRegs &nxt_r, ChunkRegs &far, const unsigned long long c) {
         // state: cur = chunk c, nxt = chunk c+1 (requested two iterations ago), chunk c+2 in flight, far = free, raw = alignment-B reads of
         //        chunk c (in flight), alo/ahi = alignment A of chunk c
         // Wave priority: the part of an iteration that feeds the memory and LDS pipes runs at high priority (3 while the
@@ -534,6 +584,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         // table-read issue raised, 0.529 with everything but the loop at 2, 0.526 as it is here.
         __builtin_amdgcn_s_setprio(3);
         load_chunk(a, c + 3 < clast ? c + 3 : clast, lane, far);
+        chunk_wait<6>(nxt_r);  // chunk c+1 (requested two steps ago) is in; c+2 and c+3 stay in flight
+        KSSD_CHUNK_WORDS_OF(cur_r, curW, curM);
+        KSSD_CHUNK_WORDS_OF(nxt_r, nxtW, nxtM);
+        (void)nxtM;
+        const struct { const uint32_t (&W)[5]; const uint32_t (&M)[2]; } cur = {curW, curM}, nxt = {nxtW, nxtM};
         const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
         uint32_t rawa[Gp::NMAX];
         if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
@@ -612,6 +667,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         if (c + 2 < c1) step(r2, r3, r1, c + 2);
         if (c + 3 < c1) step(r3, r0, r2, c + 3);
     }
+    chunk_drain(r0, r1, r2, r3);
     while (cn) {
         const uint32_t n = cn < 64 ? cn : 64;
         wave_lds_sync();
