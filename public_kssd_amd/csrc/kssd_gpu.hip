@@ -538,6 +538,112 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
 
+#if defined(KSSD_SCAN_LATELOOP)
+    // experiment: the candidate loop of a chunk runs ONE STEP LATER, under the table reads of both alignments of the
+    // following chunks: alignment B of chunk c (issued at the end of step c-1) and alignment A of chunk c+1 (issued at the top
+    // of step c) are in flight while the loop of chunk c-1 -- pure VALU work -- runs; nothing waits for an LDS answer right
+    // after asking for it.  Four register sets as before: c-1 (loop), c (masks), c+1 (table reads), c+2 (in flight from HBM).
+    ChunkRegs r0, r1, r2, r3;
+    uint32_t raw[Gp::NMAX];
+    uint32_t alo, ahi;
+    load_chunk(a, c0 < clast ? c0 : clast, lane, r1);
+    load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, r2);
+    load_chunk(a, c0 < clast ? c0 : clast, lane, r0);  // (set "c0 - 1" of the first step: never looked at, loaded to keep three requests per set)
+    for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
+        *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
+    __syncthreads();
+    if (c0 >= c1) return;
+    uint32_t s_tail = c0 ? __builtin_amdgcn_readfirstlane(a.packed[c0 * 256 - 1]) : 0u;  // the word in front of chunk c
+    uint32_t p_tail = 0, p_ebase = 0, pcl = 0, pch = 0;                                     // ... of chunk c-1, and its candidates
+    uint64_t vb_prev = 0;
+    chunk_wait<0>(r1);
+    {
+        KSSD_CHUNK_WORDS_OF(r1, w0, m0);
+        (void)m0;
+        kssd_grp_issue<SUBK, KSSD_GW, 0>(w0, T1, raw);
+        kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
+        kssd_grp_issue<SUBK, KSSD_GW, 1>(w0, T1, raw);
+    }
+    // the candidate loop of one chunk: W = its words, wm1 = the word in front of the lane's own, ebase = entry bits that
+    // do not depend on the candidate, crel_now = the chunk the wave is at (for a make-room round)
+    auto cand_loop = [&](const uint32_t (&W)[5], uint32_t wm1, uint32_t ebase, uint32_t cl, uint32_t ch, uint32_t crel_now) {
+        for (;;) {
+            const bool has = (cl | ch) != 0;
+            const uint64_t hbal = __ballot(has);
+            if (hbal == 0) break;
+            if (cn + 64 > CBUF) {  // dense parameter sets only: make room
+                wave_lds_sync();
+                const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel_now, cbuf, cn - 64, 64, stored, lane, abl_acc);
+                stored += m;
+                n_rounded += 64;
+                cn -= 64;
+                wave_lds_sync();
+            }
+            if (has) {
+                const bool in_lo = cl != 0;
+                const uint32_t word = in_lo ? cl : ch;
+                const uint32_t b = (uint32_t)__builtin_ctz(word) + (in_lo ? 0u : 32u);
+                const uint32_t rest = word & (word - 1u);
+                cl = in_lo ? rest : 0u;
+                ch = in_lo ? ch : rest;
+                uint32_t top32, front;
+                kssd_extract_carry<SUBK>(W, wm1, b, top32, front);
+                cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b | (front << 24), top32);
+            }
+            cn += __builtin_popcountll(hbal);
+        }
+    };
+    auto step = [&](const ChunkRegs &prev_r, const ChunkRegs &cur_r, ChunkRegs &nxt_r, ChunkRegs &far, const unsigned long long c) {
+        __builtin_amdgcn_s_setprio(3);
+        load_chunk(a, c + 2 < clast ? c + 2 : clast, lane, far);
+        chunk_wait<3>(nxt_r);
+        KSSD_CHUNK_WORDS_OF(prev_r, prevW, prevM);
+        KSSD_CHUNK_WORDS_OF(cur_r, curW, curM);
+        KSSD_CHUNK_WORDS_OF(nxt_r, nxtW, nxtM);
+        (void)prevM;
+        (void)nxtM;
+        uint32_t rawa[Gp::NMAX];
+        kssd_grp_issue<SUBK, KSSD_GW, 0>(nxtW, T1, rawa);  // alignment A of chunk c+1 goes in flight (B of chunk c already is)
+        const uint32_t crel = (uint32_t)(c - c0);
+        __builtin_amdgcn_s_setprio(0);
+        {   // chunk c-1: its candidates, under the table reads in flight
+            const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)p_tail, (int)prevW[3], 0x138, 0xf, 0xf, false);
+            cand_loop(prevW, wm1, p_ebase, pcl, pch, crel);
+        }
+        __builtin_amdgcn_s_setprio(2);
+        const uint64_t vb = __ballot((curM[0] & curM[1]) == 0xFFFFFFFFu);
+        uint32_t blo, bhi;
+        kssd_grp_merge<SUBK, KSSD_GW, 1>(raw, blo, bhi);
+        pcl = alo & blo & curM[0];
+        pch = ahi & bhi & curM[1];
+        const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);
+        p_ebase = ((crel & 2047u) << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
+        p_tail = s_tail;
+        s_tail = __builtin_amdgcn_readlane(curW[3], 63);
+        vb_prev = vb;
+        kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
+        if (cn >= 64) {
+            wave_lds_sync();
+            const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
+            stored += m;
+            n_rounded += 64;
+            cn -= 64;
+        }
+        kssd_grp_issue<SUBK, KSSD_GW, 1>(nxtW, T1, raw);
+        if (c + 1 >= c1) {  // the wave's last chunk: nobody comes after it to run its loop
+            __builtin_amdgcn_s_setprio(0);
+            const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)p_tail, (int)curW[3], 0x138, 0xf, 0xf, false);
+            cand_loop(curW, wm1, p_ebase, pcl, pch, crel);
+        }
+    };
+    for (unsigned long long c = c0; c < c1; c += 4) {
+        step(r0, r1, r2, r3, c);
+        if (c + 1 < c1) step(r1, r2, r3, r0, c + 1);
+        if (c + 2 < c1) step(r2, r3, r0, r1, c + 2);
+        if (c + 3 < c1) step(r3, r0, r1, r2, c + 3);
+    }
+    chunk_drain(r0, r1, r2, r3);
+#else
     // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
     // first reads overlaps the 144 KiB copy instead of following it
     ChunkRegs r0, r1, r2, r3;
@@ -668,6 +774,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         if (c + 3 < c1) step(r3, r0, r2, c + 3);
     }
     chunk_drain(r0, r1, r2, r3);
+#endif
     while (cn) {
         const uint32_t n = cn < 64 ? cn : 64;
         wave_lds_sync();
