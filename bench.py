@@ -829,6 +829,21 @@ def main():
                                                      "FETCH_SIZE pass of %s, kernel source %s)" % (pj.get("tag", "?"), pj.get("source_commit", "?")))
             except Exception:
                 pass
+        if a.cpu_sample and world == 1 and NF == 1 and not os.environ.get("KSSD_BENCH_NO_PIPELINED"):
+            # beside the headline (steps back to back on one stream): the same steps with three batches in flight on three
+            # streams -- the sort / index / rows kernels of one step under the scan of the next.  A child process (its own
+            # batch, contexts and clocks), untimed here; its line is embedded, the headline above is not touched by it.
+            try:
+                env = dict(os.environ, KSSD_BENCH_NO_PIPELINED="1")
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inflight", "3", "--cpu-sample", "0", "--steps", str(max(a.steps, 30)),
+                                    "--warmup", "3", "--genomes", str(G), "--length", str(L), "--clades", str(a.clades)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+                pj = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                res["pipelined"] = {"batches_in_flight": 3, "value": pj["value"], "unit": pj["unit"], "ms_per_step": pj["ms_per_step"],
+                                    "steps": pj["steps"], "sketch_scan_ms_under_overlap": pj["kernels"]["sketch_scan_ms"],
+                                    "what": "`bench.py --inflight 3`: every step does the same work; three steps overlap on three HIP streams"}
+            except Exception as e:   # the leg is informational
+                res["pipelined"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
     for sl in slots:
         sl.ctx.close()
