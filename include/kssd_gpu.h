@@ -210,7 +210,8 @@ int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uin
                                uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                                uint32_t **out_pos, uint64_t *h_lines, int64_t *bad_genome);
 /*
- * Streaming a long input in without a host buffer of its size: reserve the context's device text buffer once, copy
+ * Streaming a long input in without a host buffer of its size: reserve the context's device text buffer (reserving more
+ * later keeps what has been put: an input of unknown size -- a gzip'ed file -- starts from an estimate), copy
  * slices in from page-locked host memory (asynchronous, on the context's own stream; the returned ticket >= 0 tells
  * kssd_gpu_text_wait which copy to wait for before the slice's memory is refilled -- at most the last 32 copies are
  * tracked one by one), then call kssd_gpu_sketch_fasta_text / _fastq_text with text == NULL: the offsets then address

@@ -2011,12 +2011,25 @@ extern "C" int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *c, const uint8_t *text, 
 // Streaming a long input in: the context's device text buffer is reserved once, slices are copied in from (page-locked)
 // host memory asynchronously on the context's stream, and kssd_gpu_sketch_fast[aq]_text is called with text == NULL.
 // The host side needs no buffer of the file's size: a few slices that are refilled as soon as their copy has left.
+// (growing keeps what has been put so far: an input whose size is not known beforehand -- a gzip'ed file -- reserves an
+// estimate and asks for more when the estimate runs out)
 extern "C" int kssd_gpu_text_reserve(kssd_gpu_ctx *c, uint64_t bytes)
 {
     if (!c) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     HIPCK(hipStreamSynchronize(c->own_stream));
-    return ensure(&c->d_text, &c->cap_text, (size_t)bytes + 64);
+    const size_t need = (size_t)bytes + 64;
+    if (c->d_text && c->cap_text >= need) return KSSD_OK;
+    uint8_t *grown = nullptr;
+    const size_t n = need + need / 4;
+    if (hipMalloc(&grown, n) != hipSuccess) return KSSD_ERR_NOMEM;
+    if (c->d_text) {
+        if (hipMemcpy(grown, c->d_text, c->cap_text, hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(grown); return KSSD_ERR_HIP; }
+        hipFree(c->d_text);
+    }
+    c->d_text = grown;
+    c->cap_text = n;
+    return KSSD_OK;
 }
 
 // returns the copy's ticket (>= 0) for kssd_gpu_text_wait, or an error (< 0)

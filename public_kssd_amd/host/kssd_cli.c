@@ -21,6 +21,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -264,7 +265,7 @@ typedef struct job {
     kssd_batch *b;      /* FASTQ with -Q > 0, -A: tokenised on the host */
     textbuf *tx;        /* FASTA, FASTQ with -Q 0: the raw bytes, tokenised on the device (kssd_gpu_sketch_fast[aq]_text) */
     kssd_batch *own_b;  /* a text job the device handed back: the host tokeniser's batch of it */
-    int streamed;       /* one long plain file: the worker streams it into the device's text buffer (stream_file_in) */
+    int streamed;       /* one long file: the worker streams it into the device's text buffer (1 plain: stream_file_in, 2 gzip'ed: stream_gz_in) */
     int uploaded;
     uint64_t *toff, *tlen, *lines;
     int is_fq, first_file, n_files;
@@ -283,6 +284,7 @@ typedef struct job {
  * the copies of the slices before them run.  What the host holds is STREAM_BUFS x STREAM_SLICE bytes (128 MiB), whatever
  * the file's size; page-locking memory costs ~0.25 s per GB, which is why the ring is small. */
 static uint64_t STREAM_MIN = 256ull << 20;  /* files from this size on (KSSD_STREAM_MIN, bytes) */
+static uint64_t STREAM_MIN_GZ = 64ull << 20; /* gzip'ed files from this compressed size on (KSSD_STREAM_MIN_GZ) */
 static uint64_t STREAM_SLICE = 8ull << 20; /* (KSSD_STREAM_SLICE, bytes; a multiple of 4096) */
 #define STREAM_BUFS 16
 #define STREAM_READERS 8 /* slices read at a time, one thread each (the ring holds two such groups) */
@@ -290,6 +292,8 @@ static void stream_env(void)
 {
     const char *e = getenv("KSSD_STREAM_MIN");
     if (e) STREAM_MIN = strtoull(e, NULL, 10);
+    e = getenv("KSSD_STREAM_MIN_GZ");
+    if (e) STREAM_MIN_GZ = strtoull(e, NULL, 10);
     e = getenv("KSSD_STREAM_SLICE");
     if (e && strtoull(e, NULL, 10) >= 4096) STREAM_SLICE = strtoull(e, NULL, 10) / 4096 * 4096;
 }
@@ -350,16 +354,70 @@ static uint64_t stream_file_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char 
     return total;
 }
 
+/* The same for a gzip'ed input: zlib inflates straight into the ring's slices (one thread: a gzip stream has no entry
+ * points), the copies run under the inflating.  The device buffer starts from an estimate -- the size the file's trailer
+ * states (modulo 2^32, and only the last member's) or four times the compressed size, whichever is larger -- and grows
+ * (kssd_gpu_text_reserve keeps its content) when the stream turns out longer. */
+static uint64_t stream_gz_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char *path, uint64_t gz_size)
+{
+    for (int b = 0; b < STREAM_BUFS; b++)
+        if (!ring->buf[b] && !(ring->buf[b] = kssd_gpu_host_alloc(STREAM_SLICE))) die(ENOMEM, "out of page-locked memory");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) die(EIO, "%s: %s", path, kssd_host_strerror(KSSD_HOST_ERR_IO));
+    uint64_t room = gz_size * 4;
+    unsigned char tr[4];
+    if (gz_size >= 4 && pread(fd, tr, 4, (off_t)(gz_size - 4)) == 4) {
+        const uint64_t isize = (uint64_t)tr[0] | ((uint64_t)tr[1] << 8) | ((uint64_t)tr[2] << 16) | ((uint64_t)tr[3] << 24);
+        if (isize > room) room = isize;
+    }
+    room += room / 16 + (1u << 20);
+    gck(kssd_gpu_text_reserve(ctx, room), "kssd_gpu_text_reserve");
+    gzFile g = gzdopen(fd, "rb");
+    if (!g) { close(fd); die(EIO, "%s: %s", path, kssd_host_strerror(KSSD_HOST_ERR_IO)); }
+    gzbuffer(g, 1 << 20);
+    int64_t ticket[STREAM_BUFS];
+    for (int b = 0; b < STREAM_BUFS; b++) ticket[b] = -1;
+    uint64_t total = 0, k = 0;
+    double t_wait = 0, t_inflate = 0;
+    for (;; k++) {
+        const int b = (int)(k % STREAM_BUFS);
+        double t0 = now_s();
+        if (ticket[b] >= 0) gck(kssd_gpu_text_wait(ctx, ticket[b]), "kssd_gpu_text_wait");
+        t_wait += now_s() - t0;
+        t0 = now_s();
+        uint64_t n = 0;
+        while (n < STREAM_SLICE) {
+            const uint64_t want = STREAM_SLICE - n;
+            const int r = gzread(g, ring->buf[b] + n, (unsigned)(want > (1u << 30) ? (1u << 30) : want));
+            if (r < 0) { gzclose(g); die(EIO, "%s: %s", path, kssd_host_strerror(KSSD_HOST_ERR_IO)); }
+            if (r == 0) break;
+            n += (uint64_t)r;
+        }
+        t_inflate += now_s() - t0;
+        if (n == 0) break;
+        if (total + n > room) { /* longer than the estimate */
+            room = (total + n) * 2;
+            gck(kssd_gpu_text_reserve(ctx, room), "kssd_gpu_text_reserve");
+        }
+        const int64_t t = kssd_gpu_text_put(ctx, total, ring->buf[b], n);
+        if (t < 0) gck((int)t, "kssd_gpu_text_put");
+        ticket[b] = t;
+        total += n;
+        if (n < STREAM_SLICE) break;
+    }
+    gzclose(g);
+    if (getenv("KSSD_TIMING"))
+        fprintf(stderr, "{\"kssd_timing\": \"stream_gz\", \"bytes\": %llu, \"compressed\": %llu, \"s_wait_copies\": %.6f, \"s_inflate\": %.6f}\n",
+                (unsigned long long)total, (unsigned long long)gz_size, t_wait, t_inflate);
+    return total;
+}
+
 /* the job's genomes through the device: FASTA text is tokenised there, FASTQ batches arrive tokenised; pos may be NULL */
 static int job_sketch(kssd_gpu_ctx *ctx, job *j, stream_ring *ring, const filelist *fl, uint32_t flags, uint32_t min_occ, uint64_t **off,
                       uint32_t **ids, uint32_t **pos, int64_t *bad)
 {
     if ((j->tx || j->streamed) && !j->own_b) {
         const unsigned char *text = j->tx ? j->tx->p : NULL; /* NULL: already in the context's device buffer */
-        if (j->streamed && !j->uploaded) {
-            j->tlen[0] = stream_file_in(ctx, ring, fl->path[j->first_file], j->tlen[0]);
-            j->uploaded = 1;
-        }
         if (j->is_fq)
             return kssd_gpu_sketch_fastq_text(ctx, text, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, j->lines, bad);
         return kssd_gpu_sketch_fasta_text(ctx, text, j->toff, j->tlen, (uint32_t)j->n_files, flags, min_occ, off, ids, pos, bad);
@@ -386,6 +444,13 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     uint64_t *off = NULL;
     uint32_t *ids = NULL, *pos = NULL;
     int64_t bad = -1;
+    if (j->streamed && !j->uploaded) { /* the text's length (a gzip'ed input: only known now) decides what follows */
+        const double tu0 = now_s();
+        j->tlen[0] = j->streamed == 2 ? stream_gz_in(ctx, ring, fl->path[j->first_file], j->tlen[0])
+                                      : stream_file_in(ctx, ring, fl->path[j->first_file], j->tlen[0]);
+        j->uploaded = 1;
+        *t_call += now_s() - tu0;
+    }
     /* first positions (for the reference's exact file order) need genomes below 2^32 positions */
     int with_pos = 1;
     for (uint32_t g = 0; g < n; g++) {
@@ -738,8 +803,12 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             direct[i] = 0;
             trc[i] = kssd_file_probe(path, &gz, &sz);
             if (trc[i]) continue;
-            if (!gz && (fq_dev || !has_fmt(path, fq_fmt))) {
+            const int dev_tok = fq_dev || !has_fmt(path, fq_fmt); /* the device tokenises it */
+            if (!gz && dev_tok) {
                 direct[i] = 1;
+                len[i] = (size_t)sz;
+            } else if (gz && dev_tok && sz >= STREAM_MIN_GZ) {
+                direct[i] = 2; /* inflated by the device worker, slice by slice, on its way to the device */
                 len[i] = (size_t)sz;
             } else {
                 trc[i] = kssd_slurp_reuse(path, &txt[i], &txt_cap[i], &len[i]);
@@ -753,10 +822,11 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             const int fq = has_fmt(fl->path[i0 + r0], fq_fmt);
             uint64_t chunks = 0;
             int r1 = r0;
-            const int stream0 = direct[r0] && len[r0] >= STREAM_MIN; /* a long plain file is a job of its own */
+            /* a long file is a job of its own */
+            const int stream0 = direct[r0] == 2 ? 2 : (direct[r0] == 1 && len[r0] >= STREAM_MIN);
             while (r1 < nw && has_fmt(fl->path[i0 + r1], fq_fmt) == fq) {
                 const uint64_t c = (len[r1] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES;
-                if (r1 > r0 && (stream0 || (direct[r1] && len[r1] >= STREAM_MIN))) break;
+                if (r1 > r0 && (stream0 || direct[r1] == 2 || (direct[r1] == 1 && len[r1] >= STREAM_MIN))) break;
                 if (r1 > r0 && chunks + c > max_chunks) break;
                 chunks += c;
                 r1++;
@@ -777,8 +847,8 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     at += (len[i] + 15) / 16 * 16;
                 }
                 if (stream0) { /* the worker reads it, slice by slice, on its way to the device */
-                    j->streamed = 1;
-                    n_bytes += len[r0];
+                    j->streamed = stream0;
+                    n_bytes += len[r0]; /* (a gzip'ed one: its compressed size) */
                     printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + r0]);
                     goto queue_job;
                 }
@@ -796,7 +866,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
                 for (int i = r0; i < r1; i++) {
                     unsigned char *dst = tx->p + j->toff[i - r0];
-                    if (direct[i]) {
+                    if (direct[i] == 1) {
                         size_t got = 0;
                         trc[i] = kssd_read_into(fl->path[i0 + i], dst, len[i], &got);
                         j->tlen[i - r0] = got; /* (a file that shrank meanwhile) */

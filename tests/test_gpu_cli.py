@@ -234,12 +234,19 @@ def test_long_plain_files_are_streamed_to_the_device(tmp_path):
              "g1.fasta": fasta_text(rng.integers(0, 4, 3_000_000, dtype=np.uint8), n_mask=rng.random(3_000_000) < 1e-4),
              "g2.fasta": fasta_text(rng.integers(0, 4, 40_000, dtype=np.uint8)),
              "g3.fasta": fasta_text(rng.integers(0, 4, 1_200_001, dtype=np.uint8))}
+    import gzip
+    # gzip'ed inputs stream too: inflated slice by slice into the ring.  Their size is an estimate (the trailer's length field,
+    # or four times the compressed size): a two-member file whose trailer only speaks for its short last member and
+    # constant-quality reads that pack 15 : 1 make the device buffer grow on the way
+    files["z_reads.fastq.gz"] = gzip.compress(fq[0][:len(fq[0]) // 2], 1) + gzip.compress(fq[0][len(fq[0]) // 2:][:314 * 10], 1)
+    files["z_g.fasta.gz"] = gzip.compress(files["g3.fasta"], 1)
     for name, text in files.items():
         open(os.path.join(d, name), "wb").write(text)
     K.Shuf.generate(10, 6, 3, seed=11).write(os.path.join(d, "s.shuf"))
     names = sorted(files)
-    run(["dist", "-L", "s.shuf", "-o", "plain"] + names, d, env={"KSSD_STREAM_MIN": str(1 << 40)})
-    run(["dist", "-L", "s.shuf", "-o", "streamed"] + names, d, env={"KSSD_STREAM_MIN": str(1 << 20), "KSSD_STREAM_SLICE": str(1 << 16)})
+    run(["dist", "-L", "s.shuf", "-o", "plain"] + names, d, env={"KSSD_STREAM_MIN": str(1 << 40), "KSSD_STREAM_MIN_GZ": str(1 << 40)})
+    run(["dist", "-L", "s.shuf", "-o", "streamed"] + names, d,
+        env={"KSSD_STREAM_MIN": str(1 << 20), "KSSD_STREAM_MIN_GZ": "1024", "KSSD_STREAM_SLICE": str(1 << 16)})
     for fn in ("combco.0", "combco.index.0", "cofiles.stat"):
         a = open(os.path.join(d, "plain", fn), "rb").read()
         b = open(os.path.join(d, "streamed", fn), "rb").read()
