@@ -189,3 +189,66 @@ def test_sketches_of_device_tokenised_fastq_equal_the_oracle(shuf_l3k10):
             assert np.array_equal(ids[int(off[g]):int(off[g + 1])], np.sort(sk.fastq(t, Q=0))), g
     finally:
         ctx.close()
+
+
+# ---- fuzz: many small random texts, every byte class in every neighbourhood ---------------------------------------------
+
+def _fuzz_texts(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    alphabets = [b"ACGT", b"ACGTacgt", b"ACGTN", b"ACGT\n", b"ACGTNRY-*\r\n", b"ACGT>\n", b"AC>GT\n\r N", b"\n", b">", b"N>\n"]
+    out = []
+    for i in range(n):
+        ln = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 33, 100, 4095, 4096, 4097, 9000])) if i % 3 == 0 else int(rng.integers(0, 6000))
+        al = np.frombuffer(alphabets[int(rng.integers(0, len(alphabets)))], np.uint8)
+        w = rng.random(len(al)) ** 3 + 0.02
+        t = bytes(al[rng.choice(len(al), size=ln, p=w / w.sum())])
+        if kind == "fastq":
+            # line structure at random: newline density from "a few long lines" to "mostly empty lines"; at least one complete record
+            t = t.replace(b">", b"@")
+            extra = int(rng.integers(0, 40))
+            pos = np.sort(rng.integers(0, len(t) + 1, extra))
+            parts, last = [], 0
+            for p in pos:
+                parts.append(t[last:int(p)])
+                last = int(p)
+            parts.append(t[last:])
+            t = b"\n".join(parts)
+            t = t + b"\n" * max(0, 4 - t.count(b"\n")) + (b"\n" if rng.random() < 0.5 else b"")
+        else:
+            if t.rfind(b">") > t.rfind(b"\n"):   # an unclosed last header is an error of its own (tested above)
+                t += b"\n"
+        out.append(t)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["fasta", "fastq"])
+def test_device_tokenisers_fuzz(shuf_l3k10, kind):
+    import torch
+    dev = torch.device("cuda", 0)
+    texts = _fuzz_texts(kind, 600, 2026 if kind == "fasta" else 2027)
+    hb = K.Batch()
+    first = hb.reserve([len(t) for t in texts])
+    lines = []
+    for i, t in enumerate(texts):
+        lines.append(hb.fill_text(first + i, t, kind=1 if kind == "fastq" else 0, Q=0) if len(t) else 0)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        buf, offs, lens = ctx._text_layout(texts)
+        co = hb.chunk_off()
+        d_text = torch.from_numpy(buf).to(dev)
+        nchunks = int(co[-1])
+        d_packed = torch.full((nchunks * K.CHUNK_WORDS + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        d_mask = torch.full((nchunks * K.CHUNK_MASKW + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        r = ctx.tokenise_fasta_device(d_text, offs, lens, d_packed, d_mask, co, fastq=(kind == "fastq"))
+        assert r[0] == 0 and r[1] == -1, r[:2]
+        want_pos = np.array([hb.n_positions(first + i) for i in range(len(texts))], dtype=np.uint64)
+        bad = np.nonzero(r[2] != want_pos)[0]
+        assert len(bad) == 0, (int(bad[0]), texts[int(bad[0])][:200], int(r[2][bad[0]]), int(want_pos[bad[0]]))
+        if kind == "fastq":
+            assert np.array_equal(r[3], np.array(lines, dtype=np.uint64))
+        gp = d_packed.cpu().numpy().view(np.uint32)
+        gm = d_mask.cpu().numpy().view(np.uint32)
+        assert np.array_equal(gm, hb.mask()[:len(gm)])
+        assert np.array_equal(gp, hb.packed()[:len(gp)])
+    finally:
+        ctx.close()
