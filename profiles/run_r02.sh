@@ -17,6 +17,16 @@ tokprof) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpu
     f=$(find gpurun_out/${tag}_tokprof -name "*kernel_stats.csv" | head -1)
     [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_tok_kernel_stats.csv
     rm -rf gpurun_out/${tag}_tokprof; grep -v "^W\|^E" gpurun_out/${tag}_tokprof.log | tail -4; cat gpurun_out/${tag}_tok_kernel_stats.csv ;;
+proffq) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_proffq -- python3 bench.py --workload fastq --genomes 10000 --clades 500 --steps 5 --warmup 1 --parity-reads 0 > gpurun_out/${tag}_proffq.log 2>&1
+    f=$(find gpurun_out/${tag}_proffq -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && grep -v "at::native" "$f" > gpurun_out/${tag}_fastq_kernel_stats.csv
+    rm -rf gpurun_out/${tag}_proffq; tail -2 gpurun_out/${tag}_proffq.log | cut -c1-300; python3 - gpurun_out/${tag}_fastq_kernel_stats.csv <<'PY'
+import csv, sys
+for r in csv.reader(open(sys.argv[1])):
+    if r[0] == "Name": continue
+    print("%-70s calls %4s avg %9.1f us" % (r[0][:70], r[1], float(r[3]) / 1e3))
+PY
+    ;;
 smoke) timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 ;;
 inflight) timeout 600 python bench.py --inflight 3 --steps 30 --warmup 3 --cpu-sample 0 > gpurun_out/${tag}_bench_inflight3.json 2> gpurun_out/${tag}_bench_inflight3.err; tail -2 gpurun_out/${tag}_bench_inflight3.err; cut -c1-400 gpurun_out/${tag}_bench_inflight3.json ;;
 info) { nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us /sys/fs/cgroup/cpu/cpu.cfs_period_us 2>/dev/null; grep -c processor /proc/cpuinfo; grep "model name" /proc/cpuinfo | head -1; free -g | head -2; python3 -c "import os;print(len(os.sched_getaffinity(0)))"; } 2>&1 | tee gpurun_out/${tag}_info.txt ;;

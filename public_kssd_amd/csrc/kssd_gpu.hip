@@ -836,10 +836,11 @@ struct ExactArgs {
     SketchStatus *status;
 };
 
+#define EXACT_THREADS 256  // four waves share one reservation of staging room (see below); 1 024 threads: fewer atomics, and 450 us instead of 210 -- too few chains in flight
 #define EXACT_PER 4  // candidates per thread: the kernel is a chain of dependent memory round trips (record -> genome of the chunk ->
                      // cuckoo slots -> cursor -> staging region), so every thread keeps four chains in flight
 template <typename K>
-__global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactArgs x)
+__global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams P, ExactArgs x)
 {
     // grid = (blocks per slice, slices): block (bx, w) takes candidates [1024 bx, 1024 bx + 1024) of scan wave w,
     // thread t the candidates 1024 bx + 256 j + t
@@ -851,8 +852,8 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         atomicMax(&x.status->cand_need, want);
     }
     const uint32_t n = want < x.cand_cap ? want : (uint32_t)x.cand_cap;
-    const uint32_t i0 = blockIdx.x * (256u * EXACT_PER) + threadIdx.x;
-    if (blockIdx.x * (256u * EXACT_PER) >= n) return;  // whole block past the end of the slice
+    const uint32_t i0 = blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) + threadIdx.x;
+    if (blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) >= n) return;  // whole block past the end of the slice
     // Same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases out of the scanning
     // lane's registers (kssd_extract_carry) and whether all of them are known to be bases, so this stage is a streaming
     // read of 16-byte records plus two probes of the L2-resident cuckoo table; the packed stream is read again only for
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
     bool valid[EXACT_PER];
 #pragma unroll
     for (int j = 0; j < EXACT_PER; j++) {
-        const uint32_t i = i0 + 256u * j;
+        const uint32_t i = i0 + (uint32_t)EXACT_THREADS * j;
         ok[j] = i < n;
         cd[j] = ok[j] ? x.cand[(unsigned long long)w * x.cand_cap + i] : make_ulonglong2(0ull, 0ull);
     }
@@ -915,7 +916,9 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
         dr[j] = kssd_s2_tuple(P, u[j], h1 ? e1[j].rank : e2[j].rank);
     }
     // Survivors go to their genome's staging region.  Candidates arrive in stream order, so a wave's survivors almost
-    // always belong to ONE genome: then one returning atomic reserves room for all of them.
+    // always belong to ONE genome, and so do the workgroup's: then ONE returning atomic reserves room for all of them.
+    // (One per wave was enough for genome-sized sketches; a read set is one genome, and 34 000 waves queueing at one
+    // address took 0.45 ms for 8.6 M candidates.)
     uint64_t bal[EXACT_PER];
     uint32_t total = 0, g0 = 0;
     bool have = false, same = true;
@@ -929,11 +932,36 @@ __global__ __launch_bounds__(256) void sketch_exact_kernel(KssdParams P, ExactAr
             total += (uint32_t)__builtin_popcountll(bal[j]);
         }
     }
+    __shared__ uint32_t s_kind[EXACT_THREADS / 64], s_g[EXACT_THREADS / 64], s_tot[EXACT_THREADS / 64], s_base;
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0) { s_kind[wave] = have ? (same ? 1u : 2u) : 0u; s_g[wave] = g0; s_tot[wave] = total; }
+    __syncthreads();
+    bool wg_same = true;
+    uint32_t wg_g = 0xFFFFFFFFu, wg_before = 0, wg_total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < EXACT_THREADS / 64; k++) {
+        const uint32_t kind = s_kind[k];
+        if (kind == 2u) wg_same = false;
+        if (kind == 1u) {
+            if (wg_g == 0xFFFFFFFFu) wg_g = s_g[k];
+            else if (s_g[k] != wg_g) wg_same = false;
+            if (k < wave) wg_before += s_tot[k];
+            wg_total += s_tot[k];
+        }
+    }
+    if (wg_same && wg_total) {  // (workgroup-uniform)
+        if (threadIdx.x == 0) s_base = atomicAdd(&x.cursor[wg_g], wg_total);
+        __syncthreads();
+    }
     if (!have) return;
     if (same) {
         uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&x.cursor[g0], total);
-        at = __builtin_amdgcn_readfirstlane(at);
+        if (wg_same) {
+            at = s_base + wg_before;
+        } else {
+            if (lane == 0) at = atomicAdd(&x.cursor[g0], total);
+            at = __builtin_amdgcn_readfirstlane(at);
+        }
         const unsigned long long r0 = x.reg_off[g0], cap = x.reg_off[g0 + 1] - r0;
 #pragma unroll
         for (int j = 0; j < EXACT_PER; j++) {
@@ -1324,7 +1352,11 @@ __global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const K *__restri
             kv = a[i];
             v = KeyOps<K>::id(kv);
             if (i == 0 || KeyOps<K>::id(a[i - 1]) != v) {
-                unsigned long long lo = i + 1, hi = n;  // first index > i with a different tuple
+                // first index > i with a different tuple: gallop (runs are short -- one entry in a genome, a dozen in a read
+                // set -- and a bisection of the whole array is 22 dependent reads for every one of them), then bisect the last stride
+                unsigned long long lo = i + 1, d = 1;
+                while (lo + d - 1 < n && KeyOps<K>::id(a[lo + d - 1]) == v) { lo += d; d <<= 1; }
+                unsigned long long hi = lo + d - 1 < n ? lo + d - 1 : n;
                 while (lo < hi) {
                     const unsigned long long mid = (lo + hi) >> 1;
                     if (KeyOps<K>::id(a[mid]) == v) lo = mid + 1;
@@ -1349,8 +1381,13 @@ __global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const K *__restri
     }
     if (!WRITE) {
         if (threadIdx.x == 0) tile_cnt[blockIdx.x] = out_base;
-        if (distinct) atomicAdd(&acc[0], distinct);
-        if (zero_occ) atomicAdd(&acc[1], zero_occ);
+        uint32_t d_tot, z_tot;  // one atomic per workgroup, not one per thread
+        block_excl_scan(distinct, wsum, d_tot);
+        block_excl_scan(zero_occ, wsum, z_tot);
+        if (threadIdx.x == 0) {
+            if (d_tot) atomicAdd(&acc[0], d_tot);
+            if (z_tot) atomicAdd(&acc[1], z_tot);
+        }
     }
 }
 
@@ -1430,7 +1467,8 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
     const uint32_t g = blockIdx.x;
     const uint32_t n = kept[g];
     const unsigned long long r0 = reg_off[g], o0 = out_off[g];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    // gridDim.y > 1 when the batch holds a large genome (a read set's 262 570 ids copied by one workgroup: 154 us)
+    for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
         const K kv = regions[r0 + i];
         out_ids[o0 + i] = KeyOps<K>::id(kv);
         if (out_pos) out_pos[o0 + i] = KeyOps<K>::pos(kv);
@@ -1525,7 +1563,8 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     }
     hipLaunchKernelGGL(sketch_offsets_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)c->d_kept, n_genomes,
                        (unsigned long long *)d_out_off, (unsigned long long)out_cap, c->d_status);
-    hipLaunchKernelGGL((sketch_gather_kernel<K>), dim3(n_genomes), dim3(256), 0, s, (const unsigned long long *)c->d_reg_off,
+    hipLaunchKernelGGL((sketch_gather_kernel<K>), dim3(n_genomes, c->h_big.empty() ? 1u : (n_genomes < 64u ? 256u : 16u)), dim3(256), 0, s,
+                       (const unsigned long long *)c->d_reg_off,
                        (const K *)regions, (const uint32_t *)c->d_kept, (const unsigned long long *)d_out_off,
                        d_out_ids, d_out_pos, (const SketchStatus *)c->d_status);
     return KSSD_OK;
@@ -1716,9 +1755,9 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
     x.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
     x.status = c->d_status;
-    const dim3 grid((unsigned)((pl.cand_cap + 256 * EXACT_PER - 1) / (256 * EXACT_PER)), pl.n_slices);
-    if (pl.with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), grid, dim3(256), 0, s, c->P, x);
-    else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), grid, dim3(256), 0, s, c->P, x);
+    const dim3 grid((unsigned)((pl.cand_cap + EXACT_THREADS * EXACT_PER - 1) / (EXACT_THREADS * EXACT_PER)), pl.n_slices);
+    if (pl.with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), grid, dim3(EXACT_THREADS), 0, s, c->P, x);
+    else hipLaunchKernelGGL((sketch_exact_kernel<uint32_t>), grid, dim3(EXACT_THREADS), 0, s, c->P, x);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
