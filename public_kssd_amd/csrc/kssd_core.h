@@ -32,7 +32,7 @@ struct KssdParams {
     uint32_t comp_num; // iseq2comem.c:63-64
     uint32_t dim_end;  // accepted permutation ranks are [0, dim_end)          iseq2comem.c:74-76
     uint32_t hashsize, hashlimit;  // command_dist.c:217-236, iseq2comem.c:61
-    uint32_t g_log2;   // exact table G: two cuckoo halves of 2^g_log2 slots each
+    uint32_t g_log2;   // exact table G: 2^g_log2 buckets of two slots
     uint32_t g_mul[2]; // their multiplicative hashes (chosen by kssd_build_tables)
     uint64_t dim_mask; // 4*subk ones
 };
@@ -345,10 +345,31 @@ struct KssdG {  // one slot of the exact table: accepted sub-context -> permutat
     uint32_t rank;
 };
 
-// The exact table is a two-choice cuckoo table: G[0 .. 2^g_log2) is addressed by g_mul[0], G[2^g_log2 .. 2*2^g_log2)
-// by g_mul[1]; an accepted sub-context sits in exactly one of its two slots, so a lookup is two INDEPENDENT
-// 8-byte reads and never a probe loop (the scan kernel keeps them in flight across a whole chunk).
+// The exact table: 2^g_log2 buckets of TWO slots (16 bytes, one read).  An accepted sub-context sits in the bucket g_mul[0]
+// sends it to -- at a quarter load 98.6 % of the buckets hold all of theirs -- or, when that bucket was full, in the bucket
+// g_mul[1] names; bit 31 of a bucket's first rank word says "some key of this bucket went elsewhere", so that a lookup reads
+// the second bucket only then (1.4 % of the lookups).  (Round 2 until here: two-choice cuckoo with one-slot buckets,
+// two 8-byte reads per lookup in two different lines -- the exact stage is bound by the number of random reads the L2
+// takes per second, ~85 G/s: 8.6 M candidates of a read set took 210 us, the 2.9 M of the default batch 71.)
+#define KSSD_G_MOVED 0x80000000u
 KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t mul, uint32_t g_log2) { return (dim * mul) >> (32 - g_log2); }
+struct KssdGBucket {  // = KssdG[2]
+    uint32_t key0, rank0, key1, rank1;
+};
+// the bucket's verdict: 1 = found (rank set), 0 = not in the table, 2 = look into the second bucket
+KSSD_HD int kssd_g_match(const KssdGBucket &b, uint32_t dim, uint32_t &rank)
+{
+    if (b.key0 == dim) { rank = b.rank0 & ~KSSD_G_MOVED; return 1; }
+    if (b.key1 == dim) { rank = b.rank1; return 1; }
+    return (b.rank0 & KSSD_G_MOVED) ? 2 : 0;
+}
+KSSD_HD bool kssd_g_find(const KssdParams &P, const KssdG *__restrict__ G, uint32_t dim, uint32_t &rank)
+{
+    const KssdGBucket *B = reinterpret_cast<const KssdGBucket *>(G);
+    int r = kssd_g_match(B[kssd_g_slot(dim, P.g_mul[0], P.g_log2)], dim, rank);
+    if (r == 2) r = kssd_g_match(B[kssd_g_slot(dim, P.g_mul[1], P.g_log2)], dim, rank) == 1 ? 1 : 0;
+    return r == 1;
+}
 
 // Stage 2, arithmetic only.  fwd = the 2k bases of the k-mer (first base in the highest of the 4k bits);
 // u = canonical k-mer (iseq2comem.c:245), dim = its sub-context (:246).
@@ -406,10 +427,9 @@ KSSD_HD bool kssd_stage2(const KssdParams &P, int64_t s, int64_t lo_ok, int64_t 
     uint32_t dim;
     if (!kssd_s2_decode(P, packed[pw], packed[pw + 1], packed[pw + 2], mask[mw], mask[mw + 1], (uint32_t)b0, u, dim)) return false;
     // exact membership + rank (the reference reads the 16^subk-entry permutation here, :247-249)
-    const KssdG e1 = G[kssd_g_slot(dim, P.g_mul[0], P.g_log2)];
-    const KssdG e2 = G[(1u << P.g_log2) + kssd_g_slot(dim, P.g_mul[1], P.g_log2)];
-    if (e1.key != dim && e2.key != dim) return false;
-    dr_out = kssd_s2_tuple(P, u, e1.key == dim ? e1.rank : e2.rank);
+    uint32_t rank;
+    if (!kssd_g_find(P, G, dim, rank)) return false;
+    dr_out = kssd_s2_tuple(P, u, rank);
     return true;
 }
 
@@ -534,23 +554,26 @@ static inline void kssd_build_tables(KssdParams &P, const std::vector<uint32_t> 
         add_bloom(accepted[r]);
         add_bloom(rc);
     }
-    // two-choice cuckoo insertion; a walk that does not end picks new multipliers and starts over
-    const size_t half = (size_t)1 << P.g_log2;
+    // every key into the bucket its first multiplier names, or -- that one full -- into its second bucket, the first one marked;
+    // both full (it does not happen at a quarter load, but nothing forbids it): new multipliers, start over
+    const size_t nb = (size_t)1 << P.g_log2;
     uint64_t seed = 0x243F6A8885A308D3ull;
     for (int attempt = 0;; attempt++) {
-        G.assign(2 * half, KssdG{KSSD_EMPTY_KEY, 0});
+        G.assign(2 * nb, KssdG{KSSD_EMPTY_KEY, 0});
         bool ok = true;
         for (size_t r = 0; r < accepted.size() && ok; r++) {
-            KssdG cur{accepted[r], (uint32_t)r};
-            int side = 0;
+            const size_t b0 = kssd_g_slot(accepted[r], P.g_mul[0], P.g_log2), b1 = kssd_g_slot(accepted[r], P.g_mul[1], P.g_log2);
             ok = false;
-            for (int hop = 0; hop < 512; hop++) {
-                const size_t slot = side * half + kssd_g_slot(cur.key, P.g_mul[side], P.g_log2);
-                if (G[slot].key == KSSD_EMPTY_KEY) { G[slot] = cur; ok = true; break; }
-                const KssdG t = G[slot];
-                G[slot] = cur;
-                cur = t;
-                side ^= 1;
+            for (int pass = 0; pass < 2 && !ok; pass++) {
+                const size_t b = pass ? b1 : b0;
+                for (int k = 0; k < 2 && !ok; k++) {
+                    if (G[2 * b + k].key == KSSD_EMPTY_KEY) {
+                        G[2 * b + k].key = accepted[r];
+                        G[2 * b + k].rank = (G[2 * b + k].rank & KSSD_G_MOVED) | (uint32_t)r;  // (slot 0 may carry its bucket's mark already)
+                        ok = true;
+                    }
+                }
+                if (!ok && pass == 0) G[2 * b0].rank |= KSSD_G_MOVED;
             }
         }
         if (ok) break;

@@ -898,22 +898,24 @@ __global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams 
             }
         }
     }
-    KssdG e1[EXACT_PER], e2[EXACT_PER];
+    const KssdGBucket *GB = reinterpret_cast<const KssdGBucket *>(x.G);
+    KssdGBucket gb[EXACT_PER];  // one 16-byte read per candidate, all in flight together (kssd_core.h: the exact table)
     unsigned long long glo[EXACT_PER], ghi[EXACT_PER];
 #pragma unroll
     for (int j = 0; j < EXACT_PER; j++) {
-        e1[j] = x.G[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
-        e2[j] = x.G[(1u << P.g_log2) + kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)];
+        gb[j] = GB[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
         glo[j] = x.chunk_off[gid[j]] * KSSD_CHUNK;
         ghi[j] = x.chunk_off[gid[j] + 1] * KSSD_CHUNK;
     }
 #pragma unroll
     for (int j = 0; j < EXACT_PER; j++) {
         const long long s = (long long)cd[j].x, b0 = s - P.out;
-        const bool h1 = e1[j].key == dim[j], h2 = e2[j].key == dim[j];
-        ok[j] = ok[j] && valid[j] && (h1 || h2) && b0 >= (long long)glo[j] && b0 + P.nb <= (long long)ghi[j];
+        uint32_t rank = 0;
+        int hit = kssd_g_match(gb[j], dim[j], rank);
+        if (hit == 2) hit = kssd_g_match(GB[kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)], dim[j], rank) == 1 ? 1 : 0;  // (1.4 % of the buckets)
+        ok[j] = ok[j] && valid[j] && hit == 1 && b0 >= (long long)glo[j] && b0 + P.nb <= (long long)ghi[j];
         gpos[j] = (uint32_t)(s - (long long)glo[j]);  // first-position mode: genomes are < 2^32 positions there (checked on the host)
-        dr[j] = kssd_s2_tuple(P, u[j], h1 ? e1[j].rank : e2[j].rank);
+        dr[j] = kssd_s2_tuple(P, u[j], rank);
     }
     // Survivors go to their genome's staging region.  Candidates arrive in stream order, so a wave's survivors almost
     // always belong to ONE genome, and so do the workgroup's: then ONE returning atomic reserves room for all of them.
@@ -1183,23 +1185,23 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                         }
                     }
                 }
-                KssdG e1[FUSE_PER], e2[FUSE_PER];
+                const KssdGBucket *GB = reinterpret_cast<const KssdGBucket *>(fx.G);
+                KssdGBucket gb[FUSE_PER];
+#pragma unroll
+                for (int j = 0; j < FUSE_PER; j++) gb[j] = GB[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
 #pragma unroll
                 for (int j = 0; j < FUSE_PER; j++) {
-                    e1[j] = fx.G[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
-                    e2[j] = fx.G[(1u << P.g_log2) + kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)];
-                }
-#pragma unroll
-                for (int j = 0; j < FUSE_PER; j++) {
-                    const bool h1 = e1[j].key == dim[j], h2 = e2[j].key == dim[j];
-                    ok[j] = ok[j] && (h1 || h2);
+                    uint32_t rank = 0;
+                    int hit = kssd_g_match(gb[j], dim[j], rank);
+                    if (hit == 2) hit = kssd_g_match(GB[kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)], dim[j], rank) == 1 ? 1 : 0;
+                    ok[j] = ok[j] && hit == 1;
                     const uint64_t bal = __ballot(ok[j]);
                     if (bal) {  // one LDS atomic per wave reserves room for its survivors
                         uint32_t at = 0;
                         if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__builtin_popcountll(bal));
                         at = __builtin_amdgcn_readfirstlane(at) + rank_in(bal);
                         if (ok[j] && at < fx.lds_keys) {
-                            const uint32_t dr = kssd_s2_tuple(P, u[j], h1 ? e1[j].rank : e2[j].rank);
+                            const uint32_t dr = kssd_s2_tuple(P, u[j], rank);
                             const uint32_t gpos = (uint32_t)((long long)cd[j].x - glo);
                             a[at] = fx.by_pos ? KeyOps<K>::make(gpos, dr) : KeyOps<K>::make(dr, gpos);
                         }
