@@ -521,30 +521,68 @@ def run_fastq(a, shuf, dev):
 
 
 # ------------------------------------------------------------------------------------------------------
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, as children, BEFORE
+    anything in this process touches the GPU (never an exec from a process that has initialised HIP), relay rank 0's one
+    JSON line and the children's exit code.  Under `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set
+    and this function is not reached."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    log("[bench] --gpus %d without a launcher: starting %s" % (a.gpus, " ".join(cmd[1:10])))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in r.stdout.decode(errors="replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            log(ln)
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode != 0:
+        return r.returncode
+    return 0 if line is not None else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU")
-    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--genomes", type=int, default=None, help="genomes per GPU (allpairs: 1000; mammal: as many 3 Gb records as asked, default 8)")
+    ap.add_argument("--length", type=int, default=None, help="bases per genome (allpairs: 5 000 000; mammal: 3 000 000 000)")
     ap.add_argument("--clades", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
     ap.add_argument("--spinup", type=int, default=40, help="untimed steps before the warmup steps (GPU clock ramp; 0 = none)")
-    ap.add_argument("--workload", choices=["allpairs", "fastq"], default="allpairs",
+    ap.add_argument("--workload", choices=["allpairs", "fastq", "mammal"], default="allpairs",
                     help="allpairs = BASELINE configs[1] (the metric's config; configs[2] with --genomes 10000 --clades 500); "
-                         "fastq = configs[3]: reads -> read-set sketch -> containment against the reference sketches")
-    ap.add_argument("--partition", choices=["transpose", "query"], default="transpose",
-                    help="N > 1: transpose = own sketches indexed, all gathered sketches as query rows (all-pairs only, the index "
-                         "build stays constant per rank); query = the north_star partition, full index on every rank, own query block")
+                         "fastq = configs[3]: reads -> read-set sketch -> containment against the reference sketches; "
+                         "mammal = configs[4]: 3 Gb records at -k 10 -s 7 -l 5, sketch throughput")
+    ap.add_argument("--partition", choices=["both", "query", "transpose"], default="both",
+                    help="N > 1: query = the north_star partition (full index on every rank, own query block as rows): the headline; "
+                         "transpose = own sketches indexed, all gathered sketches as query rows (all-pairs only, the index build stays "
+                         "constant per rank); both (default) = query as the headline value, transpose measured beside it")
     ap.add_argument("--e2e-files", type=int, default=1024, help="files of the end-to-end / reference leg (the CPU sample under several names)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="fastq workload: reads of 150 bp")
     ap.add_argument("--parity-reads", type=int, default=10_000_000, help="fastq workload: reads of the oracle slice (0 = skip)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
                     help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial, the default; 3 = pipelined)")
     a = ap.parse_args()
+    if a.genomes is None:
+        a.genomes = 8 if a.workload == "mammal" else 1000
+    if a.length is None:
+        a.length = 3_000_000_000 if a.workload == "mammal" else 5_000_000
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)                             # nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -557,17 +595,24 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("KSSD_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; gloo only for the 1-GPU check
-        if backend == "nccl":
+        want = os.environ.get("KSSD_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI; gloo only for the 1-GPU check
+        if want == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(want)
+        backend = dist.get_backend()                      # what the line reports: the transport that really ran
 
     G, L = a.genomes, a.length
     NF = max(1, a.inflight)
+    if a.workload == "mammal":
+        if world != 1:
+            # the path shards by genome with no exchange: N ranks = N independent replicas of this run
+            log("[bench] --workload mammal on %d ranks: independent replicas, no collective" % world)
+        return run_mammal(a, dev, world, rank)
     shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
     if a.workload == "fastq":
         if world != 1:
@@ -592,179 +637,206 @@ def main():
     R = G * world
     from public_kssd_amd.shard import ShardedSearch
 
-    class Slot:
-        pass
-    slots = []
-    for j in range(NF):
-        sl = Slot()
-        sl.ctx = K.GpuCtx(shuf, local)
-        # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
-        sl.off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
-        sl.ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
-        sl.shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
-        sl.planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
-        sl.tstream = torch.cuda.Stream(device=dev) if NF > 1 else torch.cuda.current_stream()
-        sl.stream = sl.tstream.cuda_stream
-        sl.scanned, sl.sorted = torch.cuda.Event(), torch.cuda.Event()
-        sl.unit = cap
-        sl.search = ShardedSearch(world, rank, G, cap, dev, sl.ctx, partition=a.partition)
-        # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
-        # status read-back has told the host how many ids this batch really has
-        sl.idx_bound = cap
-        slots.append(sl)
-
-    def plan_prep(sl):
-        sl.ctx.sketch_plan(packed, mask, chunk_off, sl.off_l, sl.ids_l, cap, K.SKETCH_FASTA, 1)
-        sl.ctx.sketch_phase(K.PHASE_PREP, sl.stream)
-
-    def index_build(sl):
-        # the one exchange step of the path (N > 1): all-gather of every rank's packed sketches (RCCL over xGMI), then the
-        # index in the chosen partition (public_kssd_amd/shard.py).  The unit a rank contributes is its first sl.unit ids.
-        sl.search.index(sl.off_l, sl.ids_l[:sl.unit], sl.idx_bound, stream=sl.stream, tstream=sl.tstream if world > 1 else None)
-
-    def rows(sl):
-        sl.search.rows(sl.off_l, sl.ids_l[:sl.unit], sl.shared, sl.planes, stream=sl.stream)
-
-    def run_steps(n_steps):
-        """n_steps whole steps, pipelined over the NF slots; everything is enqueued, nothing synchronised"""
-        if NF < 3:
-            for n in range(n_steps):                      # back to back (NF = 2: two independent chains)
-                sl = slots[n % NF]
-                plan_prep(sl)
-                for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
-                    sl.ctx.sketch_phase(ph, sl.stream)
-                index_build(sl)
-                rows(sl)
-            return
-        if n_steps > 0:
-            plan_prep(slots[0])
-        for n in range(n_steps + 2):                      # two more rounds drain the pipeline
-            cur, prev, old = slots[n % NF], slots[(n - 1) % NF], slots[(n - 2) % NF]
-            if n < n_steps:
-                if n >= 2:
-                    cur.tstream.wait_event(old.sorted)    # the gap's LDS users are through (the rows of step n-3
-                cur.ctx.sketch_phase(K.PHASE_SCAN, cur.stream)   # precede this scan on its own stream)
-                cur.scanned.record(cur.tstream)
-            if 1 <= n <= n_steps:                         # step n-1: exact stage under scan n, sort after it
-                prev.ctx.sketch_phase(K.PHASE_EXACT, prev.stream)
-                if n < n_steps:
-                    prev.tstream.wait_event(cur.scanned)
-                prev.ctx.sketch_phase(K.PHASE_FINISH, prev.stream)
-                prev.sorted.record(prev.tstream)
-                index_build(prev)                         # runs under scan n+1
-            if n + 1 < n_steps:                           # setup of step n+1 ahead of the rows that share its stream
-                plan_prep(slots[(n + 1) % NF])
-            if 2 <= n:                                    # step n-2: all-pairs rows after scan n
-                if n < n_steps:
-                    old.tstream.wait_event(cur.scanned)
-                rows(old)
-
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # first calls size the workspaces of every context; retry if a staging region was too small
-    for sl in slots:
-        for attempt in range(6):
-            plan_prep(sl)
-            for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
-                sl.ctx.sketch_phase(ph, sl.stream)
-            index_build(sl)
-            rows(sl)
-            rc, total, bad = sl.ctx.sketch_status(sl.stream)
-            if rc == 0:
-                sl.idx_bound = min(cap, int(total) + 1024)
-                break
-            if rc != K.capi.ERR_OVERFLOW:
-                raise SystemExit("sketch failed: rc=%d" % rc)
-        else:
-            raise SystemExit("sketch kept overflowing")
-    sync()
-    if world > 1:
-        # the exchange unit shrinks from the padded capacity to what the fullest rank really holds (+ a margin): setup,
-        # untimed -- every step then gathers 20 % fewer bytes
-        need = torch.tensor([max(sl.idx_bound for sl in slots)], dtype=torch.int64, device=dev)
-        dist.all_reduce(need, op=dist.ReduceOp.MAX)
-        unit = min(cap, (int(need.item()) + 4096 + 1023) // 1024 * 1024)
+    def measure(partition):
+        """the whole measurement (sizing passes, spin-up, warm-up, the timed steps, the size-independent checks of the result)
+        in one partition of the matrix; returns the numbers and rank 0's tensors for the line"""
+        class Slot:
+            pass
+        slots = []
+        for j in range(NF):
+            sl = Slot()
+            sl.ctx = K.GpuCtx(shuf, local)
+            # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
+            sl.off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+            sl.ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
+            sl.shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
+            sl.planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
+            sl.tstream = torch.cuda.Stream(device=dev) if NF > 1 else torch.cuda.current_stream()
+            sl.stream = sl.tstream.cuda_stream
+            sl.scanned, sl.sorted = torch.cuda.Event(), torch.cuda.Event()
+            sl.unit = cap
+            sl.search = ShardedSearch(world, rank, G, cap, dev, sl.ctx, partition=partition)
+            # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
+            # status read-back has told the host how many ids this batch really has
+            sl.idx_bound = cap
+            slots.append(sl)
+
+        def plan_prep(sl):
+            sl.ctx.sketch_plan(packed, mask, chunk_off, sl.off_l, sl.ids_l, cap, K.SKETCH_FASTA, 1)
+            sl.ctx.sketch_phase(K.PHASE_PREP, sl.stream)
+
+        def index_build(sl):
+            # the one exchange step of the path (N > 1): all-gather of every rank's packed sketches (RCCL over xGMI), then the
+            # index in the chosen partition (public_kssd_amd/shard.py).  The unit a rank contributes is its first sl.unit ids.
+            sl.search.index(sl.off_l, sl.ids_l[:sl.unit], sl.idx_bound, stream=sl.stream, tstream=sl.tstream if world > 1 else None)
+
+        def rows(sl):
+            sl.search.rows(sl.off_l, sl.ids_l[:sl.unit], sl.shared, sl.planes, stream=sl.stream)
+
+        def run_steps(n_steps):
+            """n_steps whole steps, pipelined over the NF slots; everything is enqueued, nothing synchronised"""
+            if NF < 3:
+                for n in range(n_steps):                      # back to back (NF = 2: two independent chains)
+                    sl = slots[n % NF]
+                    plan_prep(sl)
+                    for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                        sl.ctx.sketch_phase(ph, sl.stream)
+                    index_build(sl)
+                    rows(sl)
+                return
+            if n_steps > 0:
+                plan_prep(slots[0])
+            for n in range(n_steps + 2):                      # two more rounds drain the pipeline
+                cur, prev, old = slots[n % NF], slots[(n - 1) % NF], slots[(n - 2) % NF]
+                if n < n_steps:
+                    if n >= 2:
+                        cur.tstream.wait_event(old.sorted)    # the gap's LDS users are through (the rows of step n-3
+                    cur.ctx.sketch_phase(K.PHASE_SCAN, cur.stream)   # precede this scan on its own stream)
+                    cur.scanned.record(cur.tstream)
+                if 1 <= n <= n_steps:                         # step n-1: exact stage under scan n, sort after it
+                    prev.ctx.sketch_phase(K.PHASE_EXACT, prev.stream)
+                    if n < n_steps:
+                        prev.tstream.wait_event(cur.scanned)
+                    prev.ctx.sketch_phase(K.PHASE_FINISH, prev.stream)
+                    prev.sorted.record(prev.tstream)
+                    index_build(prev)                         # runs under scan n+1
+                if n + 1 < n_steps:                           # setup of step n+1 ahead of the rows that share its stream
+                    plan_prep(slots[(n + 1) % NF])
+                if 2 <= n:                                    # step n-2: all-pairs rows after scan n
+                    if n < n_steps:
+                        old.tstream.wait_event(cur.scanned)
+                    rows(old)
+
+        # first calls size the workspaces of every context; retry if a staging region was too small
         for sl in slots:
-            sl.unit = unit
-            sl.search = ShardedSearch(world, rank, G, unit, dev, sl.ctx, partition=a.partition)
-            index_build(sl)
-            rows(sl)
+            for attempt in range(6):
+                plan_prep(sl)
+                for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                    sl.ctx.sketch_phase(ph, sl.stream)
+                index_build(sl)
+                rows(sl)
+                rc, total, bad = sl.ctx.sketch_status(sl.stream)
+                if rc == 0:
+                    sl.idx_bound = min(cap, int(total) + 1024)
+                    break
+                if rc != K.capi.ERR_OVERFLOW:
+                    raise SystemExit("sketch failed: rc=%d" % rc)
+            else:
+                raise SystemExit("sketch kept overflowing")
         sync()
-    # setup, untimed like the sizing passes above: the clocks of an idle GPU need some tens of milliseconds of work to
-    # settle (measured: the scan launch takes 0.54 ms in the first dozen steps after a pause and 0.52 ms from then on)
-    run_steps(a.spinup)
-    sync()
-    run_steps(a.warmup)
-    sync()
-    for sl in slots:
-        sl.ctx.kernel_time(0, reset=True)
-        sl.ctx.kernel_time(1, reset=True)
-    t0 = time.perf_counter()
-    run_steps(a.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    scan_ms = dist_ms = 0.0
-    scan_n = dist_n = 0
-    used = slots
-    for sl in used:
-        rc, total, bad = sl.ctx.sketch_status(sl.stream)
-        if rc != 0:
-            raise SystemExit("sketch status rc=%d after the timed loop" % rc)
-        ms, n = sl.ctx.kernel_time(0)
-        scan_ms += ms * n
-        scan_n += n
-        ms, n = sl.ctx.kernel_time(1)
-        dist_ms += ms * n
-        dist_n += n
-    scan_ms = scan_ms / scan_n if scan_n else 0.0       # average launch duration over every timed launch
-    dist_ms = dist_ms / dist_n if dist_n else 0.0
-    ctx, stream = slots[0].ctx, slots[0].stream
-    off_l, ids_l, shared = slots[0].off_l, slots[0].ids_l, slots[0].shared
-    n_stage1, n_bloom = ctx.scan_stats(stream)
-    for sl in used[1:]:                                   # every slot worked on the same batch: same results
-        assert torch.equal(sl.off_l, off_l) and torch.equal(sl.shared, shared), "slots disagree"
-        assert torch.equal(sl.ids_l[:int(total)], ids_l[:int(total)]), "slots disagree"
+        exchange_us = None
+        unit = cap
+        if world > 1:
+            # the exchange unit shrinks from the padded capacity to what the fullest rank really holds (+ a margin): setup,
+            # untimed -- every step then gathers 20 % fewer bytes
+            need = torch.tensor([max(sl.idx_bound for sl in slots)], dtype=torch.int64, device=dev)
+            dist.all_reduce(need, op=dist.ReduceOp.MAX)
+            unit = min(cap, (int(need.item()) + 4096 + 1023) // 1024 * 1024)
+            for sl in slots:
+                sl.unit = unit
+                sl.search = ShardedSearch(world, rank, G, unit, dev, sl.ctx, partition=partition)
+                index_build(sl)
+                rows(sl)
+            sync()
+        # setup, untimed like the sizing passes above: the clocks of an idle GPU need some tens of milliseconds of work to
+        # settle (measured: the scan launch takes 0.54 ms in the first dozen steps after a pause and 0.52 ms from then on)
+        run_steps(a.spinup)
+        sync()
+        run_steps(a.warmup)
+        sync()
+        for sl in slots:
+            sl.ctx.kernel_time(0, reset=True)
+            sl.ctx.kernel_time(1, reset=True)
+        t0 = time.perf_counter()
+        run_steps(a.steps)
+        sync()
+        dt = time.perf_counter() - t0
+        scan_ms = dist_ms = 0.0
+        scan_n = dist_n = 0
+        for sl in slots:
+            rc, total, bad = sl.ctx.sketch_status(sl.stream)
+            if rc != 0:
+                raise SystemExit("sketch status rc=%d after the timed loop" % rc)
+            ms, n = sl.ctx.kernel_time(0)
+            scan_ms += ms * n
+            scan_n += n
+            ms, n = sl.ctx.kernel_time(1)
+            dist_ms += ms * n
+            dist_n += n
+        scan_ms = scan_ms / scan_n if scan_n else 0.0       # average launch duration over every timed launch
+        dist_ms = dist_ms / dist_n if dist_n else 0.0
+        ctx, stream = slots[0].ctx, slots[0].stream
+        off_l, ids_l, shared = slots[0].off_l, slots[0].ids_l, slots[0].shared
+        n_stage1, n_bloom = ctx.scan_stats(stream)
+        for sl in slots[1:]:                                  # every slot worked on the same batch: same results
+            assert torch.equal(sl.off_l, off_l) and torch.equal(sl.shared, shared), "slots disagree"
+            assert torch.equal(sl.ids_l[:int(total)], ids_l[:int(total)]), "slots disagree"
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
 
-    # outside the timed region: the scan with nothing else on the device (sketch call alone, one stream), for the
-    # kernel's own roofline figure next to the one measured under the pipeline's contention
-    scan_alone_ms = None
-    if NF > 1 and world == 1:
-        sl = slots[0]
-        sl.ctx.kernel_time(0, reset=True)
-        for _ in range(5):
-            plan_prep(sl)
-            for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
-                sl.ctx.sketch_phase(ph, sl.stream)
-        torch.cuda.synchronize()
-        scan_alone_ms, _ = sl.ctx.kernel_time(0)
+        if world > 1:
+            # the exchange alone, untimed beside the steps: the two all-gathers + the unpacking kernel of one step, between
+            # events on the stream they run on, averaged over 20 rounds behind a barrier (max over ranks)
+            sl = slots[0]
+            g = sl.search.gather
+            ts = sl.tstream
+            for _ in range(3):
+                with torch.cuda.stream(ts):
+                    g(sl.off_l, sl.ids_l[:sl.unit], stream=sl.stream)
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(ts):
+                e0.record(ts)
+                for _ in range(20):
+                    g(sl.off_l, sl.ids_l[:sl.unit], stream=sl.stream)
+                e1.record(ts)
+            sync()
+            ex = torch.tensor([e0.elapsed_time(e1) * 1e3 / 20], dtype=torch.float64, device=dev)
+            dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+            exchange_us = float(ex.item())
 
-    if world > 1:
-        # size-independent check of the WHOLE distributed result, untimed: every rank's block gathered, the global matrix
-        # assembled as shard.py lays it out -- it must be symmetric and carry every rank's sketch sizes on its diagonal
-        # (the foreign rows of a rank are the transposes of other ranks' foreign rows: any rank computing a wrong block shows)
-        blocks = torch.zeros(world * G * R, dtype=torch.int32, device=dev)
-        sizes_all = torch.zeros(world * G, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(blocks, shared)
-        dist.all_gather_into_tensor(sizes_all, (off_l[1:] - off_l[:-1]).to(torch.int32).contiguous())
-        if a.partition == "query":
-            full = blocks.view(world * G, R)                       # rank r wrote rows [r*G, (r+1)*G) x all columns
+        # outside the timed region: the scan with nothing else on the device (sketch call alone, one stream), for the
+        # kernel's own roofline figure next to the one measured under the pipeline's contention
+        scan_alone_ms = None
+        if NF > 1 and world == 1:
+            sl = slots[0]
+            sl.ctx.kernel_time(0, reset=True)
+            for _ in range(5):
+                plan_prep(sl)
+                for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                    sl.ctx.sketch_phase(ph, sl.stream)
+            torch.cuda.synchronize()
+            scan_alone_ms, _ = sl.ctx.kernel_time(0)
+
+        if world > 1:
+            # size-independent check of the WHOLE distributed result, untimed: every rank's block gathered, the global matrix
+            # assembled as shard.py lays it out -- it must be symmetric and carry every rank's sketch sizes on its diagonal
+            # (the foreign rows of a rank are the transposes of other ranks' foreign rows: any rank computing a wrong block shows)
+            blocks = torch.zeros(world * G * R, dtype=torch.int32, device=dev)
+            sizes_all = torch.zeros(world * G, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(blocks, shared)
+            dist.all_gather_into_tensor(sizes_all, (off_l[1:] - off_l[:-1]).to(torch.int32).contiguous())
+            if partition == "query":
+                full = blocks.view(world * G, R)                       # rank r wrote rows [r*G, (r+1)*G) x all columns
+            else:
+                full = blocks.view(world, R, G).permute(1, 0, 2).reshape(R, R)   # rank r wrote [all rows] x its G columns
+            assert torch.equal(full.diagonal(), sizes_all), "N > 1: diagonal of the global matrix != the sketch sizes"
+            assert torch.equal(full, full.t()), "N > 1: the global all-pairs matrix is not symmetric"
+            checksum = int(full.to(torch.int64).sum().item())          # the same number in either partition
+            del blocks, full
         else:
-            full = blocks.view(world, R, G).permute(1, 0, 2).reshape(R, R)   # rank r wrote [all rows] x its G columns
-        assert torch.equal(full.diagonal(), sizes_all), "N > 1: diagonal of the global matrix != the sketch sizes"
-        assert torch.equal(full, full.t()), "N > 1: the global all-pairs matrix is not symmetric"
-        del blocks, full
-    if rank == 0:
+            checksum = int(shared.to(torch.int64).sum().item())
         # size-independent sanity on this rank's block of the matrix
         szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
-        if a.partition == "query":
+        if partition == "query":
             sh = shared.view(G, R)   # [this rank's genomes (query rows)] x [all genomes]
             own = sh[:, rank * G:(rank + 1) * G]
         else:
@@ -772,11 +844,43 @@ def main():
             own = sh[rank * G:(rank + 1) * G, :]
         assert torch.equal(own.diagonal(), szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
         assert torch.equal(own, own.t()), "all-pairs shared-count matrix must be symmetric"
+        res = dict(dt=dt, scan_ms=scan_ms, dist_ms=dist_ms, scan_n=scan_n, dist_n=dist_n, total=int(total), n_stage1=n_stage1,
+                   n_bloom=n_bloom, exchange_us=exchange_us, unit=unit, scan_alone_ms=scan_alone_ms, checksum=checksum,
+                   off=off_l.cpu().numpy(), ids=ids_l.cpu().numpy().view(np.uint32))
+        for sl in slots:
+            sl.ctx.close()
+        del slots
+        torch.cuda.empty_cache()
+        return res
+
+    PART_DESC = {"query": "full index on every rank, own query block as rows (north_star: query-sharded matrix, all-gather of the reference sketches)",
+                 "transpose": "own genomes indexed, all gathered sketches as query rows (transpose of the query block, all-pairs only)"}
+    if world == 1:
+        head_part, other_part = "query", None               # one GPU: both partitions are the same calls
+    elif a.partition == "both":
+        head_part, other_part = "query", "transpose"
+    else:
+        head_part, other_part = a.partition, None
+    m = measure(head_part)
+    other = measure(other_part) if other_part else None
+    if other is not None:
+        assert other["checksum"] == m["checksum"], "the two partitions assemble different matrices"
+    dt, scan_ms, dist_ms, total = m["dt"], m["scan_ms"], m["dist_ms"], m["total"]
+
+    if rank == 0:
         n_bases = G * L
         scan_bytes = 0.375 * n_bases + 4.0 * total        # 2-bit base + 1-bit mask, 4 B per id
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs = G * R
         dist_bytes = (4 if a.no_planes else 36) * pairs + 4.0 * (total + R / G * total)
+        if world > 1:
+            par = {"ranks": world, "backend": backend, "partition": head_part,
+                   "what": "genomes sharded x%d for sketching (no communication); ONE exchange per step: all-gather of the packed "
+                           "sketches (torch.distributed backend '%s'%s); partition '%s': %s"
+                           % (world, backend, " = RCCL over xGMI" if backend == "nccl" else " -- NOT RCCL: development check", head_part,
+                              PART_DESC[head_part])}
+        else:
+            par = "single GPU"
         res = {
             "metric": "genomes sketched/s (whole hot path per step: sketch + index + all-pairs distances, L3K10)",
             "value": world * G * a.steps / dt,
@@ -789,28 +893,38 @@ def main():
                                    "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
                        "pairs_per_step": world * pairs, "batches_in_flight": NF,
-                       "parallelism": ("genomes and matrix blocks sharded x%d, all-gather of sketches over RCCL; partition '%s': %s"
-                                       % (world, a.partition, "own genomes indexed, all gathered sketches as query rows (transpose of the "
-                                          "query block, all-pairs only)" if a.partition == "transpose" else
-                                          "full index on every rank, own query block as rows (north_star)")) if world > 1 else "single GPU"},
+                       "parallelism": par},
             "spinup": a.spinup,
             "pairs_per_s": world * pairs * a.steps / dt,
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
-            "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [scan_n, dist_n],
+            "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [m["scan_n"], m["dist_n"]],
                         "dist_rows_GBs": dist_bytes / (dist_ms * 1e-3) / 1e9 if dist_ms > 0 else None,
-                        "scan_positions_past_stage1": n_stage1 / n_bases, "scan_positions_past_bloom": n_bloom / n_bases},
+                        "scan_positions_past_stage1": m["n_stage1"] / n_bases, "scan_positions_past_bloom": m["n_bloom"] / n_bases},
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_launch": scan_bytes},
         }
-        if scan_alone_ms:
-            res["kernels"]["sketch_scan_ms_alone"] = scan_alone_ms
-            res["roofline"]["frac_alone"] = scan_bytes / (scan_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if world > 1:
+            res["backend"] = backend
+            res["ranks_seen"] = world
+            res["exchange"] = {"us": m["exchange_us"], "unit_ids_per_rank": m["unit"], "bytes_gathered_per_rank": world * (4 * m["unit"] + 8 * (G + 1)),
+                               "what": "two all_gather_into_tensor (offsets, padded id units) + the unpacking kernel, alone on the step's "
+                                       "stream, mean of 20, max over ranks"}
+            res["matrix_checksum"] = m["checksum"]
+            if other is not None:
+                res["partition_" + other_part] = {
+                    "value": world * G * a.steps / other["dt"], "unit": "genomes/s", "ms_per_step": other["dt"] / a.steps * 1e3,
+                    "pairs_per_s": world * pairs * a.steps / other["dt"], "exchange_us": other["exchange_us"],
+                    "sketch_scan_ms": other["scan_ms"], "dist_rows_ms": other["dist_ms"],
+                    "what": PART_DESC[other_part] + "; same steps / warmup / batch, measured after the headline; the assembled global "
+                            "matrix has the headline's checksum"}
+        if m["scan_alone_ms"]:
+            res["kernels"]["sketch_scan_ms_alone"] = m["scan_alone_ms"]
+            res["roofline"]["frac_alone"] = scan_bytes / (m["scan_alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if a.cpu_sample and world == 1 and kept:
-            ol = off_l.cpu().numpy()
-            il = ids_l.cpu().numpy().view(np.uint32)
+            ol, il = m["off"], m["ids"]
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
             cores = host_cores()
             cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files)
@@ -845,11 +959,11 @@ def main():
             except Exception as e:   # the leg is informational
                 res["pipelined"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
-    for sl in slots:
-        sl.ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -158,6 +158,14 @@ int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *ctx, uint32_t *d_out_pos);
  */
 int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *ctx, uint32_t max_tuples);
 
+/*
+ * Tuning knob of the scan: at most max_workgroups workgroups of 16 waves (0 = default, one per compute unit).  Every wave
+ * owns one contiguous run of the batch's chunks, so fewer workgroups mean longer runs per wave.  The results do not
+ * depend on it; the parity tests use it to give a wave more than 2 048 chunks at a size the oracle checks in seconds
+ * (what a 34 GB read set or a batch of mammalian genomes does on the full grid).
+ */
+int kssd_gpu_set_scan_grid(kssd_gpu_ctx *ctx, uint32_t max_workgroups);
+
 /* host-level convenience: HOST packed/mask in, malloc'd HOST CSR out (free with kssd_gpu_free) */
 int kssd_gpu_sketch_batch(kssd_gpu_ctx *ctx, const uint32_t *packed, const uint32_t *mask,
                           const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags,

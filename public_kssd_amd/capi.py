@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid",
 ]
 
 
@@ -143,6 +143,7 @@ def gpu_lib():
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
         L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
         L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
+        L.kssd_gpu_set_scan_grid.argtypes = [vp, u32]
         L.kssd_gpu_dist_multi.argtypes = [vp, i32, i32, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_device_count.restype = i32
         L.kssd_gpu_dist_select.argtypes = [vp, vp, vp, u32, vp, vp, u32, i32, i32, i32, C.c_double, i32, vp,
@@ -782,6 +783,10 @@ class GpuCtx:
     def set_lds_sort_limit(self, max_tuples):
         """genomes staging more tuples than this take the global-memory dedup path (0 = default); results unchanged"""
         _gck(gpu_lib().kssd_gpu_set_lds_sort_limit(self.h, max_tuples))
+
+    def set_scan_grid(self, max_workgroups):
+        """at most this many scan workgroups (0 = one per CU): longer chunk runs per wave; results unchanged"""
+        _gck(gpu_lib().kssd_gpu_set_scan_grid(self.h, max_workgroups))
 
     def scan_stats(self, stream=None):
         """(positions that passed the stage-1 filter, positions that also passed the Bloom test) of the last scan"""

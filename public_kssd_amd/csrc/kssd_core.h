@@ -134,33 +134,6 @@ KSSD_HD uint32_t kssd_grp_field(const uint32_t (&Wd)[5], const uint32_t (&V)[4],
 #endif
 }
 
-#if defined(KSSD_SCAN_PREDB) && defined(__HIPCC__)
-// experiment (libkssd_gpu_predb.so): the reads of alignment B only for the groups in which alignment A left a position
-// standing (plo/phi = A's answer masks, validity applied) -- B's other answers cannot matter.  Fewer active lanes per LDS
-// instruction (27 % on random sequence) mean fewer bank conflicts; the price is a compare and an exec-mask region per group.
-template <int SUBK, int GW, typename T1PTR>
-__device__ __forceinline__ void kssd_grp_issue_pred(const uint32_t (&Wd)[5], T1PTR T1, uint32_t plo, uint32_t phi,
-                                                    uint32_t (&raw)[KssdGrp<SUBK, GW>::NMAX])
-{
-    typedef KssdGrp<SUBK, GW> Gp;
-    uint32_t V[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) V[i] = __builtin_amdgcn_alignbit(Wd[i], Wd[i + 1], 16);
-    const volatile uint8_t *T1v = (const volatile uint8_t *)T1;  // volatile: the compiler must not hoist the read out of its condition
-#pragma unroll
-    for (int q = 0; q < Gp::NMAX; q++) {
-        raw[q] = 0;
-        if (q < Gp::NB) {
-            const int Q = Gp::QB0 + Gp::W * q, lo = Q < 0 ? 0 : Q, hi = Q + Gp::W - 1 > 63 ? 63 : Q + Gp::W - 1;
-            const unsigned long long bits = ((hi - lo + 1 >= 64) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
-            const uint32_t mlo = (uint32_t)bits, mhi = (uint32_t)(bits >> 32);
-            const uint32_t hit = (mlo ? (plo & mlo) : 0u) | (mhi ? (phi & mhi) : 0u);
-            if (hit) raw[q] = T1v[kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1))];
-        }
-    }
-}
-#endif
-
 // issue the table reads of one alignment (ALN 0 = A, 1 = B); raw[q] = answer bits of group q
 template <int SUBK, int GW, int ALN, typename T1PTR>
 KSSD_HD void kssd_grp_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[KssdGrp<SUBK, GW>::NMAX])
@@ -179,15 +152,7 @@ KSSD_HD void kssd_grp_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[K
     for (int q = 0; q < Gp::NMAX; q++) {
         if (q < Gp::count(ALN)) {
             const int Q = Gp::first(ALN) + Gp::W * q;
-#if defined(KSSD_SCAN_B64) && defined(__HIP_DEVICE_COMPILE__)
-            // experiment (libkssd_gpu_b64.so, profiles/scanbench_b64): the same byte out of an aligned 8-byte read.  ds_read_b64
-            // banks on (a/4) mod 64, but an 8-byte read occupies TWO of the 64 banks: 32 lanes still fall into 32 bins
-            const uint32_t idx = kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1));
-            const uint2 v8 = *reinterpret_cast<const uint2 *>(&T1[idx & ~7u]);
-            raw[q] = (((idx & 4u) ? v8.y : v8.x) >> ((idx & 3u) * 8u)) & 0xFFu;
-#else
             raw[q] = T1[kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1))];
-#endif
         } else {
             raw[q] = 0;
         }

@@ -108,6 +108,7 @@ struct kssd_gpu_ctx {
     uint32_t last_n_genomes;
     int last_launch_rc;
     uint32_t lds_sort_limit;  // kssd_gpu_set_lds_sort_limit (0 = DEDUP_MAX_N)
+    uint32_t scan_grid_limit; // kssd_gpu_set_scan_grid (0 = one workgroup per CU)
     std::vector<uint64_t> h_reg_off;
     std::vector<uint32_t> h_big;  // genomes of the last batch that take the global-memory dedup path
     // the planned call (kssd_gpu_sketch_plan), executed phase by phase (kssd_gpu_sketch_phase)
@@ -409,46 +410,6 @@ struct ScanArgs {
 };
 
 // one chunk of the lane's share of the stream: 64 positions + halo, and their validity bits
-#if defined(KSSD_SCAN_ASMLOAD)
-// The chunk loads as inline assembly with hand-placed s_waitcnt vmcnt(N).  Left to the compiler, the first of the four
-// unrolled steps waits with vmcnt(0) -- for the chunks c+2 and c+3 that have only just been requested -- because its
-// wait-count bookkeeping loses the order of the pending loads across the loop's back edge (and flushes in front of a loop
-// that stores and uses loaded registers).  Here the compiler does not know these are loads: the registers are the asm's
-// outputs, and chunk_wait<N> -- "at most N vector memory operations still in flight", the registers passed through it so
-// that no use can move in front of it -- is what makes them valid.  Three operations per chunk, issued in chunk order and
-// completing in order: the chunk requested two steps ago is complete when at most 6 are outstanding (stores the compiler
-// knows about only make that wait conservative).
-typedef uint32_t kssd_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t kssd_u32x2 __attribute__((ext_vector_type(2)));
-struct ChunkRegs {
-    kssd_u32x4 w;
-    uint32_t w4;
-    kssd_u32x2 m;
-};
-__device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long c, uint32_t lane, ChunkRegs &r)
-{
-    const uint32_t *bp = a.packed + c * 256;  // wave-uniform bases in SGPRs, the lane's offset in a VGPR
-    const uint32_t *bm = a.mask + c * 128;
-    const uint32_t o16 = lane * 16u, o8 = lane * 8u;
-    asm volatile("global_load_dword %0, %3, %5 offset:16\n\tglobal_load_dwordx4 %1, %3, %5\n\tglobal_load_dwordx2 %2, %4, %6"
-                 : "=&v"(r.w4), "=&v"(r.w), "=&v"(r.m)
-                 : "v"(o16), "v"(o8), "s"(bp), "s"(bm));
-}
-template <int N>
-__device__ __forceinline__ void chunk_wait(ChunkRegs &r)
-{
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r.w4), "+v"(r.w), "+v"(r.m) : "n"(N));
-}
-// behind the loop: the last two requests are never used, but they are still going to WRITE their registers -- all four
-// sets stay allocated (the asm "uses" them) until nothing is in flight any more
-__device__ __forceinline__ void chunk_drain(ChunkRegs &a, ChunkRegs &b, ChunkRegs &c, ChunkRegs &d)
-{
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(a.w4), "+v"(a.w), "+v"(a.m), "+v"(b.w4), "+v"(b.w), "+v"(b.m), "+v"(c.w4), "+v"(c.w), "+v"(c.m), "+v"(d.w4), "+v"(d.w),
-                   "+v"(d.m));
-}
-#define KSSD_CHUNK_WORDS_OF(r, WN, MN) const uint32_t WN[5] = {(r).w.x, (r).w.y, (r).w.z, (r).w.w, (r).w4}; const uint32_t MN[2] = {(r).m.x, (r).m.y}
-#else
 struct ChunkRegs {
     uint32_t W[5];
     uint32_t M[2];
@@ -463,11 +424,6 @@ __device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long
     const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + c * 128 + lane * 2);
     r.M[0] = m.x; r.M[1] = m.y;
 }
-template <int N>
-__device__ __forceinline__ void chunk_wait(ChunkRegs &) {}
-__device__ __forceinline__ void chunk_drain(ChunkRegs &, ChunkRegs &, ChunkRegs &, ChunkRegs &) {}
-#define KSSD_CHUNK_WORDS_OF(r, WN, MN) const uint32_t (&WN)[5] = (r).W; const uint32_t (&MN)[2] = (r).M
-#endif
 
 // A buffered stage-1 candidate (8 bytes in LDS):
 //   x  [11:0] position inside its chunk (lane << 6 | b)   [22:12] chunk - c0, modulo 2048 (entries live for a few chunks)
@@ -538,112 +494,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
 
-#if defined(KSSD_SCAN_LATELOOP)
-    // experiment: the candidate loop of a chunk runs ONE STEP LATER, under the table reads of both alignments of the
-    // following chunks: alignment B of chunk c (issued at the end of step c-1) and alignment A of chunk c+1 (issued at the top
-    // of step c) are in flight while the loop of chunk c-1 -- pure VALU work -- runs; nothing waits for an LDS answer right
-    // after asking for it.  Four register sets as before: c-1 (loop), c (masks), c+1 (table reads), c+2 (in flight from HBM).
-    ChunkRegs r0, r1, r2, r3;
-    uint32_t raw[Gp::NMAX];
-    uint32_t alo, ahi;
-    load_chunk(a, c0 < clast ? c0 : clast, lane, r1);
-    load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, r2);
-    load_chunk(a, c0 < clast ? c0 : clast, lane, r0);  // (set "c0 - 1" of the first step: never looked at, loaded to keep three requests per set)
-    for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
-        *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
-    __syncthreads();
-    if (c0 >= c1) return;
-    uint32_t s_tail = c0 ? __builtin_amdgcn_readfirstlane(a.packed[c0 * 256 - 1]) : 0u;  // the word in front of chunk c
-    uint32_t p_tail = 0, p_ebase = 0, pcl = 0, pch = 0;                                     // ... of chunk c-1, and its candidates
-    uint64_t vb_prev = 0;
-    chunk_wait<0>(r1);
-    {
-        KSSD_CHUNK_WORDS_OF(r1, w0, m0);
-        (void)m0;
-        kssd_grp_issue<SUBK, KSSD_GW, 0>(w0, T1, raw);
-        kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
-        kssd_grp_issue<SUBK, KSSD_GW, 1>(w0, T1, raw);
-    }
-    // the candidate loop of one chunk: W = its words, wm1 = the word in front of the lane's own, ebase = entry bits that
-    // do not depend on the candidate, crel_now = the chunk the wave is at (for a make-room round)
-    auto cand_loop = [&](const uint32_t (&W)[5], uint32_t wm1, uint32_t ebase, uint32_t cl, uint32_t ch, uint32_t crel_now) {
-        for (;;) {
-            const bool has = (cl | ch) != 0;
-            const uint64_t hbal = __ballot(has);
-            if (hbal == 0) break;
-            if (cn + 64 > CBUF) {  // dense parameter sets only: make room
-                wave_lds_sync();
-                const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel_now, cbuf, cn - 64, 64, stored, lane, abl_acc);
-                stored += m;
-                n_rounded += 64;
-                cn -= 64;
-                wave_lds_sync();
-            }
-            if (has) {
-                const bool in_lo = cl != 0;
-                const uint32_t word = in_lo ? cl : ch;
-                const uint32_t b = (uint32_t)__builtin_ctz(word) + (in_lo ? 0u : 32u);
-                const uint32_t rest = word & (word - 1u);
-                cl = in_lo ? rest : 0u;
-                ch = in_lo ? ch : rest;
-                uint32_t top32, front;
-                kssd_extract_carry<SUBK>(W, wm1, b, top32, front);
-                cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b | (front << 24), top32);
-            }
-            cn += __builtin_popcountll(hbal);
-        }
-    };
-    auto step = [&](const ChunkRegs &prev_r, const ChunkRegs &cur_r, ChunkRegs &nxt_r, ChunkRegs &far, const unsigned long long c) {
-        __builtin_amdgcn_s_setprio(3);
-        load_chunk(a, c + 2 < clast ? c + 2 : clast, lane, far);
-        chunk_wait<3>(nxt_r);
-        KSSD_CHUNK_WORDS_OF(prev_r, prevW, prevM);
-        KSSD_CHUNK_WORDS_OF(cur_r, curW, curM);
-        KSSD_CHUNK_WORDS_OF(nxt_r, nxtW, nxtM);
-        (void)prevM;
-        (void)nxtM;
-        uint32_t rawa[Gp::NMAX];
-        kssd_grp_issue<SUBK, KSSD_GW, 0>(nxtW, T1, rawa);  // alignment A of chunk c+1 goes in flight (B of chunk c already is)
-        const uint32_t crel = (uint32_t)(c - c0);
-        __builtin_amdgcn_s_setprio(0);
-        {   // chunk c-1: its candidates, under the table reads in flight
-            const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)p_tail, (int)prevW[3], 0x138, 0xf, 0xf, false);
-            cand_loop(prevW, wm1, p_ebase, pcl, pch, crel);
-        }
-        __builtin_amdgcn_s_setprio(2);
-        const uint64_t vb = __ballot((curM[0] & curM[1]) == 0xFFFFFFFFu);
-        uint32_t blo, bhi;
-        kssd_grp_merge<SUBK, KSSD_GW, 1>(raw, blo, bhi);
-        pcl = alo & blo & curM[0];
-        pch = ahi & bhi & curM[1];
-        const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);
-        p_ebase = ((crel & 2047u) << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
-        p_tail = s_tail;
-        s_tail = __builtin_amdgcn_readlane(curW[3], 63);
-        vb_prev = vb;
-        kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
-        if (cn >= 64) {
-            wave_lds_sync();
-            const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
-            stored += m;
-            n_rounded += 64;
-            cn -= 64;
-        }
-        kssd_grp_issue<SUBK, KSSD_GW, 1>(nxtW, T1, raw);
-        if (c + 1 >= c1) {  // the wave's last chunk: nobody comes after it to run its loop
-            __builtin_amdgcn_s_setprio(0);
-            const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)p_tail, (int)curW[3], 0x138, 0xf, 0xf, false);
-            cand_loop(curW, wm1, p_ebase, pcl, pch, crel);
-        }
-    };
-    for (unsigned long long c = c0; c < c1; c += 4) {
-        step(r0, r1, r2, r3, c);
-        if (c + 1 < c1) step(r1, r2, r3, r0, c + 1);
-        if (c + 2 < c1) step(r2, r3, r0, r1, c + 2);
-        if (c + 3 < c1) step(r3, r0, r1, r2, c + 3);
-    }
-    chunk_drain(r0, r1, r2, r3);
-#else
     // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
     // first reads overlaps the 144 KiB copy instead of following it
     ChunkRegs r0, r1, r2, r3;
@@ -665,18 +515,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint64_t vb_prev = 0;
 
     // prologue: chunk c0 through both alignments
-    chunk_wait<6>(r0);
-    {
-        KSSD_CHUNK_WORDS_OF(r0, w0, m0);
-        (void)m0;
-        kssd_grp_issue<SUBK, KSSD_GW, 0>(w0, T1, raw);
-        kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
-#if defined(KSSD_SCAN_PREDB)
-        kssd_grp_issue_pred<SUBK, KSSD_GW>(w0, T1, alo & m0[0], ahi & m0[1], raw);
-#else
-        kssd_grp_issue<SUBK, KSSD_GW, 1>(w0, T1, raw);  // alignment B of chunk c0 in flight
-#endif
-    }
+    kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
+    kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
+    kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of chunk c0 in flight
 
     // one chunk.  The four register sets rotate by name (the loop below is unrolled four times): copying one
     // set into another would make every iteration wait for the reads it has just issued.
@@ -690,11 +531,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         // table-read issue raised, 0.529 with everything but the loop at 2, 0.526 as it is here.
         __builtin_amdgcn_s_setprio(3);
         load_chunk(a, c + 3 < clast ? c + 3 : clast, lane, far);
-        chunk_wait<6>(nxt_r);  // chunk c+1 (requested two steps ago) is in; c+2 and c+3 stay in flight
-        KSSD_CHUNK_WORDS_OF(cur_r, curW, curM);
-        KSSD_CHUNK_WORDS_OF(nxt_r, nxtW, nxtM);
-        (void)nxtM;
-        const struct { const uint32_t (&W)[5]; const uint32_t (&M)[2]; } cur = {curW, curM}, nxt = {nxtW, nxtM};
+        const ChunkRegs &cur = cur_r, &nxt = nxt_r;  // chunk c+1 was requested two steps ago; c+2 and c+3 stay in flight
         const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
         uint32_t rawa[Gp::NMAX];
         if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
@@ -760,11 +597,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 n_rounded += 64;
                 cn -= 64;
             }
-#if defined(KSSD_SCAN_PREDB)
-            kssd_grp_issue_pred<SUBK, KSSD_GW>(nxt.W, T1, alo & nxt.M[0], ahi & nxt.M[1], raw);
-#else
+            if (ABL != 2 && ((uint32_t)(c - c0) & 2047u) == 2047u) {
+                // A round takes the NEWEST 64 entries, so the ones at the bottom of the buffer can wait for as long as the wave
+                // runs -- and an entry names its chunk modulo 2048 (bloom_round's `age`).  Every 2048 chunks the buffer is
+                // emptied: no entry is ever older than 2047 chunks, however many chunks a wave owns (a 34 GB read set, a batch
+                // of mammalian genomes: more than 2048 chunks per wave).  One partial round per 8.4 M positions.
+                while (cn) {
+                    const uint32_t n = cn < 64 ? cn : 64;
+                    wave_lds_sync();
+                    const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, (uint32_t)(c - c0), cbuf, cn - n, n, stored, lane, abl_acc);
+                    stored += m;
+                    n_rounded += n;
+                    cn -= n;
+                }
+            }
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
-#endif
         }
     };
     for (unsigned long long c = c0; c < c1; c += 4) {
@@ -773,8 +620,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         if (c + 2 < c1) step(r2, r3, r1, c + 2);
         if (c + 3 < c1) step(r3, r0, r2, c + 3);
     }
-    chunk_drain(r0, r1, r2, r3);
-#endif
     while (cn) {
         const uint32_t n = cn < 64 ? cn : 64;
         wave_lds_sync();
@@ -1657,7 +1502,8 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     // candidate list between the scan and the exact stage: patterns of S (both strands) + Bloom false positives
     // (one private slice per wave of the scan grid)
     const uint64_t want_blocks = (n_chunks + SCAN_WAVES - 1) / SCAN_WAVES;
-    const int grid = (int)(want_blocks < (uint64_t)c->cu_count ? want_blocks : (uint64_t)c->cu_count);
+    const uint64_t max_blocks = c->scan_grid_limit ? c->scan_grid_limit : (uint64_t)c->cu_count;
+    const int grid = (int)(want_blocks < max_blocks ? want_blocks : max_blocks);
     const uint32_t n_slices = (uint32_t)(grid > 0 ? grid : 1) * SCAN_WAVES;
     uint64_t cand_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * (2.0 * rate + 0.0005) * c->cand_factor / n_slices) + 256;
     if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
@@ -1816,6 +1662,13 @@ extern "C" int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *c, uint32_t max_tuples)
 {
     if (!c) return KSSD_ERR_PARAM;
     c->lds_sort_limit = max_tuples;
+    return KSSD_OK;
+}
+
+extern "C" int kssd_gpu_set_scan_grid(kssd_gpu_ctx *c, uint32_t max_workgroups)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    c->scan_grid_limit = max_workgroups;
     return KSSD_OK;
 }
 

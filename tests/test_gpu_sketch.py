@@ -448,3 +448,41 @@ def test_low_complexity_megabases_overflow_and_retry(shuf_l3k10):
                 assert np.array_equal(ids2[int(off2[g]):int(off2[g + 1])], np.sort(sk.fasta(t))), g
     finally:
         ctx.close()
+
+
+def test_a_wave_that_owns_more_than_2048_chunks(shuf_l3k10):
+    """A buffered stage-1 candidate names its chunk modulo 2048 and a Bloom round takes the newest 64 entries: without the
+    periodic drain the entries at the bottom of a wave's buffer are attributed to a chunk 2048 k too late once the wave owns
+    more than 2048 chunks (a 34 GB read set, a batch of mammalian genomes on the full grid).  Here: ONE scan workgroup
+    (kssd_gpu_set_scan_grid) over 40 000 chunks = 2 500 per wave, with a long N stretch in the middle so that entries wait
+    across a candidate-free run, against the oracle and against the default grid."""
+    rng = np.random.default_rng(2048)
+    n = 40_000 * 4096 - 1000
+    codes = rng.integers(0, 4, n, dtype=np.uint8)
+    nm = np.zeros(n, dtype=bool)
+    nm[rng.integers(0, n, 300)] = True
+    text = fasta_text(codes, b"long", n_mask=nm)
+    # a second genome: bases, then 12 Mb of N written as one stretch (one invalid position in the batch), then bases again
+    c2 = rng.integers(0, 4, 30_000_000, dtype=np.uint8)
+    t2 = fasta_text(c2[:9_000_000], b"gap") + b"N" * 12_000_000 + b"\n" + fasta_text(c2[9_000_000:], b"x")[len(b">x\n"):]
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    want = [np.sort(sk.fasta(text)), np.sort(sk.fasta(t2))]
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        b = K.Batch()
+        b.add_fasta(text)
+        b.add_fasta(t2)
+        assert b.n_chunks > 16 * 2048
+        res = {}
+        for grid in (1, 0):
+            ctx.set_scan_grid(grid)
+            off, ids = ctx.sketch_batch(b)
+            res[grid] = (off.copy(), ids.copy())
+            for g in range(2):
+                got = ids[int(off[g]):int(off[g + 1])]
+                assert np.array_equal(got, want[g]), (grid, g, len(got), len(want[g]))
+        assert np.array_equal(res[0][1], res[1][1])
+        b.close()
+    finally:
+        ctx.set_scan_grid(0)
+        ctx.close()
