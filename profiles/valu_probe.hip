@@ -20,6 +20,10 @@ __global__ __launch_bounds__(1024) void probe(uint32_t *out, unsigned long long 
     for (uint32_t i = threadIdx.x; i < 32768; i += blockDim.x) lds[i] = i * 2654435761u + seed;
     __syncthreads();
     uint32_t a[8], b = threadIdx.x * 2654435761u + seed, c = seed ^ 0x5bd1e995u;
+    unsigned long long d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = (unsigned long long)b * (i + 5) + seed;
+    asm volatile("s_mov_b64 s[10:11], %0" : : "s"((unsigned long long)seed * 0x9E3779B97F4A7C15ull) : "s10", "s11");
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = b * (i + 3);
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -40,7 +44,23 @@ __global__ __launch_bounds__(1024) void probe(uint32_t *out, unsigned long long 
     if (OP == 12) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));                                      \
     if (OP == 13) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a[i]));                                                       \
     if (OP == 14) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));     \
-    if (OP == 15) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+    if (OP == 15) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));                                   \
+    if (OP == 16) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(b) : "s10", "s11");           \
+    if (OP == 17) asm volatile("v_cndmask_b32_e64 %0, 0, 1, s[10:11]" : "=v"(a[i]) : : "s10", "s11");                     \
+    if (OP == 18) asm volatile("v_cmp_gt_u32_e64 s[10:11], %0, %1" : : "v"(a[i]), "v"(b) : "s10", "s11");                  \
+    if (OP == 19) asm volatile("v_cmp_gt_u32_e64 s[10:11], %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(a[i]) : "v"(b) : "s10", "s11"); \
+    if (OP == 20) asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(d[i]) : "v"(b & 31));                                    \
+    if (OP == 21) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));                          \
+    if (OP == 22) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                                  \
+    if (OP == 23) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                              \
+    if (OP == 24) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i]));                                                    \
+    if (OP == 25) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));                                                  \
+    if (OP == 26) asm volatile("v_bfe_i32 %0, %0, 4, 1" : "+v"(a[i]));                                                     \
+    if (OP == 27) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                              \
+    if (OP == 28) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xc8" : "+v"(a[i]) : "v"(b), "v"(c));                    \
+    if (OP == 29) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                                 \
+    if (OP == 30) asm volatile("v_readlane_b32 s10, %0, 63" : : "v"(a[i]) : "s10");                                        \
+    if (OP == 31) asm volatile("s_nop 0");
         REP8(ONE)
         REP8(ONE)
         if (OP >= 8 && OP <= 11) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); b += a[0] & 0xFF; }
@@ -49,7 +69,7 @@ __global__ __launch_bounds__(1024) void probe(uint32_t *out, unsigned long long 
     const unsigned long long t1 = __builtin_readcyclecounter();
     uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc ^= a[i];
+    for (int i = 0; i < 8; i++) acc ^= a[i] ^ (uint32_t)d[i] ^ (uint32_t)(d[i] >> 32);
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
     if ((threadIdx.x & 63) == 0) ticks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
@@ -102,6 +122,22 @@ int main()
         run<13>("v_ffbl_b32", threads);
         run<14>("v_mov_b32 dpp wave_shr", threads);
         run<15>("v_mbcnt_lo", threads);
+        run<16>("v_cndmask_e64 sgpr", threads);
+        run<17>("v_cndmask_e64 0,1,sgpr", threads);
+        run<18>("v_cmp_gt_u32_e64 sgpr", threads);
+        run<19>("v_cmp+s_nop+v_cndmask", threads);
+        run<20>("v_lshlrev_b64", threads);
+        run<21>("v_lshl_add_u64", threads);
+        run<22>("v_or3_b32", threads);
+        run<23>("v_xor_b32", threads);
+        run<24>("v_lshrrev_b32", threads);
+        run<25>("v_mov_b32", threads);
+        run<26>("v_bfe_i32", threads);
+        run<27>("v_min_u32", threads);
+        run<28>("v_bitop3_b32", threads);
+        run<29>("v_perm_b32", threads);
+        run<30>("v_readlane_b32", threads);
+        run<31>("s_nop 0", threads);
         run<8>("ds_bpermute_b32", threads);
         run<9>("ds_permute_b32", threads);
         run<10>("ds_read_u8 random", threads);

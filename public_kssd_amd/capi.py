@@ -288,8 +288,10 @@ class SketchSet:
         assert self.counts is None or len(self.counts) == len(self.ids)
 
     def _c(self):
-        self._nm = b"".join(os.fsencode(n).ljust(256, b"\0")[:256] for n in self.names) or b"\0"
-        self._nmbuf = C.create_string_buffer(self._nm, len(self._nm))
+        nm = b"".join(os.fsencode(n).ljust(256, b"\0")[:256] for n in self.names) or b"\0"
+        if getattr(self, "_nm", None) != nm:  # (a set passed as both arguments of one call must not replace the buffer the first struct points into)
+            self._nm = nm
+            self._nmbuf = C.create_string_buffer(nm, len(nm))
         self._ids = self.ids if len(self.ids) else np.zeros(1, np.uint32)
         koc = self.counts is not None
         self._cnt = (self.counts if len(self.counts) else np.zeros(1, np.uint16)) if koc else None

@@ -284,7 +284,12 @@ KSSD_HD void kssd_extract_carry(const uint32_t (&W)[5], uint32_t Wm1, uint32_t b
     // two select levels on the 96-bit window instead of three 4-way selects (7 v_cndmask / v_bfi instead of 9): bit 5 of b
     // picks four consecutive words, bit 4 three of those; then one 64-bit shift each for the 16 bases and for the 4 bases
     // in front (a v_bfe_u32 at offset 32 - sh would be cheaper but wraps to offset 0 when sh = 0)
-    const uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 4, 1), s2 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 5, 1);
+    uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 4, 1), s2 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 5, 1);
+    // The masks are made opaque: knowing that they are all ones or all zeros, the compiler rewrites every bitwise select
+    // below as v_cmp + v_cndmask_b32 with an SGPR-pair condition -- and on gfx950 a v_cndmask_b32 issues four to five times
+    // slower than a v_bfi_b32 (profiles/r03a_valu_probe.txt: 12 against 2.8 cycles per wave instruction and SIMD at four
+    // waves).  Eleven of them per candidate pass were a third of the scan kernel's time.
+    asm volatile("" : "+v"(s1), "+v"(s2));
 #define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
     const uint32_t x0 = KSSD_BSEL(s2, W[1], Wm1), x1 = KSSD_BSEL(s2, W[2], W[0]), x2 = KSSD_BSEL(s2, W[3], W[1]), x3 = KSSD_BSEL(s2, W[4], W[2]);
     const uint32_t pre = KSSD_BSEL(s1, x1, x0), hi = KSSD_BSEL(s1, x2, x1), lo = KSSD_BSEL(s1, x3, x2);

@@ -576,9 +576,114 @@ int kssd_index_read(kssd_sketchset *s, const char *dir)
 /* ---- distance report ------------------------------------------------------------------------------------ */
 static inline double dist_arg(int metric, double m) { return metric == 0 ? 1 / (2 * m) + 0.5 : 1 / m; }
 
-/* one line of distance.out, the arithmetic and the formats of output_ctrl (command_dist.c:1251-1287) */
-static int format_line(char *buf, size_t cap, const char *qn, const char *rn, uint32_t X, uint32_t Y, uint32_t s,
-                       int kmerlen, int dim_rd_len, const kssd_print_opt *o, uint64_t cmprsn)
+/*
+ * Number formatting of the report.  The reference prints every number of a line with snprintf ("%.6lf", "%E",
+ * command_dist.c:1269-1286); the C library formats a double through arbitrary-precision arithmetic, and with eight
+ * numbers per line that was most of the report's time.  The two formats are produced here exactly as the library
+ * produces them -- the digits of the double's exact binary value, rounded to nearest, ties to even -- by integer
+ * arithmetic: "%.6lf" exactly (128-bit product of the mantissa and 10^6), "%E" through an 80-bit scaling whose error
+ * is bounded and a hand-over to snprintf whenever the scaled value is within 2^-20 of a rounding boundary (one value
+ * in a million).  Anything unusual (nan, inf, subnormals, |x| >= 1e12 for "%.6lf") goes to snprintf as well.  The
+ * arithmetic that produces the numbers (log, pow, erfc) stays the host libm's.
+ */
+static inline char *put_uint(char *p, uint64_t v)
+{
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
+static inline char *put_digits(char *p, uint32_t v, int n) /* exactly n digits, zero padded */
+{
+    for (int i = n - 1; i >= 0; i--) { p[i] = (char)('0' + v % 10); v /= 10; }
+    return p + n;
+}
+
+char *kssd_fmt_f6(char *p, double x) /* "%.6lf" */
+{
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    const int ef = (int)((b >> 52) & 0x7FF);
+    if (ef == 0x7FF || ef >= 1023 + 39) return p + sprintf(p, "%.6lf", x); /* nan, inf, |x| >= 2^39 */
+    if (b >> 63) *p++ = '-';
+    uint64_t M = b & 0x000FFFFFFFFFFFFFull;
+    int E;
+    if (ef) { M |= 1ull << 52; E = ef - 1075; } else E = -1074;
+    /* |x| * 10^6 = M * 10^6 * 2^E, E < 0: integer part and remainder of a 128-bit product */
+    const unsigned __int128 P = (unsigned __int128)M * 1000000u;
+    const int sh = -E;
+    uint64_t N = 0;
+    if (sh < 128) {
+        N = (uint64_t)(P >> sh);
+        const unsigned __int128 rem = P & ((((unsigned __int128)1) << sh) - 1), half = ((unsigned __int128)1) << (sh - 1);
+        if (rem > half || (rem == half && (N & 1))) N++;
+    }
+    p = put_uint(p, N / 1000000u);
+    *p++ = '.';
+    return put_digits(p, (uint32_t)(N % 1000000u), 6);
+}
+
+static long double pow10_tab[700]; /* 10^(i - 340) */
+static int pow10_ready;
+static void pow10_init(void)
+{
+#pragma omp critical(kssd_pow10)
+    {
+        if (!pow10_ready) {
+            for (int i = 0; i < 700; i++) pow10_tab[i] = powl(10.0L, (long double)(i - 340));
+            __atomic_store_n(&pow10_ready, 1, __ATOMIC_RELEASE);
+        }
+    }
+}
+
+char *kssd_fmt_e6(char *p, double x) /* "%E" */
+{
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    const int ef = (int)((b >> 52) & 0x7FF);
+    if (ef == 0x7FF || (ef == 0 && (b << 1))) return p + sprintf(p, "%E", x); /* nan, inf, subnormal */
+    if (b >> 63) *p++ = '-';
+    if (ef == 0) { memcpy(p, "0.000000E+00", 12); return p + 12; }
+    if (!__atomic_load_n(&pow10_ready, __ATOMIC_ACQUIRE)) pow10_init();
+    const long double ax = (long double)fabs(x);
+    const int e2 = ef - 1023;                                      /* |x| = m * 2^e2, 1 <= m < 2 */
+    int d = (int)floor((double)e2 * 0.30102999566398120);          /* floor(log10 |x|) or one less */
+    long double s = ax * pow10_tab[6 - d + 340];                   /* in [10^6, 10^8): 7 or 8 digits in front of the point */
+    int unsure = fabsl(s - 9999999.5L) < 0x1p-20L;                 /* "9.999999" or "1.000000" of the next decade? */
+    if (!unsure && s > 9999999.5L) {
+        d++;
+        s = ax * pow10_tab[6 - d + 340];                           /* in [10^6 - 0.05, 10^7) */
+    }
+    const long double fl = floorl(s), fr = s - fl;
+    if (unsure || fabsl(fr - 0.5L) < 0x1p-20L || s < 999999.9L) { /* too close to a tie for the 80-bit product: the library decides */
+        if (b >> 63) p--;
+        return p + sprintf(p, "%E", x);
+    }
+    uint32_t N = (uint32_t)fl + (fr > 0.5L ? 1u : 0u);
+    if (N >= 10000000u) { N = 1000000u; d++; }
+    *p++ = (char)('0' + N / 1000000u);
+    *p++ = '.';
+    p = put_digits(p, N % 1000000u, 6);
+    *p++ = 'E';
+    *p++ = d < 0 ? '-' : '+';
+    const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+    return ad >= 100 ? put_digits(p, ad, 3) : put_digits(p, ad, 2);
+}
+
+/* what a line without shared k-mers looks like behind its names and sizes: the same bytes for every such pair of one
+ * report (metric 0, distance 1, "-NAN" p-values, "[inf,inf]"), formatted once by the library */
+typedef struct {
+    int len;
+    char txt[160];
+    double sqrt_half; /* pow(0.5, 0.5) of this libm, computed once per report */
+} zero_tail;
+
+/* one line of distance.out exactly as output_ctrl writes it (command_dist.c:1251-1287): the library's bounded formatting.
+ * Used for lines whose names leave no room for the fast path and, once per report, for the tail of the lines without
+ * shared k-mers.  force: skip the -D test (the tail is wanted whatever the threshold) */
+static int format_line_lib(char *buf, size_t cap, const char *qn, const char *rn, uint32_t X, uint32_t Y, uint32_t s, int kmerlen,
+                           int dim_rd_len, const kssd_print_opt *o, uint64_t cmprsn, int force)
 {
     double rs = 0;
     if (o->correction) {
@@ -591,7 +696,7 @@ static int format_line(char *buf, size_t cap, const char *qn, const char *rn, ui
     double m = ((double)s - rs) / den;
     double d = log(dist_arg(o->metric, m)) / kmerlen;
     if (d > 1) d = 1;
-    if (d > o->dthreshold) return 0;
+    if (!force && d > o->dthreshold) return 0;
     int len = snprintf(buf, cap, "%s\t%s\t%u-%u|%u|%u\t%.6lf\t%.6lf", qn, rn, s, (uint32_t)rs, X, Y, m, d);
     if ((size_t)len >= cap) len = (int)cap - 1;
     if (o->pfield > 0) {
@@ -609,6 +714,64 @@ static int format_line(char *buf, size_t cap, const char *qn, const char *rn, ui
     len += snprintf(buf + len, cap - (size_t)len, "\n");
     if ((size_t)len >= cap) len = (int)cap - 1;
     return len;
+}
+
+/* one line of distance.out, the arithmetic and the formats of output_ctrl (command_dist.c:1251-1287) */
+static int format_line(char *buf, size_t cap, const char *qn, size_t qlen, const char *rn, size_t rlen, uint32_t X, uint32_t Y, uint32_t s,
+                       int kmerlen, int dim_rd_len, const kssd_print_opt *o, uint64_t cmprsn, const zero_tail *zt)
+{
+    double rs = 0;
+    if (o->correction) {
+        uint32_t xo = X - s, yo = Y - s;
+        double miss = 1 - 1 / pow((double)4, (double)(kmerlen - dim_rd_len));
+        double px = 1 - pow(miss, (double)xo), py = 1 - pow(miss, (double)yo);
+        rs = px * py * (uint32_t)(xo + yo) / (px + py - 2 * px * py);
+    }
+    uint32_t den = o->metric == 0 ? X + Y - s : (X < Y ? X : Y);
+    char *p = buf;
+    const int roomy = qlen + rlen + 220 <= cap;
+    if (roomy && zt && s == 0 && den != 0 && !o->correction) { /* nothing shared: the constant tail */
+        if (1.0 > o->dthreshold) return 0;
+        memcpy(p, qn, qlen); p += qlen; *p++ = '\t';
+        memcpy(p, rn, rlen); p += rlen; *p++ = '\t';
+        memcpy(p, "0-0|", 4); p += 4;
+        p = put_uint(p, X); *p++ = '|';
+        p = put_uint(p, Y);
+        memcpy(p, zt->txt, (size_t)zt->len);
+        return (int)(p - buf) + zt->len;
+    }
+    double m = ((double)s - rs) / den;
+    double d = log(dist_arg(o->metric, m)) / kmerlen;
+    if (d > 1) d = 1;
+    if (d > o->dthreshold) return 0;
+    if (!roomy) return format_line_lib(buf, cap, qn, rn, X, Y, s, kmerlen, dim_rd_len, o, cmprsn, 0);
+    memcpy(p, qn, qlen); p += qlen; *p++ = '\t';
+    memcpy(p, rn, rlen); p += rlen; *p++ = '\t';
+    p = put_uint(p, s); *p++ = '-';
+    p = put_uint(p, (uint32_t)rs); *p++ = '|';
+    p = put_uint(p, X); *p++ = '|';
+    p = put_uint(p, Y); *p++ = '\t';
+    p = kssd_fmt_f6(p, m); *p++ = '\t';
+    p = kssd_fmt_f6(p, d);
+    if (o->pfield > 0) {
+        const double sqrt_half = zt ? zt->sqrt_half : pow(0.5, 0.5); /* command_dist.c:1273 */
+        double sd = pow(m * (1 - m) / den, 0.5);
+        double pv = 0.5 * erfc(m / sd * sqrt_half);
+        *p++ = '\t';
+        p = kssd_fmt_e6(p, pv); *p++ = '\t';
+        p = kssd_fmt_e6(p, pv * cmprsn);
+        if (o->pfield > 1) {
+            double m1 = m - 1.96 * sd, m2 = m + 1.96 * sd;
+            double d1 = log(dist_arg(o->metric, m2)) / kmerlen, d2 = log(dist_arg(o->metric, m1)) / kmerlen;
+            *p++ = '\t'; *p++ = '[';
+            p = kssd_fmt_f6(p, m1); *p++ = ',';
+            p = kssd_fmt_f6(p, m2); *p++ = ']'; *p++ = '\t'; *p++ = '[';
+            p = kssd_fmt_f6(p, d1); *p++ = ',';
+            p = kssd_fmt_f6(p, d2); *p++ = ']';
+        }
+    }
+    *p++ = '\n';
+    return (int)(p - buf);
 }
 
 typedef struct {
@@ -664,64 +827,96 @@ static int print_rows(const char *path, const uint32_t *shared, const uint64_t *
     const uint64_t cmprsn = (uint32_t)(R * Q); /* 32-bit product like command_dist.c:1186 */
     const int kmerlen = qry->kmerlen, drl = qry->dim_rd_len;
     int threads = o->threads > 0 ? o->threads : 1;
-    const uint32_t QB = 64; /* queries formatted per parallel batch, written back in order */
-    strbuf *sb = calloc(QB, sizeof(strbuf));
-    int nomem = 0;
-    if (!sb) { fclose(f); return KSSD_HOST_ERR_NOMEM; }
-    for (uint32_t q0 = 0; q0 < Q; q0 += QB) {
-        const uint32_t q1 = q0 + QB < Q ? q0 + QB : Q;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-        for (uint32_t q = q0; q < q1; q++) {
-            strbuf *b = &sb[q - q0];
-            b->n = 0;
-            char line[1024];
-            const uint32_t *row = shared ? shared + (size_t)q * R : NULL;
-            const uint64_t nrow = row ? R : poff[q + 1] - poff[q]; /* entries of this row */
-            const uint32_t *rr = row ? NULL : pr + poff[q], *rs = row ? NULL : ps + poff[q];
-#define ROW_REF(i) (row ? (uint32_t)(i) : rr[i])
-#define ROW_SHARED(i) (row ? row[i] : rs[i])
-            const uint32_t Y = (uint32_t)(qry->off[q + 1] - qry->off[q]);
-            if (o->n_max) { /* -N: the n_max largest raw metrics, earlier reference wins ties (:1212-1227) */
-                double bm[1026];
-                int bi[1026];
-                for (int i = 0; i < o->n_max; i++) { bm[i] = 0; bi[i] = -1; }
-                uint32_t bs[1026];
-                for (uint64_t e = 0; e < nrow; e++) {
-                    const uint32_t r = ROW_REF(e), s = ROW_SHARED(e);
-                    const uint32_t X = (uint32_t)(ref->off[r + 1] - ref->off[r]);
-                    const double m = o->metric == 1 ? (double)s / (X < Y ? X : Y) : (double)s / (X + Y - s);
-                    for (int i = o->n_max - 1; i >= 0; i--) {
-                        if (m > bm[i]) { bm[i + 1] = bm[i]; bi[i + 1] = bi[i]; bs[i + 1] = bs[i]; bm[i] = m; bi[i] = (int)r; bs[i] = s; }
-                        else break;
-                    }
-                }
-                for (int i = 0; i < o->n_max; i++) {
-                    if (bi[i] < 0) continue;
-                    const uint32_t r = (uint32_t)bi[i];
-                    int len = format_line(line, sizeof line, qry->names[q], ref->names[r],
-                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, bs[i], kmerlen, drl, o, cmprsn);
-                    if (len > 1) sb_add(b, line, (size_t)len);
-                }
-            } else {
-                for (uint64_t e = 0; e < nrow; e++) {
-                    const uint32_t r = ROW_REF(e);
-                    int len = format_line(line, sizeof line, qry->names[q], ref->names[r],
-                                          (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, ROW_SHARED(e), kmerlen, drl, o, cmprsn);
-                    if (len > 1) sb_add(b, line, (size_t)len);
-                }
-            }
-#undef ROW_REF
-#undef ROW_SHARED
-        }
-        for (uint32_t q = q0; q < q1; q++) {
-            if (sb[q - q0].failed) nomem = 1;
-            if (sb[q - q0].n) fwrite(sb[q - q0].p, 1, sb[q - q0].n, f);
+    /* the tail of every line without shared k-mers, from the library's own formatting of one such pair */
+    zero_tail zt;
+    {
+        volatile double half = 0.5;
+        zt.sqrt_half = pow(half, half);
+        char tmp[512];
+        const int n = format_line_lib(tmp, sizeof tmp, "", "", 1, 1, 0, kmerlen, drl, o, cmprsn, 1);
+        static const char pre[] = "\t\t0-0|1|1";
+        zt.len = 0;
+        if (n > (int)sizeof pre - 1 && n - (int)(sizeof pre - 1) < (int)sizeof zt.txt && memcmp(tmp, pre, sizeof pre - 1) == 0) {
+            zt.len = n - (int)(sizeof pre - 1);
+            memcpy(zt.txt, tmp + sizeof pre - 1, (size_t)zt.len);
         }
     }
-    for (uint32_t i = 0; i < QB; i++) free(sb[i].p);
+    uint32_t *rlen = malloc(((size_t)R + 1) * sizeof *rlen);
+    const uint32_t QB = 64; /* queries formatted per parallel batch, written back in order */
+    strbuf *sb = calloc(2 * (size_t)QB, sizeof(strbuf)); /* two batches: one is written while the next one is formatted */
+    int nomem = 0, ioerr = 0;
+    if (!sb || !rlen) { free(sb); free(rlen); fclose(f); return KSSD_HOST_ERR_NOMEM; }
+    for (uint32_t r = 0; r < R; r++) rlen[r] = (uint32_t)strlen(ref->names[r]);
+    fflush(f);
+#pragma omp parallel num_threads(threads)
+    {
+        int par = 0;
+        for (uint32_t q0 = 0; q0 < Q; q0 += QB, par ^= 1) {
+            const uint32_t q1 = q0 + QB < Q ? q0 + QB : Q;
+            strbuf *bat = sb + (size_t)par * QB;
+#pragma omp for schedule(dynamic, 1) nowait
+            for (uint32_t q = q0; q < q1; q++) {
+                strbuf *b = &bat[q - q0];
+                b->n = 0;
+                char line[1024];
+                const char *qn = qry->names[q];
+                const size_t qlen = strlen(qn);
+                const uint32_t *row = shared ? shared + (size_t)q * R : NULL;
+                const uint64_t nrow = row ? R : poff[q + 1] - poff[q]; /* entries of this row */
+                const uint32_t *rr = row ? NULL : pr + poff[q], *rs = row ? NULL : ps + poff[q];
+#define ROW_REF(i) (row ? (uint32_t)(i) : rr[i])
+#define ROW_SHARED(i) (row ? row[i] : rs[i])
+                const uint32_t Y = (uint32_t)(qry->off[q + 1] - qry->off[q]);
+                if (o->n_max) { /* -N: the n_max largest raw metrics, earlier reference wins ties (:1212-1227) */
+                    double bm[1026];
+                    int bi[1026];
+                    for (int i = 0; i < o->n_max; i++) { bm[i] = 0; bi[i] = -1; }
+                    uint32_t bs[1026];
+                    for (uint64_t e = 0; e < nrow; e++) {
+                        const uint32_t r = ROW_REF(e), s = ROW_SHARED(e);
+                        const uint32_t X = (uint32_t)(ref->off[r + 1] - ref->off[r]);
+                        const double m = o->metric == 1 ? (double)s / (X < Y ? X : Y) : (double)s / (X + Y - s);
+                        for (int i = o->n_max - 1; i >= 0; i--) {
+                            if (m > bm[i]) { bm[i + 1] = bm[i]; bi[i + 1] = bi[i]; bs[i + 1] = bs[i]; bm[i] = m; bi[i] = (int)r; bs[i] = s; }
+                            else break;
+                        }
+                    }
+                    for (int i = 0; i < o->n_max; i++) {
+                        if (bi[i] < 0) continue;
+                        const uint32_t r = (uint32_t)bi[i];
+                        int len = format_line(line, sizeof line, qn, qlen, ref->names[r], rlen[r],
+                                              (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, bs[i], kmerlen, drl, o, cmprsn, &zt);
+                        if (len > 1) sb_add(b, line, (size_t)len);
+                    }
+                } else {
+                    for (uint64_t e = 0; e < nrow; e++) {
+                        const uint32_t r = ROW_REF(e);
+                        int len = format_line(line, sizeof line, qn, qlen, ref->names[r], rlen[r],
+                                              (uint32_t)(ref->off[r + 1] - ref->off[r]), Y, ROW_SHARED(e), kmerlen, drl, o, cmprsn, &zt);
+                        if (len > 1) sb_add(b, line, (size_t)len);
+                    }
+                }
+#undef ROW_REF
+#undef ROW_SHARED
+            }
+            /* everybody has formatted its rows of this batch -- and the batch before it has been written: the thread that
+             * wrote it cannot have arrived here before it was done */
+#pragma omp barrier
+#pragma omp single nowait
+            {   /* one thread writes the batch, the others go on with the next one (the other set of buffers) */
+                for (uint32_t q = q0; q < q1; q++) {
+                    if (bat[q - q0].failed) nomem = 1;
+                    if (bat[q - q0].n && fwrite(bat[q - q0].p, 1, bat[q - q0].n, f) != bat[q - q0].n) ioerr = 1;
+                }
+            }
+        }
+    }
+    for (uint32_t i = 0; i < 2 * QB; i++) free(sb[i].p);
     free(sb);
+    free(rlen);
     if (nomem) { fclose(f); return KSSD_HOST_ERR_NOMEM; }
-    return fclose(f) == 0 ? KSSD_HOST_OK : KSSD_HOST_ERR_IO;
+    if (fclose(f) != 0 || ioerr) return KSSD_HOST_ERR_IO;
+    return KSSD_HOST_OK;
 }
 
 /* ---- kssd reverse ------------------------------------------------------------------------------------- */

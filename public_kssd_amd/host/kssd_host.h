@@ -188,6 +188,12 @@ int kssd_distance_print(const char *path, const uint32_t *shared, const kssd_ske
 int kssd_distance_print_pairs(const char *path, const uint64_t *pair_off, const uint32_t *pair_ref, const uint32_t *pair_shared,
                               const kssd_sketchset *ref, const kssd_sketchset *qry, const kssd_print_opt *opt);
 
+/* the report's two number formats, byte for byte what the C library's "%.6lf" / "%E" write (exact integer arithmetic,
+ * the library itself for non-finite and borderline values); p must have room for 32 bytes when |x| < 2^39 or the format
+ * is "%E", for 330 otherwise; returns the end of the text */
+char *kssd_fmt_f6(char *p, double x);
+char *kssd_fmt_e6(char *p, double x);
+
 #ifdef __cplusplus
 }
 #endif
