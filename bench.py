@@ -196,10 +196,15 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
                            "buffers on the host threads, raw text H2D, tokenised on the device, sketch kernels, D2H, slot order, "
                            "combco.* written -- wall time of the command, the better of two runs (HIP start-up varies by ~0.1 s from "
                            "process to process)", "sample": fa_desc, "stages": tm, "seconds_runs": runs}
-            dt2, _ = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist", "--keepskf", "our_sk"], d)
-            e2e["search"] = {"value": nf * nf / dt2, "unit": "pairs/s", "seconds": dt2,
-                             "what": "`kssd dist -r <sketches> -o <dir> <sketches>`: %d x %d all-pairs incl. reading the sketches, the device "
-                                     "search and the distance.out text (%d MB) on %d host threads"
+            dt2a, tm2a = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist0", "our_sk"], d, {"KSSD_TIMING": "1"})
+            dt2, tm2 = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist", "our_sk"], d, {"KSSD_TIMING": "1"})
+            runs2 = [dt2a, dt2]
+            if dt2a < dt2:
+                dt2, tm2 = dt2a, tm2a
+            e2e["search"] = {"value": nf * nf / dt2, "unit": "pairs/s", "seconds": dt2, "seconds_runs": runs2, "stages": tm2,
+                             "what": "`kssd dist -r <sketches> -o <dir> <sketches>`: %d x %d all-pairs incl. process start, reading the "
+                                     "sketches, the device search and the distance.out text (%d MB) on %d host threads -- the same command "
+                                     "line the reference is timed with below; wall time of the command, the better of two runs"
                                      % (nf, nf, os.path.getsize(os.path.join(d, "our_dist", "distance.out")) >> 20, cores)}
             out["end_to_end"] = e2e
         # ---- the real reference binary when the snapshot carries it ----
@@ -223,8 +228,11 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
             ko.run_ref(["dist", "-p", p_srch, "-o", "ref_idx", "ref_sk"], cwd=d, timeout=1800)
             t_idx = time.time() - t0
             t0 = time.time()
+            ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist0", "ref_sk"], cwd=d, timeout=1800)
+            t_srch0 = time.time() - t0
+            t0 = time.time()
             ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", "ref_sk"], cwd=d, timeout=1800)
-            t_srch = time.time() - t0
+            t_srch = min(time.time() - t0, t_srch0)      # the better of two runs, like ours (the second one keeps sharedk_ct.dat for the parity check)
             out["dist_reference"] = {"value": nf * nf / t_srch, "unit": "pairs/s", "cores": p_srch, "kind": "reference",
                                      "sample": "%d x %d all-pairs of the reference's own sketches of those files: `kssd dist -r <mco> "
                                                "--keepskf <co>` wall time incl. distance.out text; its stage II (2 GiB mco.index, "

@@ -152,6 +152,14 @@ int kssd_gpu_scan_stats(kssd_gpu_ctx *ctx, uint64_t *stage1, uint64_t *bloom, vo
 int kssd_gpu_sketch_set_pos_output(kssd_gpu_ctx *ctx, uint32_t *d_out_pos);
 
 /*
+ * Process start-up, no counterpart in the reference: initialises the HIP runtime, the device's context and this
+ * library's code object on `device` (0.1 - 0.2 s per process on the measurement box).  Callable from any thread; a
+ * command that has host work to do first (reading sketch directories, opening inputs) runs it on a thread of its own so
+ * that the first real call does not pay for it.  KSSD_ERR_NO_DEVICE without a usable device.
+ */
+int kssd_gpu_warm_up(int device);
+
+/*
  * Tuning knob of the per-genome dedup: genomes whose staging region holds more than max_tuples tuples are sorted
  * in global memory instead of in one workgroup's LDS (default and upper limit: 32 768 four-byte keys; 0 = default).
  * The results do not depend on it; the parity tests use it to send small genomes down the large-genome path.

@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up",
 ]
 
 
@@ -256,6 +256,18 @@ class Shuf:
             return cls((s.id, s.k, s.subk, s.drlevel), t)
         finally:
             host_lib().kssd_shuf_release(C.byref(s))
+
+    @staticmethod
+    def read_core(path):
+        """(header tuple, accepted u32[dim_end], from_cache) -- what the command line loads of a .shuf (kssd_shuf_read_core)"""
+        s = _Shuf()
+        acc, n, cached = C.c_void_p(), C.c_uint32(0), C.c_int(0)
+        _hck(host_lib().kssd_shuf_read_core(os.fsencode(path), C.byref(s), C.byref(acc), C.byref(n), C.byref(cached)))
+        try:
+            a = np.frombuffer((C.c_char * (4 * n.value)).from_address(acc.value), dtype=np.uint32).copy()
+        finally:
+            C.CDLL(None).free(acc)
+        return (s.id, s.k, s.subk, s.drlevel), a, bool(cached.value)
 
     def write(self, path):
         s = _Shuf(self.id, self.k, self.subk, self.drlevel, self.table.ctypes.data_as(C.POINTER(C.c_int32)))

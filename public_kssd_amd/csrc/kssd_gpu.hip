@@ -305,6 +305,20 @@ extern "C" int kssd_gpu_device_count(void)
     return n;
 }
 
+__global__ void warm_up_kernel(uint32_t *p) { if (p) *p = 1; }
+
+extern "C" int kssd_gpu_warm_up(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KSSD_ERR_NO_DEVICE;
+    HIPCK(hipSetDevice(device));
+    HIPCK(hipFree(nullptr));  // the device's context
+    hipLaunchKernelGGL(warm_up_kernel, dim3(1), dim3(64), 0, 0, (uint32_t *)nullptr);  // the library's code object onto the device
+    HIPCK(hipGetLastError());
+    HIPCK(hipDeviceSynchronize());
+    return KSSD_OK;
+}
+
 template <typename T>
 static int ensure(T **p, size_t *cap, size_t need, size_t slack = 0)
 {

@@ -31,8 +31,11 @@
 
 #define VERSION "kssd-mi355x 0.1 (formats and results of KSSD version 1.2.21)"
 
+static char g_unlink_on_die[KSSD_PATHLEN + 64]; /* a file this run created and has not finished (sharedk_ct.dat) */
+
 static void die(int code, const char *fmt, ...)
 {
+    if (g_unlink_on_die[0]) unlink(g_unlink_on_die);
     va_list ap;
     va_start(ap, fmt);
     fprintf(stderr, "kssd: ");
@@ -227,8 +230,17 @@ static void gck(int rc, const char *what)
     if (rc != KSSD_OK) die(rc == KSSD_ERR_CAPACITY ? ENOSPC : EIO, "%s: %s", what, kssd_gpu_strerror(rc));
 }
 
-/* the .shuf of this run: -L <file>, or a fresh default.shuf in the output directory (get_dim_shuffle, command_dist.c:193-216) */
-static void load_shuf(const dist_opt *o, kssd_shuf *s)
+/* the .shuf of this run: -L <file>, or a fresh default.shuf in the output directory (get_dim_shuffle, command_dist.c:193-216).
+ * What comes back is the header and the accepted sub-contexts -- all the sketch path looks at (kssd_shuf_read_core: from the
+ * .core file beside the .shuf when there is one, so that a run does not start by reading 64 MiB or 1 GiB for 16 KiB of it) */
+typedef struct {
+    kssd_shuf h; /* table == NULL */
+    uint32_t *accepted;
+    uint32_t n_accepted;
+    int from_cache;
+} shuf_core;
+
+static void load_shuf(const dist_opt *o, shuf_core *s)
 {
     char path[KSSD_PATHLEN + 16];
     if (o->dr_file[0]) {
@@ -246,8 +258,16 @@ static void load_shuf(const dist_opt *o, kssd_shuf *s)
         printf("kssd shuffle: shuf_id=%d, k = %d, halfCtxLen = %d, level= %d\n", g.id, g.k, g.subk, g.drlevel);
         kssd_shuf_release(&g);
     }
-    int rc = kssd_shuf_read(s, path);
+    int rc = kssd_shuf_read_core(path, &s->h, &s->accepted, &s->n_accepted, &s->from_cache);
     if (rc) die(EIO, "read_dim_shuffle_file(): %s: %s", path, kssd_host_strerror(rc));
+}
+
+/* HIP initialisation (driver, device context, code object) costs 0.1 - 0.2 s per process: started on a thread of its own
+ * at the top of a command, it runs while the command reads its .shuf or its sketch directories */
+static void *warm_device(void *arg)
+{
+    kssd_gpu_warm_up(*(const int *)arg); /* (a missing device is reported by the call that needs it) */
+    return NULL;
 }
 
 /* ---------------------------------------------------------------------------------------------------
@@ -589,7 +609,8 @@ typedef struct {
     filelist *fl;
     uint32_t hashsize;
     kssd_shuf_hdr hdr;
-    const int32_t *table;
+    const uint32_t *accepted; /* the .shuf's accepted sub-contexts (load_shuf) */
+    uint32_t n_accepted;
     double t_ctx_destroy;
     double t_ctx;   /* the slowest worker's context creation (HIP initialisation, code object load, table upload) */
     double t_gpu;   /* summed over the workers: seconds inside process_job */
@@ -608,7 +629,7 @@ static void *worker_main(void *arg)
     pipeline *pl = w->pl;
     kssd_gpu_ctx *ctx = NULL;
     const double tc0 = now_s();
-    gck(kssd_gpu_create(&ctx, &pl->hdr, pl->table, w->device), "kssd_gpu_create");
+    gck(kssd_gpu_create_compact(&ctx, &pl->hdr, pl->accepted, pl->n_accepted, w->device), "kssd_gpu_create");
     pthread_mutex_lock(&pl->mu);
     if (now_s() - tc0 > pl->t_ctx) pl->t_ctx = now_s() - tc0;
     pthread_mutex_unlock(&pl->mu);
@@ -669,15 +690,16 @@ static int cmp_job(const void *a, const void *b)
  * gzip'ed input is unpacked; the reference opens --byread inputs without zcat and scans the compressed bytes.) */
 static void sketch_files_byread(const dist_opt *o, filelist *fl, const char *outdir)
 {
-    kssd_shuf shuf;
-    load_shuf(o, &shuf);
+    shuf_core sc;
+    load_shuf(o, &sc);
+    const kssd_shuf shuf = sc.h;
     kssd_derived d;
     if (kssd_derive(&d, shuf.k, shuf.subk, shuf.drlevel))
         die(EINVAL, "get_hashsz(): primer_ind out of range(0 ~ 24): this might caused by too small or too large k (k=%d, level=%d)", shuf.k, shuf.drlevel);
     printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
-    gck(kssd_gpu_create(&g_ctx, &hdr, shuf.table, o->device), "kssd_gpu_create");
-    kssd_shuf_release(&shuf);
+    gck(kssd_gpu_create_compact(&g_ctx, &hdr, sc.accepted, sc.n_accepted, o->device), "kssd_gpu_create");
+    free(sc.accepted);
     kssd_batch *b = kssd_batch_create();
     for (int i = 0; i < fl->n; i++) {
         printf("decomposing %s by reads\n", fl->path[i]);
@@ -732,14 +754,20 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     oa.abundance = abundance;
     o = &oa;
     if (abundance) printf("running mt_shortreads2koc()\n");
-    kssd_shuf shuf;
-    load_shuf(o, &shuf);
+    const double t_start = now_s();
+    pthread_t warm;
+    int warm_dev = o->device;
+    const int warming = pthread_create(&warm, NULL, warm_device, &warm_dev) == 0; /* under the .shuf read */
+    shuf_core sc;
+    load_shuf(o, &sc);
+    const kssd_shuf shuf = sc.h;
     kssd_derived d;
     if (kssd_derive(&d, shuf.k, shuf.subk, shuf.drlevel))
         die(EINVAL, "get_hashsz(): primer_ind out of range(0 ~ 24): this might caused by too small or too large k (k=%d, level=%d)", shuf.k, shuf.drlevel);
     printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
-    const double t_start = now_s();
+    const double t_shuf = now_s() - t_start;
+    if (warming) pthread_join(warm, NULL);
     int n_dev = o->gpus > 0 ? o->gpus : 1;
     {
         const int have = kssd_gpu_device_count();
@@ -756,7 +784,8 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pl.fl = fl;
     pl.hashsize = d.hashsize;
     pl.hdr = hdr;
-    pl.table = shuf.table;
+    pl.accepted = sc.accepted;
+    pl.n_accepted = sc.n_accepted;
     const int n_batches = n_workers + 1; /* one being filled, one per worker */
     pl.pool = calloc((size_t)n_batches, sizeof *pl.pool);
     for (int i = 0; i < n_batches; i++) {
@@ -931,7 +960,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pthread_mutex_unlock(&pl.mu);
     for (int i = 0; i < n_workers; i++) pthread_join(ws[i].th, NULL);
     printf("\n");
-    kssd_shuf_release(&shuf);
+    free(sc.accepted);
     const double t_sketched = now_s();
 
     /* the jobs' results in file order */
@@ -983,9 +1012,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     free(s.counts);
     if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
         fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
-                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
+                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
                         "\"s_workers_summed\": %.6f, \"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
-                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_read, t_tok,
+                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_shuf, sc.from_cache, t_read, t_tok,
                 pl.t_gpu, pl.t_call, now_s() - t_sketched);
 }
 
@@ -1005,6 +1034,10 @@ static void build_index_files(const char *codir, const char *mcodir)
 /* search (mco_cbdco_nobin_dist + dist_print_nobin, command_dist.c:670-808,1161-1250) */
 static void search(const dist_opt *o, const char *refdir, const char *qrydir)
 {
+    const double t_start = now_s();
+    pthread_t warm;
+    int warm_dev = o->device;
+    const int warming = !o->skf[0] && pthread_create(&warm, NULL, warm_device, &warm_dev) == 0;
     kssd_sketchset ref, qry;
     int rc;
     if (kssd_probe_dir(refdir) & 1) rc = kssd_sketchset_read(&ref, refdir);
@@ -1015,17 +1048,22 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
         die(EINVAL, "query args not match ref args: ref.comp_num = %d vs. %d = qry.comp_num", ref.comp_num, qry.comp_num);
     if (ref.shuf_id != qry.shuf_id)
         die(EINVAL, "query args not match ref args: ref.shuf_id = %d vs. %d = qry.shuf_id", (int)ref.shuf_id, (int)qry.shuf_id);
+    const double t_read = now_s();
     mkdir(o->outdir, 0700);
     char skf[KSSD_PATHLEN + 32], distf[KSSD_PATHLEN + 32];
     snprintf(skf, sizeof skf, "%s/sharedk_ct.dat", o->outdir);
     snprintf(distf, sizeof distf, "%s/distance.out", o->outdir);
     const size_t cells = (size_t)ref.n * qry.n;
-    /* the count matrix lives in the file itself, mapped like the reference maps it (command_dist.c:741-748): Q x R may
-     * exceed the host's memory, the device works it off in row tiles (kssd_gpu_dist) */
+    /* With --keepskf the count matrix lives in the file itself, mapped like the reference maps it (command_dist.c:741-748):
+     * Q x R may exceed the host's memory, the device works it off in row tiles (kssd_gpu_dist).  Without it the reference
+     * removes the file when the report is written (:1249), so it is never created here: the counts stay in anonymous
+     * memory.  A selecting report (-N / -D) that does not keep the file needs no dense matrix on the host at all. */
     uint32_t *shared = NULL;
     uint64_t *pair_off = NULL;
     uint32_t *pair_ref = NULL, *pair_shared = NULL;
     int skfd = -1;
+    const int selecting = !o->skf[0] && (o->num_neigb > 0 || o->mut_dist_max < 1.0);
+    double t_ctx = 0, t_dist = 0;
     if (o->skf[0]) { /* -f: reuse a kept shared-k-mer file (command_dist.c:735-738) */
         skfd = open(o->skf, O_RDONLY);
         struct stat st;
@@ -1035,20 +1073,30 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
     } else {
         if (access(skf, F_OK) == 0) die(EEXIST, " mco_cbdco_nobin_dist():%s", skf); /* the reference refuses to overwrite */
         printf("disf_sz=%zu\trefnum=%u\tqrynum=%u\n", cells * 4, ref.n, qry.n);
-        skfd = open(skf, O_RDWR | O_CREAT, 0600);
-        if (skfd < 0 || ftruncate(skfd, (off_t)(cells * 4)) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
-        if (cells) shared = mmap(NULL, cells * 4, PROT_READ | PROT_WRITE, MAP_SHARED, skfd, 0);
-        if (cells && shared == MAP_FAILED) die(errno, "mmap %s", skf);
+        if (o->keep_skf) {
+            skfd = open(skf, O_RDWR | O_CREAT | O_EXCL, 0600);
+            if (skfd < 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+            snprintf(g_unlink_on_die, sizeof g_unlink_on_die, "%s", skf); /* a failed run must not leave a zero-filled file behind */
+            if (ftruncate(skfd, (off_t)(cells * 4)) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+            if (cells) shared = mmap(NULL, cells * 4, PROT_READ | PROT_WRITE, MAP_SHARED, skfd, 0);
+            if (cells && shared == MAP_FAILED) die(errno, "mmap %s", skf);
+        } else if (!selecting && cells) {
+            shared = mmap(NULL, cells * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (shared == MAP_FAILED) die(errno, "mco_cbdco_nobin_dist(): %zu bytes of shared k-mer counts", cells * 4);
+        }
+        if (warming) pthread_join(warm, NULL);
         int n_dev = o->gpus > 0 ? o->gpus : 1;
         const int have = kssd_gpu_device_count();
         if (have <= 0) die(ENODEV, "kssd_gpu_create_for_dist: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
         if (o->device + n_dev > have) die(ENODEV, "--gpus %d from device %d: only %d device(s) visible", n_dev, o->device, have);
-        if (o->num_neigb > 0 || o->mut_dist_max < 1.0) {
+        const double t0 = now_s();
+        if (selecting) {
             /* -N / -D leave few lines: let the device pick the pairs that can be printed (output_ctrl's rules with a
              * margin), the host ranks / tests those exactly and formats only them */
             if (o->num_neigb > 1024 || (uint32_t)o->num_neigb > ref.n)
                 die(EINVAL, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, ref.n);
             gck(kssd_gpu_create_for_dist(&g_ctx, qry.kmerlen, o->device), "kssd_gpu_create_for_dist");
+            t_ctx = now_s() - t0;
             gck(kssd_gpu_dist_select(g_ctx, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, o->metric, o->correction, qry.dim_rd_len,
                                      o->mut_dist_max, o->num_neigb, shared, &pair_off, &pair_ref, &pair_shared), "dist");
             kssd_gpu_destroy(g_ctx);
@@ -1060,8 +1108,10 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
             gck(kssd_gpu_dist_multi(devs, n_dev, qry.kmerlen, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
             free(devs);
         }
-        if (cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+        t_dist = now_s() - t0;
+        if (o->keep_skf && cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
     }
+    const double t_print0 = now_s();
     kssd_print_opt po = {o->metric, o->outfields, o->correction, o->mut_dist_max, o->num_neigb, o->p};
     rc = pair_off ? kssd_distance_print_pairs(distf, pair_off, pair_ref, pair_shared, &ref, &qry, &po)
                   : kssd_distance_print(distf, shared, &ref, &qry, &po);
@@ -1070,9 +1120,13 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
     kssd_gpu_free(pair_shared);
     if (rc != 0)
         die(rc == KSSD_HOST_ERR_PARAM ? EINVAL : EIO, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, ref.n);
+    g_unlink_on_die[0] = 0; /* the run is through: a kept count file stays */
     if (cells && shared) munmap(shared, cells * 4);
     if (skfd >= 0) close(skfd);
-    if (!o->keep_skf && !o->skf[0]) remove(skf);
+    if (getenv("KSSD_TIMING"))
+        fprintf(stderr, "{\"kssd_timing\": \"search\", \"refs\": %u, \"queries\": %u, \"host_threads\": %d, \"s_total\": %.6f, \"s_read_sketches\": %.6f, "
+                        "\"s_device\": %.6f, \"s_context_create\": %.6f, \"s_report\": %.6f}\n",
+                ref.n, qry.n, o->p, now_s() - t_start, t_read - t_start, t_dist, t_ctx, now_s() - t_print0);
     kssd_sketchset_release(&ref);
     kssd_sketchset_release(&qry);
 }

@@ -9,6 +9,7 @@
 #include <string.h>
 #include <time.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -139,6 +140,100 @@ int kssd_shuf_read(kssd_shuf *s, const char *path)
     fclose(f);
     s->id = hdr[0]; s->k = hdr[1]; s->subk = hdr[2]; s->drlevel = hdr[3];
     s->table = t;
+    return KSSD_HOST_OK;
+}
+
+/* The accepted sub-contexts of a .shuf: accepted[r] = the sub-context the permutation sends to rank r, r < dim_end =
+ * max(16^(subk - drlevel), 4096) (iseq2comem.c:74-76, 247-249).  They are all of the file the sketch path ever looks at --
+ * 16 KiB of a 64 MiB (L3K10) or 1 GiB (-s 7) table -- so they are kept beside it as "<file>.core":
+ *   u32 magic, u32 version, i32 id, k, subk, drlevel, u64 size of the .shuf, i64 its mtime (ns), u32 n, u32 pad, u32 accepted[n]
+ * A core whose header does not describe the .shuf as it is now is ignored and rewritten; a directory that cannot be
+ * written to just means the table is scanned every time (mapped, scanned by the OpenMP team, never copied). */
+#define SHUF_CORE_MAGIC 0x6b737363u /* "kssc" */
+typedef struct {
+    uint32_t magic, version;
+    int32_t id, k, subk, drlevel;
+    uint64_t shuf_size;
+    int64_t shuf_mtime_ns;
+    uint32_t n, pad;
+} shuf_core_hdr;
+
+int kssd_shuf_read_core(const char *path, kssd_shuf *hdr_out, uint32_t **accepted_out, uint32_t *n_out, int *from_cache)
+{
+    memset(hdr_out, 0, sizeof *hdr_out);
+    *accepted_out = NULL;
+    *n_out = 0;
+    if (from_cache) *from_cache = 0;
+    size_t L = strlen(path);
+    if (L < 5 || strcmp(path + L - 5, ".shuf") != 0) return KSSD_HOST_ERR_FORMAT; /* command_shuffle.c:194-196 */
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return KSSD_HOST_ERR_IO;
+    struct stat st;
+    int32_t hdr[4];
+    if (fstat(fd, &st) != 0 || pread(fd, hdr, sizeof hdr, 0) != (ssize_t)sizeof hdr || hdr[2] < 1 || hdr[2] >= 8) {
+        close(fd);
+        return KSSD_HOST_ERR_FORMAT;
+    }
+    const size_t n_tab = (size_t)1 << (4 * hdr[2]);
+    if ((uint64_t)st.st_size < 16 + n_tab * 4) { close(fd); return KSSD_HOST_ERR_FORMAT; }
+    hdr_out->id = hdr[0]; hdr_out->k = hdr[1]; hdr_out->subk = hdr[2]; hdr_out->drlevel = hdr[3];
+    if (hdr[3] < 0 || hdr[3] > hdr[2]) { close(fd); return KSSD_HOST_ERR_FORMAT; }
+    uint64_t sub = 1ull << (4 * (hdr[2] - hdr[3]));
+    const uint32_t dim_end = (uint32_t)(sub > 4096 ? sub : 4096); /* MIN_SUBCTX_DIM_SMP_SZ, command_shuffle.h:29 */
+    if (dim_end > n_tab) { close(fd); return KSSD_HOST_ERR_FORMAT; }
+    uint32_t *acc = malloc((size_t)dim_end * 4);
+    if (!acc) { close(fd); return KSSD_HOST_ERR_NOMEM; }
+    const int64_t mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+    char cpath[KSSD_PATHLEN + 16];
+    snprintf(cpath, sizeof cpath, "%s.core", path);
+    if (!getenv("KSSD_NO_SHUF_CORE")) {
+        int cfd = open(cpath, O_RDONLY);
+        if (cfd >= 0) {
+            shuf_core_hdr ch;
+            if (read(cfd, &ch, sizeof ch) == (ssize_t)sizeof ch && ch.magic == SHUF_CORE_MAGIC && ch.version == 1 && ch.id == hdr[0] && ch.k == hdr[1] &&
+                ch.subk == hdr[2] && ch.drlevel == hdr[3] && ch.shuf_size == (uint64_t)st.st_size && ch.shuf_mtime_ns == mtime_ns &&
+                ch.n == dim_end && read(cfd, acc, (size_t)dim_end * 4) == (ssize_t)((size_t)dim_end * 4)) {
+                close(cfd);
+                close(fd);
+                *accepted_out = acc;
+                *n_out = dim_end;
+                if (from_cache) *from_cache = 1;
+                return KSSD_HOST_OK;
+            }
+            close(cfd);
+        }
+    }
+    const int32_t *tab = mmap(NULL, 16 + n_tab * 4, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (tab == MAP_FAILED) { free(acc); return KSSD_HOST_ERR_IO; }
+    tab += 4;
+    memset(acc, 0xFF, (size_t)dim_end * 4);
+    uint64_t found = 0;
+    int dup = 0;
+#pragma omp parallel for schedule(static) reduction(+ : found) reduction(| : dup)
+    for (size_t x = 0; x < n_tab; x++) {
+        const int32_t r = tab[x];
+        if (r >= 0 && (uint32_t)r < dim_end) {
+            uint32_t expect = 0xFFFFFFFFu; /* (two sub-contexts with one rank: not a permutation) */
+            if (!__atomic_compare_exchange_n(&acc[r], &expect, (uint32_t)x, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) dup = 1;
+            found++;
+        }
+    }
+    munmap((void *)(tab - 4), 16 + n_tab * 4);
+    if (dup || found != dim_end) { free(acc); return KSSD_HOST_ERR_FORMAT; }
+    if (!getenv("KSSD_NO_SHUF_CORE")) { /* leave the core for the next run: temporary name, then rename (a reader never sees half a file) */
+        char tmp[KSSD_PATHLEN + 48];
+        snprintf(tmp, sizeof tmp, "%s.tmp%ld", cpath, (long)getpid());
+        int wfd = open(tmp, O_WRONLY | O_CREAT | O_EXCL, 0644);
+        if (wfd >= 0) {
+            shuf_core_hdr ch = {SHUF_CORE_MAGIC, 1, hdr[0], hdr[1], hdr[2], hdr[3], (uint64_t)st.st_size, mtime_ns, dim_end, 0};
+            const int ok = write(wfd, &ch, sizeof ch) == (ssize_t)sizeof ch && write(wfd, acc, (size_t)dim_end * 4) == (ssize_t)((size_t)dim_end * 4);
+            close(wfd);
+            if (!ok || rename(tmp, cpath) != 0) unlink(tmp);
+        }
+    }
+    *accepted_out = acc;
+    *n_out = dim_end;
     return KSSD_HOST_OK;
 }
 

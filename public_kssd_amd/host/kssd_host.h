@@ -38,6 +38,11 @@ typedef struct kssd_shuf {
 int kssd_shuf_generate(kssd_shuf *s, int k, int subk, int drlevel, uint64_t seed);
 int kssd_shuf_write(const kssd_shuf *s, const char *path);
 int kssd_shuf_read(kssd_shuf *s, const char *path);
+/* what the sketch path needs of a .shuf: its header (table stays NULL) and accepted[r] = the sub-context of rank r,
+ * r < n = max(16^(subk - drlevel), 4096) (iseq2comem.c:74-76, 247-249; malloc'd, free()).  Read from "<path>.core" when
+ * that file describes the .shuf as it is now (size, mtime, header), otherwise scanned out of the mapped table and the core
+ * written for the next run; KSSD_NO_SHUF_CORE=1 neither reads nor writes it.  from_cache (may be NULL): 1 if the core was used */
+int kssd_shuf_read_core(const char *path, kssd_shuf *hdr, uint32_t **accepted, uint32_t *n, int *from_cache);
 void kssd_shuf_release(kssd_shuf *s);
 
 /* ---- packed batches (layout: include/kssd_gpu.h) ----------------------------------------------- */
