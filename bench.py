@@ -529,6 +529,232 @@ def run_fastq(a, shuf, dev):
 
 
 # ------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: 3 Gb "mammalian" records at the s7/l5 shuffle (`kssd shuffle -k 10 -s 7 -l 5`: SURVEY.md section 8 --
+# auto -L 5 is rejected by the reference, and its effective reduction is 16^4).  Sketch throughput only (the config's
+# metric); no exchange between ranks: N ranks are N replicas with their own records.
+# The reference itself cannot sketch such a record: hashlimit 4 914 < the ~45 800 ids of 3 Gb, it aborts
+# (iseq2comem.c:262-263).  So the whole-record run lifts the capacity rule (KSSD_SKETCH_NO_CAPACITY) and parity is
+# (a) record 0 cut into <= 250 Mb pieces (overlapping by 2k - 1 bases: no k-mer lost, none invented) through the oracle
+#     (and the reference binary when the snapshot carries it): the UNION of their id sets must be record 0's sketch;
+# (b) the first 400 Mb of record 0 as a record of its own WITHOUT the flag: the reference's abort, naming the genome.
+# ------------------------------------------------------------------------------------------------------
+def make_long_records(n, length, seed, dev, keep_first):
+    """n records of `length` uniform random bases with 1e-5 isolated N, packed on the device slice by slice;
+    returns packed, mask, chunk_off and (record 0's codes u8, N mask bool) on the host when keep_first"""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    chunks = (length + K.CHUNK_BASES - 1) // K.CHUNK_BASES
+    packed = torch.zeros(n * chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
+    mask = torch.zeros(n * chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
+    wsh = (30 - 2 * torch.arange(16, device=dev, dtype=torch.int64))
+    msh = torch.arange(32, device=dev, dtype=torch.int64)
+    S = 1 << 26
+    kept_c = np.empty(length, dtype=np.uint8) if keep_first else None
+    kept_n = np.empty(length, dtype=bool) if keep_first else None
+    for gi in range(n):
+        for p0 in range(0, length, S):
+            m = min(S, length - p0)
+            mp = (m + 31) // 32 * 32
+            codes = torch.randint(0, 4, (mp,), generator=g, device=dev, dtype=torch.uint8)
+            isn = torch.rand(mp, generator=g, device=dev) < 1e-5
+            isn[1:] &= ~isn[:-1]                                   # isolated: one N = one invalid position, as the tokeniser lays it out
+            ok = ~isn
+            ok[m:] = False
+            codes = torch.where(ok, codes, torch.zeros_like(codes))
+            if keep_first and gi == 0:
+                kept_c[p0:p0 + m] = codes[:m].cpu().numpy()
+                kept_n[p0:p0 + m] = isn[:m].cpu().numpy()
+            w = (codes.view(-1, 16).to(torch.int64) << wsh).sum(1).to(torch.int32)
+            mw = (ok.view(-1, 32).to(torch.int64) << msh).sum(1).to(torch.int32)
+            b0 = gi * chunks * K.CHUNK_BASES + p0
+            packed[b0 // 16:b0 // 16 + len(w)] = w
+            mask[b0 // 32:b0 // 32 + len(mw)] = mw
+            del codes, isn, ok, w, mw
+    chunk_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(chunks)
+    return packed, mask, chunk_off, (kept_c, kept_n)
+
+
+def run_mammal(a, dev, world, rank):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    G, L = a.genomes, a.length
+    t0 = time.time()
+    shuf = K.Shuf.generate(10, 7, 5, seed=20260105)
+    info = K.derive(10, 7, 5)
+    assert info.hashsize == 8191 and info.hashlimit == 4914       # SURVEY.md section 8: primer[5], 0.6 of it
+    do_par = rank == 0 and a.cpu_sample > 0
+    packed, mask, chunk_off, (c0, n0) = make_long_records(G, L, 20260105 + 7919 * rank, dev, keep_first=do_par)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("[bench] %d records x %.2f Gb packed on device in %.1f s (%.1f GB of packed bases + mask)"
+            % (G, L / 1e9, time.time() - t0, (packed.numel() + mask.numel()) * 4 / 1e9))
+    ctx = K.GpuCtx(shuf, dev.index or 0)
+    n_pos = G * L
+    cap = int(n_pos / 65536 * 1.3) + 65536
+    off_d = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    ids_d = torch.zeros(cap, dtype=torch.int32, device=dev)
+    flags = K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY
+
+    def step():
+        ctx.sketch_plan(packed, mask, chunk_off, off_d, ids_d, cap, flags, 1)
+        for ph in (K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+            ctx.sketch_phase(ph, None)
+    for attempt in range(8):                                       # sizes the workspaces
+        step()
+        rc, total, bad = ctx.sketch_status()
+        if rc == 0:
+            break
+        assert rc == K.capi.ERR_OVERFLOW, rc
+    assert rc == 0
+    if world > 1:
+        import torch.distributed as dist
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(a.warmup, 1)):
+        step()
+    sync()
+    ctx.kernel_time(0, reset=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    t0 = time.perf_counter()
+    for n in range(a.steps):
+        if n == a.steps - 1:                                       # phase split of the last step (events on the stream the phases run on)
+            ctx.sketch_plan(packed, mask, chunk_off, off_d, ids_d, cap, flags, 1)
+            for i, ph in enumerate((K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH)):
+                ev[i].record()
+                ctx.sketch_phase(ph, None)
+            ev[4].record()
+        else:
+            step()
+    sync()
+    dt = time.perf_counter() - t0
+    rc, total, bad = ctx.sketch_status()
+    assert rc == 0
+    scan_ms, scan_n = ctx.kernel_time(0)
+    phases = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+    n_stage1, n_bloom = ctx.scan_stats()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    oh = off_d.cpu().numpy()
+    ih = ids_d[:int(total)].cpu().numpy().view(np.uint32)
+    # size-independent properties on every record: ascending distinct ids, the expected sampling rate (2^-16 per position)
+    for gi in range(G):
+        x = ih[int(oh[gi]):int(oh[gi + 1])].astype(np.int64)
+        assert np.all(np.diff(x) > 0), "record %d: ids not ascending and distinct" % gi
+        assert abs(len(x) / (L / 65536.0) - 1.0) < 0.05, "record %d: %d ids for %d positions" % (gi, len(x), L)
+    res = None
+    if rank == 0:
+        scan_bytes = 0.375 * n_pos + 4.0 * total
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9
+        res = {
+            "metric": "Gbase sketched/s (fasta2co sketch of 3 Gb records at -k 10 -s 7 -l 5, whole records, capacity rule lifted)",
+            "value": world * n_pos * a.steps / dt / 1e9, "unit": "Gbase/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %d synthetic %.2f Gb records per GPU (uniform bases, 1e-5 N), shuffle -k 10 -s 7 -l 5 "
+                                   "(the runnable form of 'L5K10': SURVEY.md section 8), sketch only, KSSD_SKETCH_NO_CAPACITY" % (G, L / 1e9),
+                       "k": 10, "subk": 7, "drlevel": 5, "records_per_gpu": G, "record_len": L,
+                       "parallelism": "single GPU" if world == 1 else "%d replicas, records sharded, no collective" % world},
+            "genomes_per_s": world * G * a.steps / dt, "ids_per_batch": int(total), "ids_per_record": int(total) / G,
+            "phase_ms_last_step": dict(zip(["prep", "scan", "exact", "dedup_finish(rocPRIM sort path)"], [float(x) for x in phases])),
+            "kernels": {"sketch_scan_ms": scan_ms, "launches_timed": scan_n,
+                        "scan_positions_past_stage1": n_stage1 / n_pos, "scan_positions_past_bloom": n_bloom / n_pos},
+            "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<7>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": scan_bytes},
+        }
+    if do_par:
+        import kssd_oracle as ko
+        from synth import fasta_text
+        cores = host_cores()
+        got0 = ih[int(oh[0]):int(oh[1])]
+        # (b) the reference's capacity abort on a 400 Mb record (its own genome index in the error)
+        c400 = (400_000_000 // K.CHUNK_BASES)
+        co2 = np.array([0, 256, 256 + c400], dtype=np.uint64)        # a small record in front: the abort must name record 1
+        o2 = torch.zeros(3, dtype=torch.int64, device=dev)
+        i2 = torch.zeros(65536, dtype=torch.int32, device=dev)
+        rc2 = None
+        for attempt in range(8):
+            ctx.sketch_device(packed, mask, co2, o2, i2, 65536)
+            rc2, tot2, bad2 = ctx.sketch_status()
+            if rc2 != K.capi.ERR_OVERFLOW:
+                break
+        assert rc2 == K.capi.ERR_CAPACITY and bad2 == 1, "400 Mb record: expected the reference's capacity abort, got rc %r genome %r" % (rc2, bad2)
+        # (a) record 0 in <= 250 Mb pieces through the oracle
+        P = 250_000_000
+        ov = 2 * 10 - 1
+        t0 = time.time()
+        texts = []
+        for s0 in range(0, L, P):
+            b = max(0, s0 - ov)
+            texts.append(fasta_text(c0[b:s0 + P], b"rec0_%d" % (s0 // P), n_mask=n0[b:s0 + P]))
+        t_text = time.time() - t0
+        t0 = time.time()
+        thr = min(cores, len(texts))
+        ooff, oids = ko.sketch_texts(shuf.table, 10, 7, 5, texts, threads=thr)
+        t_or = time.time() - t0
+        union = np.unique(oids)
+        assert np.array_equal(got0, union), "record 0: GPU sketch (%d ids) != union of the oracle's pieces (%d ids)" % (len(got0), len(union))
+        res["parity"] = {"record0_ids": int(len(got0)), "pieces": len(texts), "piece_len": P, "oracle_seconds": t_or,
+                         "capacity_abort_400Mb": "KSSD_ERR_CAPACITY naming record 1 (hashlimit 4914), as iseq2comem.c:262-263",
+                         "what": "record 0's sketch == union of the oracle's id sets of its %d overlapping pieces (bit-exact)" % len(texts)}
+        res["cpu_baseline"] = {"value": L / 1e9 / t_or, "unit": "Gbase/s", "cores": thr, "kind": "port",
+                               "sample": "record 0 (%.2f Gbase) as %d FASTA texts of <= 250 Mb in memory, oracle/kssd_oracle.c "
+                                         "sketch_texts, OpenMP over the pieces (the 1 GiB table of -s 7 misses every cache)" % (L / 1e9, len(texts))}
+        # the same pieces as files: the product's command line and, when the snapshot carries it, the reference binary
+        d = tempfile.mkdtemp(prefix="kssd_benchm_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            os.mkdir(os.path.join(d, "fa"))
+            for i, t in enumerate(texts):
+                with open(os.path.join(d, "fa", "rec0_%02d.fasta" % i), "wb") as f:
+                    f.write(t)
+            nb_txt = sum(len(t) for t in texts)
+            n_pieces = len(texts)
+            del texts
+            shuf.write(os.path.join(d, "s7l5.shuf"))
+            if os.access(KSSD_BIN, os.X_OK):
+                dt1, tm1 = _run_ours(["dist", "-p", cores, "-L", "s7l5.shuf", "-o", "our_sk0", "fa"], d, {"KSSD_TIMING": "1"})
+                dt2, tm2 = _run_ours(["dist", "-p", cores, "-L", "s7l5.shuf", "-o", "our_sk", "fa"], d, {"KSSD_TIMING": "1"})
+                runs = [dt1, dt2]
+                if dt1 < dt2:
+                    dt2, tm2 = dt1, tm1
+                ours = ko.sketch_sets_by_name(os.path.join(d, "our_sk"))
+                u = np.unique(np.concatenate([ours["rec0_%02d.fasta" % i] for i in range(n_pieces)]))
+                assert np.array_equal(u, got0), "kssd CLI: union of the pieces' sketches != record 0's sketch"
+                for i in range(n_pieces):
+                    assert np.array_equal(np.sort(ours["rec0_%02d.fasta" % i]), np.sort(oids[int(ooff[i]):int(ooff[i + 1])])), "kssd CLI piece %d != oracle" % i
+                res["end_to_end"] = {"value": L / 1e9 / dt2, "unit": "Gbase/s", "seconds": dt2, "seconds_runs": runs, "stages": tm2,
+                                     "what": "`kssd dist -L s7l5.shuf -o <dir> <dir of %d FASTA files, %.2f GB>`: wall time of the command incl. the "
+                                             "1 GiB .shuf (second run: its 16 KiB core), the better of two runs; every piece's sketch equals the oracle's"
+                                             % (n_pieces, nb_txt / 1e9)}
+            if ko.have_ref() and shutil.which("zcat"):
+                p_ref = max(1, min(cores, n_pieces - 1))            # the reference only goes parallel with more files than threads (command_dist.c:275)
+                t0 = time.time()
+                ko.run_ref(["dist", "-p", p_ref, "-L", "s7l5.shuf", "-o", "ref_sk", "fa"], cwd=d, timeout=3000)
+                t_ref = time.time() - t0
+                sets = ko.sketch_sets_by_name(os.path.join(d, "ref_sk"))
+                u = np.unique(np.concatenate(list(sets.values())))
+                assert np.array_equal(u, got0), "reference binary: union of the pieces' sketches != record 0's GPU sketch"
+                res["cpu_baseline_port"] = res["cpu_baseline"]
+                res["cpu_baseline"] = {"value": L / 1e9 / t_ref, "unit": "Gbase/s", "cores": p_ref, "kind": "reference", "seconds": t_ref,
+                                       "sample": "record 0 as %d FASTA files of <= 250 Mb in tmpfs, `oracle/_ref/kssd dist -p %d -L s7l5.shuf` wall time "
+                                                 "incl. process start and the 1 GiB .shuf load; the whole 3 Gb record it cannot sketch (capacity abort)"
+                                                 % (len(sets), p_ref)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------
 def self_launch(a):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, as children, BEFORE
     anything in this process touches the GPU (never an exec from a process that has initialised HIP), relay rank 0's one

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../include/kssd_gpu.h"
+extern "C" int kssd_gpu_dev_wavetimes(unsigned long long *out, uint32_t n_waves);  // libkssd_gpu_dev.so only
 
 #define CK(x)                                                                         \
     do {                                                                              \
@@ -186,6 +187,38 @@ int main(int argc, char **argv)
     printf("variant=%s genomes=%u len=%llu rc=%d ids=%llu checksum=%016llx scan_ms=%.4f (%u launches) algorithmic %.1f GB/s\n",
            getenv("KSSD_DEV_ABLATE") ? getenv("KSSD_DEV_ABLATE") : "product", G, (unsigned long long)L, rc,
            (unsigned long long)total, (unsigned long long)h, ms, nl, bytes / ms / 1e6);
+    if (getenv("KSSD_DEV_WAVETIME")) {
+        // where the launch's time goes per wave: start skew, table copy, the chunk loop, and how long the machine waits for its
+        // slowest wave (static partition: every wave owns the same number of chunks)
+        const uint32_t nw = 256 * 16;
+        std::vector<unsigned long long> t(nw * 3);
+        if (kssd_gpu_dev_wavetimes(t.data(), nw) == 0) {
+            unsigned long long t_min = ~0ull, t_end = 0;
+            for (uint32_t w = 0; w < nw; w++) { t_min = std::min(t_min, t[3 * w]); t_end = std::max(t_end, t[3 * w + 2]); }
+            std::vector<double> start(nw), tab(nw), loop(nw), fin(nw);
+            for (uint32_t w = 0; w < nw; w++) {
+                start[w] = (double)(t[3 * w] - t_min);
+                tab[w] = (double)(t[3 * w + 1] - t[3 * w]);
+                loop[w] = (double)(t[3 * w + 2] - t[3 * w + 1]);
+                fin[w] = (double)(t[3 * w + 2] - t_min);
+            }
+            auto pr = [&](const char *nm, std::vector<double> v) {
+                std::sort(v.begin(), v.end());
+                printf("  %-28s min %9.0f  p10 %9.0f  median %9.0f  p90 %9.0f  max %9.0f\n", nm, v[0], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+            };
+            printf("per-wave ticks of the last scan launch (4096 waves; the launch spans %llu ticks):\n", t_end - t_min);
+            pr("first instruction", start);
+            pr("table copy + barrier", tab);
+            pr("chunk loop", loop);
+            pr("wave finished at", fin);
+            std::vector<double> cu(256);
+            for (uint32_t b = 0; b < 256; b++) { double m = 0; for (uint32_t w = 0; w < 16; w++) m = std::max(m, fin[b * 16 + w]); cu[b] = m; }
+            pr("workgroup finished at", cu);
+            double idle = 0;
+            for (uint32_t w = 0; w < nw; w++) idle += (double)(t_end - t_min) - fin[w];
+            printf("  wave-time idle behind the slowest wave: %.1f %% of waves x span\n", 100.0 * idle / ((double)nw * (double)(t_end - t_min)));
+        }
+    }
     kssd_gpu_destroy(ctx);
     return 0;
 }

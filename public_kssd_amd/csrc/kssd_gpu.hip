@@ -421,6 +421,9 @@ struct ScanArgs {
     unsigned long long cand_cap;    // per wave
     uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
     SketchStatus *status;
+#ifdef KSSD_DEV
+    unsigned long long *dev_times;  // development build: per wave {first instruction, tables in LDS, last chunk done} (s_memtime)
+#endif
 };
 
 // one chunk of the lane's share of the stream: 64 positions + halo, and their validity bits
@@ -507,6 +510,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     if (c1 > a.n_chunks) c1 = a.n_chunks;
     const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
+#ifdef KSSD_DEV
+    const unsigned long long dev_t0 = __builtin_readcyclecounter();
+#endif
 
     // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
     // first reads overlaps the 144 KiB copy instead of following it
@@ -520,6 +526,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
     __syncthreads();
+#ifdef KSSD_DEV
+    const unsigned long long dev_t1 = __builtin_readcyclecounter();
+#endif
     if (c0 >= c1) return;
     // what a lane needs from its neighbours for the hand-over to the exact stage: the packed word in front of its own
     // (lane 0: the last word of the chunk before, carried in an SGPR from step to step) and whether the neighbours' 64
@@ -642,6 +651,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         n_rounded += n;
         cn -= n;
     }
+#ifdef KSSD_DEV
+    if (a.dev_times && lane == 0) {
+        a.dev_times[wid * 3] = dev_t0;
+        a.dev_times[wid * 3 + 1] = dev_t1;
+        a.dev_times[wid * 3 + 2] = __builtin_readcyclecounter();
+    }
+#endif
     if (lane == 0) {
         a.cand_count[wid] = stored;
         atomicAdd(&a.status->n_stage1, (unsigned long long)n_rounded);
@@ -1568,6 +1584,18 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
     return KSSD_OK;
 }
 
+#ifdef KSSD_DEV
+static unsigned long long *g_dev_times;
+// development build only (scanbench): the per-wave time stamps of the last scan, 3 per wave
+extern "C" int kssd_gpu_dev_wavetimes(unsigned long long *out, uint32_t n_waves)
+{
+    if (!g_dev_times) return KSSD_ERR_PARAM;
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(out, g_dev_times, (size_t)n_waves * 3 * 8, hipMemcpyDeviceToHost));
+    return KSSD_OK;
+}
+#endif
+
 static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
 {
     const auto &pl = c->plan;
@@ -1577,6 +1605,14 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.status = c->d_status;
+#ifdef KSSD_DEV
+    {
+        static unsigned long long *d_times = nullptr;
+        if (!d_times && getenv("KSSD_DEV_WAVETIME")) hipMalloc(&d_times, 4096 * 16 * 3 * 8);
+        a.dev_times = d_times;
+        g_dev_times = d_times;
+    }
+#endif
     const int grid = pl.grid;
     const unsigned evi = c->ev_n[0] % EV_RING;
     hipEvent_t e0 = c->ev_a[0][evi], e1 = c->ev_b[0][evi];
