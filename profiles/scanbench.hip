@@ -193,30 +193,37 @@ int main(int argc, char **argv)
         const uint32_t nw = 256 * 16;
         std::vector<unsigned long long> t(nw * 3);
         if (kssd_gpu_dev_wavetimes(t.data(), nw) == 0) {
-            unsigned long long t_min = ~0ull, t_end = 0;
-            for (uint32_t w = 0; w < nw; w++) { t_min = std::min(t_min, t[3 * w]); t_end = std::max(t_end, t[3 * w + 2]); }
-            std::vector<double> start(nw), tab(nw), loop(nw), fin(nw);
+            // (time stamps of different XCDs do not share a base: only differences inside a wave are compared)
+            std::vector<double> tab(nw), loop(nw);
             for (uint32_t w = 0; w < nw; w++) {
-                start[w] = (double)(t[3 * w] - t_min);
                 tab[w] = (double)(t[3 * w + 1] - t[3 * w]);
                 loop[w] = (double)(t[3 * w + 2] - t[3 * w + 1]);
-                fin[w] = (double)(t[3 * w + 2] - t_min);
             }
             auto pr = [&](const char *nm, std::vector<double> v) {
                 std::sort(v.begin(), v.end());
-                printf("  %-28s min %9.0f  p10 %9.0f  median %9.0f  p90 %9.0f  max %9.0f\n", nm, v[0], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+                double mean = 0;
+                for (double x : v) mean += x;
+                mean /= (double)v.size();
+                printf("  %-34s min %9.0f  p10 %9.0f  median %9.0f  mean %9.0f  p90 %9.0f  max %9.0f\n", nm, v[0], v[v.size() / 10], v[v.size() / 2], mean,
+                       v[v.size() * 9 / 10], v.back());
             };
-            printf("per-wave ticks of the last scan launch (4096 waves; the launch spans %llu ticks):\n", t_end - t_min);
-            pr("first instruction", start);
+            printf("per-wave ticks of the last scan launch (4096 waves):\n");
             pr("table copy + barrier", tab);
             pr("chunk loop", loop);
-            pr("wave finished at", fin);
-            std::vector<double> cu(256);
-            for (uint32_t b = 0; b < 256; b++) { double m = 0; for (uint32_t w = 0; w < 16; w++) m = std::max(m, fin[b * 16 + w]); cu[b] = m; }
-            pr("workgroup finished at", cu);
-            double idle = 0;
-            for (uint32_t w = 0; w < nw; w++) idle += (double)(t_end - t_min) - fin[w];
-            printf("  wave-time idle behind the slowest wave: %.1f %% of waves x span\n", 100.0 * idle / ((double)nw * (double)(t_end - t_min)));
+            std::vector<double> cumax(256), cumin(256), xcd(8, 0.0);
+            for (uint32_t b = 0; b < 256; b++) {
+                double mx = 0, mn = 1e30;
+                for (uint32_t w = 0; w < 16; w++) { mx = std::max(mx, loop[b * 16 + w]); mn = std::min(mn, loop[b * 16 + w]); xcd[b % 8] += loop[b * 16 + w] / (32.0 * 16.0); }
+                cumax[b] = mx;
+                cumin[b] = mn;
+            }
+            pr("slowest wave of a workgroup", cumax);
+            pr("fastest wave of a workgroup", cumin);
+            printf("  mean chunk loop by XCD (workgroup %% 8):");
+            for (int x = 0; x < 8; x++) printf(" %.0f", xcd[x]);
+            double mean = 0, mx = 0;
+            for (uint32_t w = 0; w < nw; w++) { mean += loop[w] / nw; mx = std::max(mx, loop[w]); }
+            printf("\n  mean / max of the chunk loops: %.3f (what a launch that ended with its average wave would take)\n", mean / mx);
         }
     }
     kssd_gpu_destroy(ctx);

@@ -75,6 +75,7 @@ struct SketchStatus {
     unsigned long long n_stage1, n_bloom;
     unsigned int cand_overflow;    // a shard of the candidate list was too small
     unsigned int cand_need;        // entries the fullest shard wanted
+    unsigned int queue_next;       // the scan's block queue: next block nobody has taken yet (set to the number of waves by PREP)
 };
 
 struct kssd_gpu_ctx {
@@ -100,6 +101,8 @@ struct kssd_gpu_ctx {
     size_t cap_cand;
     uint32_t *d_cand_count;
     size_t cap_cand_count;
+    unsigned long long *d_blk_info;  // per block of the last scan: where its candidates are (scan_blk_pack)
+    size_t cap_blk_info;
     uint64_t last_cand_cap;
     uint64_t cand_floor;    // per-slice capacity an overflowed attempt asked for (kept for the retries)
     double cand_factor;
@@ -202,7 +205,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
     c->cu_count = prop.multiProcessorCount;
     c->P = P;
     c->region_factor = 2.0;
-    c->cand_factor = 1.5;
+    c->cand_factor = 2.0;  // waves work off different numbers of blocks: room for the busiest
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     int rc = ctx_upload_tables(c, accepted);
     if (rc != KSSD_OK) { delete c; return rc; }
@@ -270,7 +273,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_big_alt, c->d_big_tmp,
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
                     c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -371,7 +374,7 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
                                  uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < sizeof(SketchStatus) / 4) status_words[c] = 0;
+    if (c < sizeof(SketchStatus) / 4) status_words[c] = c == offsetof(SketchStatus, queue_next) / 4 ? n_slices : 0u;
     if (c < n_genomes) cursor[c] = 0;
     if (c < n_slices) cand_count[c] = 0;
     if (c >= n_chunks) return;
@@ -392,7 +395,7 @@ __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_of
 {
     // grid = (genomes or more, parts): workgroup (g, y) writes every gridDim.y-th run of 256 chunks of genome g
     const uint64_t t = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
-    if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
+    if (t < sizeof(SketchStatus) / 4) status_words[t] = t == offsetof(SketchStatus, queue_next) / 4 ? n_slices : 0u;
     for (uint64_t i = t; i < n_genomes; i += nt) cursor[i] = 0;
     for (uint64_t i = t; i < n_slices; i += nt) cand_count[i] = 0;
     if (blockIdx.x >= n_genomes) return;
@@ -420,11 +423,25 @@ struct ScanArgs {
     ulonglong2 *cand;               // (waves of the grid) * cand_cap records {global position, carried k-mer bits}
     unsigned long long cand_cap;    // per wave
     uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
+    unsigned long long *blk_info;   // per block of SCAN_BLOCK chunks: where its candidates sit in the list (scan_blk_pack)
+    uint32_t dynamic;               // 1: blocks from the queue (the product); 0: a static round-robin (development A/B)
     SketchStatus *status;
 #ifdef KSSD_DEV
     unsigned long long *dev_times;  // development build: per wave {first instruction, tables in LDS, last chunk done} (s_memtime)
 #endif
 };
+
+// The scan's unit of work distribution: a block of SCAN_BLOCK consecutive chunks.  Waves take blocks from a queue (the first
+// one by their index, the following ones with an atomic on SketchStatus::queue_next), so a wave that runs ahead -- waves do
+// not get the same share of a CU's LDS and issue slots, CUs not the same share of the memory system: measured, the fastest
+// tenth of the waves of a static partition finished their equal shares at 70 % of the launch's time -- simply works off more
+// blocks, and the launch ends when the queue is empty instead of when the slowest wave has worked off its fixed share.
+// A wave lists the survivors of a block contiguously in its own slice of the candidate list and leaves, per block, where:
+//   bits 0-23 the number of records, bits 24-63 the index of the first one in the whole list
+#define SCAN_BLOCK 4
+__host__ __device__ __forceinline__ unsigned long long scan_blk_pack(unsigned long long first, uint32_t n) { return (first << 24) | n; }
+__host__ __device__ __forceinline__ uint32_t scan_blk_count(unsigned long long v) { return (uint32_t)(v & 0xFFFFFFull); }
+__host__ __device__ __forceinline__ unsigned long long scan_blk_first(unsigned long long v) { return v >> 24; }
 
 // one chunk of the lane's share of the stream: 64 positions + halo, and their validity bits
 struct ChunkRegs {
@@ -502,80 +519,94 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates, see bloom_round
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
-    // static partition: every wave of the grid owns one contiguous run of chunks
-    const unsigned long long total_waves = (unsigned long long)gridDim.x * SCAN_WAVES;
-    const unsigned long long wid = (unsigned long long)blockIdx.x * SCAN_WAVES + wave;
-    const unsigned long long per = (a.n_chunks + total_waves - 1) / total_waves;
-    unsigned long long c0 = wid * per, c1 = c0 + per;
-    if (c1 > a.n_chunks) c1 = a.n_chunks;
-    const unsigned long long clast = a.n_chunks - 1;  // reads past the wave's range are clamped, their results unused
+    // work distribution: blocks of SCAN_BLOCK chunks from a queue (see SCAN_BLOCK); the wave's first block is its own index
+    const uint32_t total_waves = gridDim.x * SCAN_WAVES;
+    const uint32_t wid = blockIdx.x * SCAN_WAVES + wave;
+    const unsigned long long clast = a.n_chunks - 1;  // reads past the end of the batch are clamped, their results unused
+    const uint32_t n_blocks = (uint32_t)((a.n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK);
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
 #ifdef KSSD_DEV
     const unsigned long long dev_t0 = __builtin_readcyclecounter();
 #endif
+    // the next block nobody has taken yet.  The atomic's answer is not needed before the wave is three chunks into the
+    // block it is working on: vector memory operations return in order, so by then the chunk loads issued behind it are in too
+    auto take = [&](uint32_t prev) -> uint32_t {
+        if (!a.dynamic) return prev >= n_blocks ? prev : prev + total_waves;  // (development: a static round-robin of the blocks)
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&a.status->queue_next, 1u);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto chunk_at = [&](unsigned long long c) -> unsigned long long { return c < clast ? c : clast; };
+    uint32_t b_cur = wid, b_nxt = take(b_cur);
 
     // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
     // first reads overlaps the 144 KiB copy instead of following it
     ChunkRegs r0, r1, r2, r3;
     uint32_t raw[Gp::NMAX];
     uint32_t alo, ahi;
-    load_chunk(a, c0 < clast ? c0 : clast, lane, r0);
-    load_chunk(a, c0 + 1 < clast ? c0 + 1 : clast, lane, r1);
-    load_chunk(a, c0 + 2 < clast ? c0 + 2 : clast, lane, r2);
-
+    {
+        const unsigned long long c0 = (unsigned long long)b_cur * SCAN_BLOCK;
+        load_chunk(a, chunk_at(c0), lane, r0);
+        load_chunk(a, chunk_at(c0 + 1), lane, r1);
+        load_chunk(a, chunk_at(c0 + 2), lane, r2);
+    }
     for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
         *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
     __syncthreads();
 #ifdef KSSD_DEV
     const unsigned long long dev_t1 = __builtin_readcyclecounter();
 #endif
-    if (c0 >= c1) return;
+    if (b_cur >= n_blocks) return;
     // what a lane needs from its neighbours for the hand-over to the exact stage: the packed word in front of its own
     // (lane 0: the last word of the chunk before, carried in an SGPR from step to step) and whether the neighbours' 64
-    // positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour is not looked at: its
-    // candidates -- 1.6 % -- let the exact stage read the mask)
-    uint32_t s_tail = c0 ? __builtin_amdgcn_readfirstlane(a.packed[c0 * 256 - 1]) : 0u;
+    // positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour is not looked at, and
+    // neither is lane 0's left one in the first chunk of a block: their candidates -- ~2 % -- let the exact stage read the mask)
+    uint32_t s_tail = b_cur ? __builtin_amdgcn_readfirstlane(a.packed[(unsigned long long)b_cur * SCAN_BLOCK * 256 - 1]) : 0u;
     uint64_t vb_prev = 0;
+    unsigned long long blk_c0 = (unsigned long long)b_cur * SCAN_BLOCK;  // first chunk of the block being worked on
 
-    // prologue: chunk c0 through both alignments
+    // prologue: the block's first chunk through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
     kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
-    kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of chunk c0 in flight
+    kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of the first chunk in flight
 
-    // one chunk.  The four register sets rotate by name (the loop below is unrolled four times): copying one
+    // one chunk.  The four register sets rotate by name (a block is four steps, written out): copying one
     // set into another would make every iteration wait for the reads it has just issued.
-    auto step = [&](const ChunkRegs &cur_r, ChunkRegs &nxt_r, ChunkRegs &far, const unsigned long long c) {
-        // state: cur = chunk c, nxt = chunk c+1 (requested two iterations ago), chunk c+2 in flight, far = free, raw = alignment-B reads of
-        //        chunk c (in flight), alo/ahi = alignment A of chunk c
+    //   c = the chunk of this step, crel = its index in the block, c_far = the chunk three steps ahead in the wave's
+    //   sequence (the next block's chunks once this block's are requested), last = the block's last step
+    auto step = [&](const ChunkRegs &cur_r, ChunkRegs &nxt_r, ChunkRegs &far, const unsigned long long c, const uint32_t crel,
+                    const unsigned long long c_far, const bool last) {
+        // state: cur = chunk c, nxt = the chunk after it (requested two steps ago), the one after that in flight, far = free,
+        //        raw = alignment-B reads of chunk c (in flight), alo/ahi = alignment A of chunk c
         // Wave priority: the part of an iteration that feeds the memory and LDS pipes runs at high priority (3 while the
         // loads and table reads are issued, 2 for the merges and the Bloom round), the candidate loop -- a long run of
         // VALU work that nothing waits for -- at priority 0, so that a SIMD's issue slots go first to the waves that
         // keep HBM and LDS busy.  Measured on the full batch, same box: 0.555 ms without priorities, 0.544 with only the
         // table-read issue raised, 0.529 with everything but the loop at 2, 0.526 as it is here.
         __builtin_amdgcn_s_setprio(3);
-        load_chunk(a, c + 3 < clast ? c + 3 : clast, lane, far);
-        const ChunkRegs &cur = cur_r, &nxt = nxt_r;  // chunk c+1 was requested two steps ago; c+2 and c+3 stay in flight
+        load_chunk(a, chunk_at(c_far), lane, far);
+        const ChunkRegs &cur = cur_r, &nxt = nxt_r;
         const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
         uint32_t rawa[Gp::NMAX];
-        if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of chunk c+1 goes in flight
+        if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of the next chunk goes in flight
         if (ABL == 1) {
             abl_acc ^= cur.W[0] ^ cur.W[1] ^ cur.W[2] ^ cur.W[3] ^ cur.W[4] ^ cur.M[0] ^ cur.M[1];
         } else {
             uint32_t blo, bhi;
             __builtin_amdgcn_s_setprio(2);
             kssd_grp_merge<SUBK, KSSD_GW, 1>(raw, blo, bhi);  // waits for the B reads of chunk c only
-            uint32_t cl = alo & blo & cur.M[0];  // the window start itself must be a base: kills padding / N stretches early
-            uint32_t ch = ahi & bhi & cur.M[1];
+            const uint32_t real = c < a.n_chunks ? 0xFFFFFFFFu : 0u;  // (the batch's last block may be short: its missing chunks hold nothing)
+            uint32_t cl = alo & blo & cur.M[0] & real;  // the window start itself must be a base: kills padding / N stretches early
+            uint32_t ch = ahi & bhi & cur.M[1] & real;
             __builtin_amdgcn_s_setprio(0);
             if (ABL == 2) {
                 abl_acc ^= cl ^ ch;
             } else {
                 // every pass takes one candidate of every lane that still has one: cut its pattern out of the lane's
                 // registers and buffer (position, pattern) by ballot compaction.  No LDS read in this loop: a read
-                // would have to wait behind the table reads of chunk c+1 that are in flight
-                const uint32_t crel = (uint32_t)(c - c0);
+                // would have to wait behind the table reads of the next chunk that are in flight
                 const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);  // lane and both neighbours all bases
-                const uint32_t ebase = ((crel & 2047u) << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
+                const uint32_t ebase = (crel << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
                 // the neighbouring lane's last packed word (v_mov_b32 wave_shr:1; lane 0 keeps the previous chunk's tail)
                 const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s_tail, (int)cur.W[3], 0x138, 0xf, 0xf, false);
                 for (;;) {
@@ -586,7 +617,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     if (hbal == 0) break;
                     if (cn + 64 > CBUF) {  // dense parameter sets only: make room
                         wave_lds_sync();
-                        const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
+                        const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, blk_c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
                         stored += m;
                         n_rounded += 64;
                         cn -= 64;
@@ -594,7 +625,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     }
                     if (has) {
                         // lowest set bit of (ch:cl), taken and cleared as one 64-bit value: no select on which word holds it
-                        // (selects become v_cndmask_b32, the slowest instruction of this loop by a factor of four)
                         const unsigned long long m64 = ((unsigned long long)ch << 32) | cl;
                         const uint32_t b = (uint32_t)__builtin_ctzll(m64);
                         const unsigned long long rest = m64 & (m64 - 1ull);
@@ -610,46 +640,52 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
             s_tail = __builtin_amdgcn_readlane(cur.W[3], 63);
             vb_prev = vb;
             __builtin_amdgcn_s_setprio(2);
-            // chunk c+1: alignment A is in; nothing is outstanding in LDS now, which is the cheap moment for a
-            // stage-1.5 round; then alignment B goes in flight across the loop edge
+            // the next chunk: alignment A is in; nothing is outstanding in LDS now, which is the cheap moment for a
+            // stage-1.5 round; then alignment B goes in flight across the loop edge.  A block's last step empties the
+            // buffer: the block's survivors then sit in one run of the wave's slice (blk_info), and an entry never waits
+            // longer than a block (it names its chunk relative to the block's first one)
             kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
-            if (ABL != 2 && cn >= 64) {
-                wave_lds_sync();
-                const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, (uint32_t)(c - c0), cbuf, cn - 64, 64, stored, lane, abl_acc);
-                stored += m;
-                n_rounded += 64;
-                cn -= 64;
-            }
-            if (ABL != 2 && ((uint32_t)(c - c0) & 2047u) == 2047u) {
-                // A round takes the NEWEST 64 entries, so the ones at the bottom of the buffer can wait for as long as the wave
-                // runs -- and an entry names its chunk modulo 2048 (bloom_round's `age`).  Every 2048 chunks the buffer is
-                // emptied: no entry is ever older than 2047 chunks, however many chunks a wave owns (a 34 GB read set, a batch
-                // of mammalian genomes: more than 2048 chunks per wave).  One partial round per 8.4 M positions.
-                while (cn) {
+            if (ABL != 2) {
+                while (cn >= 64 || (last && cn)) {
                     const uint32_t n = cn < 64 ? cn : 64;
                     wave_lds_sync();
-                    const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, (uint32_t)(c - c0), cbuf, cn - n, n, stored, lane, abl_acc);
+                    const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, blk_c0, crel, cbuf, cn - n, n, stored, lane, abl_acc);
                     stored += m;
                     n_rounded += n;
                     cn -= n;
+                    if (!last) break;
                 }
             }
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
         }
     };
-    for (unsigned long long c = c0; c < c1; c += 4) {
-        step(r0, r1, r3, c);
-        if (c + 1 < c1) step(r1, r2, r0, c + 1);
-        if (c + 2 < c1) step(r2, r3, r1, c + 2);
-        if (c + 3 < c1) step(r3, r0, r2, c + 3);
-    }
-    while (cn) {
-        const uint32_t n = cn < 64 ? cn : 64;
-        wave_lds_sync();
-        const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, c0, (uint32_t)(c1 - 1 - c0), cbuf, cn - n, n, stored, lane, abl_acc);
-        stored += m;
-        n_rounded += n;
-        cn -= n;
+    static_assert(SCAN_BLOCK == 4, "a block is the four written-out steps below");
+    for (;;) {
+        const unsigned long long c = blk_c0;
+        const bool more = b_nxt < n_blocks;
+        // chunks of the block after this one (none: reads clamped to the last chunk of the batch, never looked at)
+        const unsigned long long nb = more ? (unsigned long long)b_nxt * SCAN_BLOCK : clast;
+        const uint32_t b_nn = take(b_nxt);
+        // the word in front of the next block's first chunk, for lane 0 of its first step: the last 64 words of the chunk in
+        // front of it, one per lane (a wave-uniform address would become a scalar load, whose counter is the LDS reads' too)
+        uint32_t tail_v = 0;
+        if (more && nb) tail_v = a.packed[nb * 256 - 64 + lane];
+        const uint32_t first_stored = stored;
+        step(r0, r1, r3, c, 0u, c + 3, false);
+        step(r1, r2, r0, c + 1, 1u, nb, false);
+        step(r2, r3, r1, c + 2, 2u, nb + 1, false);
+        step(r3, r0, r2, c + 3, 3u, nb + 2, true);
+        if (ABL == 0 && lane == 0) {  // where the block's survivors are (clamped to what the slice holds: an overflow is reported below)
+            const unsigned long long cap = a.cand_cap;
+            const unsigned long long f = first_stored < cap ? first_stored : cap, e = stored < cap ? stored : cap;
+            a.blk_info[b_cur] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
+        }
+        if (!more) break;
+        b_cur = b_nxt;
+        b_nxt = b_nn;
+        blk_c0 = nb;
+        s_tail = __builtin_amdgcn_readlane(tail_v, 63);
+        vb_prev = 0;
     }
 #ifdef KSSD_DEV
     if (a.dev_times && lane == 0) {
@@ -660,6 +696,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
 #endif
     if (lane == 0) {
         a.cand_count[wid] = stored;
+        if (stored > a.cand_cap) {  // the wave wanted to list more than its slice holds: the call is repeated larger
+            atomicOr(&a.status->cand_overflow, 1u);
+            atomicMax(&a.status->cand_need, stored);
+        }
         atomicAdd(&a.status->n_stage1, (unsigned long long)n_rounded);
         atomicAdd(&a.status->n_bloom, (unsigned long long)stored);  // every survivor of a round was counted into `stored`
     }
@@ -965,10 +1005,7 @@ __device__ __forceinline__ void sort_in_registers(K *a, const K *__restrict__ sr
 // chunk -> genome map, one kernel less.  Used whenever no genome of the batch needs the global-memory path.
 struct FuseArgs {
     const ulonglong2 *cand;
-    unsigned long long cand_cap;
-    const uint32_t *cand_count;
-    unsigned long long per;          // chunks per scan wave (slice w covers chunks [w * per, (w + 1) * per))
-    uint32_t n_slices;
+    const unsigned long long *blk_info;  // per block of SCAN_BLOCK chunks: first record and record count (scan_blk_pack)
     const unsigned long long *chunk_off;
     const uint32_t *packed, *mask;
     const KssdG *G;
@@ -994,27 +1031,28 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     uint32_t n;
     if (FUSED) {
         __shared__ uint32_t s_n, s_pref[DEDUP_THREADS];
+        __shared__ unsigned long long s_first[DEDUP_THREADS];
         const uint32_t lane = lane_id();
         if (tid == 0) s_n = 0;
         const unsigned long long cb = fx.chunk_off[g], ce = fx.chunk_off[g + 1];
         const long long glo = (long long)(cb * KSSD_CHUNK), ghi = (long long)(ce * KSSD_CHUNK);
-        const unsigned long long w0 = ce > cb ? cb / fx.per : 1, w1 = ce > cb ? (ce - 1) / fx.per : 0;  // empty genome: no slice
+        // the blocks of the scan that overlap the genome's chunks (an empty genome: none)
+        const unsigned long long w0 = ce > cb ? cb / SCAN_BLOCK : 1, w1 = ce > cb ? (ce - 1) / SCAN_BLOCK : 0;
         __syncthreads();
         for (unsigned long long wbase = w0; wbase <= w1; wbase += DEDUP_THREADS) {
-            // candidates of up to 512 slices, flattened: prefix of their counts in LDS, then FUSE_PER per thread and round
+            // candidates of up to 512 blocks, flattened: prefix of their counts in LDS, then FUSE_PER per thread and round
             const unsigned long long w = wbase + tid;
             uint32_t cw = 0;
-            if (w <= w1 && w < fx.n_slices) {
-                cw = fx.cand_count[w];
-                if (cw > fx.cand_cap) {  // the scan wave wanted to list more than its slice holds: the call is repeated larger
-                    atomicOr(&st->cand_overflow, 1u);
-                    atomicMax(&st->cand_need, cw);
-                    cw = (uint32_t)fx.cand_cap;
-                }
+            unsigned long long first = 0;
+            if (w <= w1) {
+                const unsigned long long info = fx.blk_info[w];
+                cw = scan_blk_count(info);
+                first = scan_blk_first(info);
             }
             uint32_t total;
             const uint32_t before = block_excl_scan(cw, wsum, total);
             s_pref[tid] = before;
+            s_first[tid] = first;
             __syncthreads();
             for (uint32_t f0 = 0; f0 < total; f0 += DEDUP_THREADS * FUSE_PER) {
                 bool ok[FUSE_PER];
@@ -1027,13 +1065,13 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                     ok[j] = f < total;
                     cd[j] = make_ulonglong2(0ull, 0ull);
                     if (ok[j]) {
-                        uint32_t lo = 0, hi = DEDUP_THREADS - 1;  // last slice s with s_pref[s] <= f
+                        uint32_t lo = 0, hi = DEDUP_THREADS - 1;  // last block s with s_pref[s] <= f
                         while (lo < hi) {
                             const uint32_t mid = (lo + hi + 1) >> 1;
                             if (s_pref[mid] <= f) lo = mid;
                             else hi = mid - 1;
                         }
-                        cd[j] = fx.cand[(wbase + lo) * fx.cand_cap + (f - s_pref[lo])];
+                        cd[j] = fx.cand[s_first[lo] + (f - s_pref[lo])];
                     }
                 }
 #pragma unroll
@@ -1383,11 +1421,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         // no genome needs the global-memory sort: exact stage and per-genome sort in one kernel, straight from the candidate list
         const auto &pl = c->plan;
         fx.cand = reinterpret_cast<const ulonglong2 *>(c->d_cand);
-        fx.cand_cap = pl.cand_cap;
-        fx.cand_count = c->d_cand_count;
-        fx.n_slices = pl.n_slices;
-        fx.per = (pl.n_chunks + pl.n_slices - 1) / pl.n_slices;  // the scan kernel's partition of the chunks over its waves
-        if (fx.per == 0) fx.per = 1;
+        fx.blk_info = c->d_blk_info;
         fx.chunk_off = (const unsigned long long *)c->d_chunk_off;
         fx.packed = pl.d_packed;
         fx.mask = pl.d_mask;
@@ -1539,6 +1573,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
     if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices * 2)) != KSSD_OK) return rc;  // 16-byte records
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_blk_info, &c->cap_blk_info, (size_t)((n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK) + 1)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
     pl.big_min = big_min; pl.max_cap = max_cap; pl.max_big = max_big; pl.cand_cap = cand_cap; pl.n_slices = n_slices; pl.grid = grid;
     pl.valid = true;
@@ -1604,6 +1639,11 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     ScanArgs a;
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
+    a.blk_info = c->d_blk_info;
+    a.dynamic = 1;
+#ifdef KSSD_DEV
+    if (getenv("KSSD_DEV_STATIC")) a.dynamic = 0;
+#endif
     a.status = c->d_status;
 #ifdef KSSD_DEV
     {

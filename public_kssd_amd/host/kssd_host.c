@@ -374,7 +374,7 @@ typedef struct {
 static inline int gw_room(gwriter *w)
 {
     /* make sure position base_pos + p is inside the buffers */
-    if (w->limit) return w->p < w->limit ? KSSD_HOST_OK : KSSD_HOST_ERR_PARAM; /* reserved and zeroed up front */
+    if (w->fixed) return w->p < w->limit ? KSSD_HOST_OK : KSSD_HOST_ERR_PARAM; /* reserved and zeroed up front */
     uint64_t chunk = (w->base_pos + w->p) / CHUNK_BASES;
     if (chunk >= w->b->cap_chunks) return batch_reserve_chunks(w->b, chunk + 1);
     return KSSD_HOST_OK;
@@ -442,8 +442,8 @@ static void gw_start_fixed(gwriter *w, kssd_batch *b, uint32_t g)
     w->p = 0;
     w->pending_break = 0;
     w->pw = w->mw = 0;
-    w->limit = (b->chunk_off[g + 1] - b->chunk_off[g]) * CHUNK_BASES;
-    if (!w->limit) w->limit = 1; /* an empty reservation: nothing may be written */
+    w->limit = (b->chunk_off[g + 1] - b->chunk_off[g]) * CHUNK_BASES; /* 0 for an empty reservation: nothing may be written */
+    w->fixed = 1;
     w->genome = g;
 }
 
@@ -451,7 +451,7 @@ static void gw_finish(gwriter *w)
 {
     kssd_batch *b = w->b;
     gw_flush(w);
-    if (w->limit) { /* the layout was fixed by kssd_batch_reserve */
+    if (w->fixed) { /* the layout was fixed by kssd_batch_reserve */
         b->n_pos[w->genome] = w->p;
         return;
     }
