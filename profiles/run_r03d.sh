@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, fourth GPU call: the scan with blocks from a queue against a static round-robin of the same blocks (A/B in the
+# round 3: the scan with blocks from per-workgroup queues against a static round-robin of the same blocks (A/B in the
 # development build), parity suite, default line
 tag=${1:-r03d}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

@@ -57,6 +57,7 @@ extern "C" const char *kssd_gpu_strerror(int code)
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
+#define SCAN_QUEUE_STRIDE 32  // u32 words between the block-queue heads of two scan workgroups (one 128-byte line each)
 #define CBUF 128          // per-wave buffer of stage-1 candidates waiting for the Bloom test (8 B each)
 #define SKETCH_TRACK_FILL 0x80000000u  // internal flag: record the fullest staging region even without an overflow
 #define DEDUP_THREADS 512
@@ -75,7 +76,6 @@ struct SketchStatus {
     unsigned long long n_stage1, n_bloom;
     unsigned int cand_overflow;    // a shard of the candidate list was too small
     unsigned int cand_need;        // entries the fullest shard wanted
-    unsigned int queue_next;       // the scan's block queue: next block nobody has taken yet (set to the number of waves by PREP)
 };
 
 struct kssd_gpu_ctx {
@@ -103,6 +103,8 @@ struct kssd_gpu_ctx {
     size_t cap_cand_count;
     unsigned long long *d_blk_info;  // per block of the last scan: where its candidates are (scan_blk_pack)
     size_t cap_blk_info;
+    uint32_t *d_scan_queue;          // per scan workgroup: head of its block queue
+    size_t cap_scan_queue;
     uint64_t last_cand_cap;
     uint64_t cand_floor;    // per-slice capacity an overflowed attempt asked for (kept for the retries)
     double cand_factor;
@@ -273,7 +275,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_scan_queue, c->d_big_alt, c->d_big_tmp,
                     c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -371,10 +373,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 // (it also zeroes the small per-call state: four separate memsets cost more than this whole kernel)
 __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes, uint64_t n_chunks,
                                  uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                 uint32_t n_slices, uint32_t *__restrict__ status_words)
+                                 uint32_t n_slices, uint32_t *__restrict__ status_words, uint32_t *__restrict__ scan_queue)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < sizeof(SketchStatus) / 4) status_words[c] = c == offsetof(SketchStatus, queue_next) / 4 ? n_slices : 0u;
+    if (c < sizeof(SketchStatus) / 4) status_words[c] = 0;
+    if (c < n_slices / SCAN_WAVES) scan_queue[c * SCAN_QUEUE_STRIDE] = SCAN_WAVES;  // every workgroup's waves start with a block of their own
     if (c < n_genomes) cursor[c] = 0;
     if (c < n_slices) cand_count[c] = 0;
     if (c >= n_chunks) return;
@@ -391,11 +394,12 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
 // when genomes span many chunks.  The per-call state is zeroed by the first workgroups like above.
 __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes,
                                            uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                           uint32_t n_slices, uint32_t *__restrict__ status_words)
+                                           uint32_t n_slices, uint32_t *__restrict__ status_words, uint32_t *__restrict__ scan_queue)
 {
     // grid = (genomes or more, parts): workgroup (g, y) writes every gridDim.y-th run of 256 chunks of genome g
     const uint64_t t = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
-    if (t < sizeof(SketchStatus) / 4) status_words[t] = t == offsetof(SketchStatus, queue_next) / 4 ? n_slices : 0u;
+    if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
+    for (uint64_t i = t; i < n_slices / SCAN_WAVES; i += nt) scan_queue[i * SCAN_QUEUE_STRIDE] = SCAN_WAVES;
     for (uint64_t i = t; i < n_genomes; i += nt) cursor[i] = 0;
     for (uint64_t i = t; i < n_slices; i += nt) cand_count[i] = 0;
     if (blockIdx.x >= n_genomes) return;
@@ -424,6 +428,7 @@ struct ScanArgs {
     unsigned long long cand_cap;    // per wave
     uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
     unsigned long long *blk_info;   // per block of SCAN_BLOCK chunks: where its candidates sit in the list (scan_blk_pack)
+    uint32_t *queue;                // per workgroup (SCAN_QUEUE_STRIDE words apart): the next block of its run nobody has taken
     uint32_t dynamic;               // 1: blocks from the queue (the product); 0: a static round-robin (development A/B)
     SketchStatus *status;
 #ifdef KSSD_DEV
@@ -431,11 +436,14 @@ struct ScanArgs {
 #endif
 };
 
-// The scan's unit of work distribution: a block of SCAN_BLOCK consecutive chunks.  Waves take blocks from a queue (the first
-// one by their index, the following ones with an atomic on SketchStatus::queue_next), so a wave that runs ahead -- waves do
-// not get the same share of a CU's LDS and issue slots, CUs not the same share of the memory system: measured, the fastest
-// tenth of the waves of a static partition finished their equal shares at 70 % of the launch's time -- simply works off more
-// blocks, and the launch ends when the queue is empty instead of when the slowest wave has worked off its fixed share.
+// The scan's unit of work distribution: a block of SCAN_BLOCK consecutive chunks.  A workgroup owns one contiguous run of the
+// batch's blocks; its 16 waves take them from the workgroup's queue (the first one by their index, the following ones with
+// an atomic on the queue's head), so a wave that runs ahead simply works off more blocks and the workgroup ends when its run
+// is through instead of when its slowest wave has worked off a fixed share.  Measured on a static partition (equal shares
+// per wave): in EVERY workgroup the fastest wave finished its share at 70 % of the time the slowest one took -- the waves
+// of a CU do not get equal shares of its LDS and issue slots -- while the workgroups' means were equal to within 2 %: the
+// imbalance is inside the CU, and that is where it is levelled (a queue head per workgroup: 16 pullers on a line of its own;
+// ONE head for the whole grid was tried and saturates -- 305 000 atomics on one address take 3.6 ms).
 // A wave lists the survivors of a block contiguously in its own slice of the candidate list and leaves, per block, where:
 //   bits 0-23 the number of records, bits 24-63 the index of the first one in the whole list
 #define SCAN_BLOCK 4
@@ -519,11 +527,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates, see bloom_round
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
-    // work distribution: blocks of SCAN_BLOCK chunks from a queue (see SCAN_BLOCK); the wave's first block is its own index
-    const uint32_t total_waves = gridDim.x * SCAN_WAVES;
+    // work distribution: the workgroup's run of blocks, its waves take them from a queue (see SCAN_BLOCK)
     const uint32_t wid = blockIdx.x * SCAN_WAVES + wave;
     const unsigned long long clast = a.n_chunks - 1;  // reads past the end of the batch are clamped, their results unused
-    const uint32_t n_blocks = (uint32_t)((a.n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    const uint32_t n_blocks_all = (uint32_t)((a.n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    const uint32_t wg_per = (n_blocks_all + gridDim.x - 1) / gridDim.x;
+    const uint32_t wg_first = blockIdx.x * wg_per;
+    const uint32_t n_blocks = wg_first >= n_blocks_all ? 0u : (n_blocks_all - wg_first < wg_per ? n_blocks_all - wg_first : wg_per);  // of this workgroup
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
 #ifdef KSSD_DEV
     const unsigned long long dev_t0 = __builtin_readcyclecounter();
@@ -531,13 +541,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // the next block nobody has taken yet.  The atomic's answer is not needed before the wave is three chunks into the
     // block it is working on: vector memory operations return in order, so by then the chunk loads issued behind it are in too
     auto take = [&](uint32_t prev) -> uint32_t {
-        if (!a.dynamic) return prev >= n_blocks ? prev : prev + total_waves;  // (development: a static round-robin of the blocks)
+        if (!a.dynamic) return prev >= n_blocks ? prev : prev + SCAN_WAVES;  // (development: a static round-robin of the blocks)
         uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&a.status->queue_next, 1u);
+        if (lane == 0) v = atomicAdd(&a.queue[blockIdx.x * SCAN_QUEUE_STRIDE], 1u);
         return __builtin_amdgcn_readfirstlane(v);
     };
     auto chunk_at = [&](unsigned long long c) -> unsigned long long { return c < clast ? c : clast; };
-    uint32_t b_cur = wid, b_nxt = take(b_cur);
+    uint32_t b_cur = wave, b_nxt = take(b_cur);  // indices into the workgroup's run
 
     // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
     // first reads overlaps the 144 KiB copy instead of following it
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint32_t raw[Gp::NMAX];
     uint32_t alo, ahi;
     {
-        const unsigned long long c0 = (unsigned long long)b_cur * SCAN_BLOCK;
+        const unsigned long long c0 = (unsigned long long)(wg_first + b_cur) * SCAN_BLOCK;
         load_chunk(a, chunk_at(c0), lane, r0);
         load_chunk(a, chunk_at(c0 + 1), lane, r1);
         load_chunk(a, chunk_at(c0 + 2), lane, r2);
@@ -561,9 +571,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // (lane 0: the last word of the chunk before, carried in an SGPR from step to step) and whether the neighbours' 64
     // positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour is not looked at, and
     // neither is lane 0's left one in the first chunk of a block: their candidates -- ~2 % -- let the exact stage read the mask)
-    uint32_t s_tail = b_cur ? __builtin_amdgcn_readfirstlane(a.packed[(unsigned long long)b_cur * SCAN_BLOCK * 256 - 1]) : 0u;
+    unsigned long long blk_c0 = (unsigned long long)(wg_first + b_cur) * SCAN_BLOCK;  // first chunk of the block being worked on
+    uint32_t s_tail = blk_c0 ? __builtin_amdgcn_readfirstlane(a.packed[blk_c0 * 256 - 1]) : 0u;
     uint64_t vb_prev = 0;
-    unsigned long long blk_c0 = (unsigned long long)b_cur * SCAN_BLOCK;  // first chunk of the block being worked on
 
     // prologue: the block's first chunk through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         const unsigned long long c = blk_c0;
         const bool more = b_nxt < n_blocks;
         // chunks of the block after this one (none: reads clamped to the last chunk of the batch, never looked at)
-        const unsigned long long nb = more ? (unsigned long long)b_nxt * SCAN_BLOCK : clast;
+        const unsigned long long nb = more ? (unsigned long long)(wg_first + b_nxt) * SCAN_BLOCK : clast;
         const uint32_t b_nn = take(b_nxt);
         // the word in front of the next block's first chunk, for lane 0 of its first step: the last 64 words of the chunk in
         // front of it, one per lane (a wave-uniform address would become a scalar load, whose counter is the LDS reads' too)
@@ -678,7 +688,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         if (ABL == 0 && lane == 0) {  // where the block's survivors are (clamped to what the slice holds: an overflow is reported below)
             const unsigned long long cap = a.cand_cap;
             const unsigned long long f = first_stored < cap ? first_stored : cap, e = stored < cap ? stored : cap;
-            a.blk_info[b_cur] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
+            a.blk_info[wg_first + b_cur] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
         }
         if (!more) break;
         b_cur = b_nxt;
@@ -945,7 +955,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_key(unsigned long long v,
 }
 
 template <typename K, int EPT>
-__device__ __forceinline__ void sort_in_registers(K *a, const K *__restrict__ src, uint32_t n, uint32_t tid)
+__device__ __forceinline__ void sort_in_registers(K *a, const K *src /* may be a itself (fused path): no __restrict__ */, uint32_t n, uint32_t tid)
 {
     constexpr uint32_t np = EPT * DEDUP_THREADS;
     K x[EPT];
@@ -1573,6 +1583,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
     if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices * 2)) != KSSD_OK) return rc;  // 16-byte records
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_scan_queue, &c->cap_scan_queue, (size_t)(grid > 0 ? grid : 1) * SCAN_QUEUE_STRIDE)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_blk_info, &c->cap_blk_info, (size_t)((n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK) + 1)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
     pl.big_min = big_min; pl.max_cap = max_cap; pl.max_big = max_big; pl.cand_cap = cand_cap; pl.n_slices = n_slices; pl.grid = grid;
@@ -1608,13 +1619,13 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
         if (parts > 1024) parts = 1024;
         hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64, (unsigned)(parts ? parts : 1)), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
-                           reinterpret_cast<uint32_t *>(c->d_status));
+                           reinterpret_cast<uint32_t *>(c->d_status), c->d_scan_queue);
         HIPCK(hipGetLastError());
         return KSSD_OK;
     }
     hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
                        (const uint64_t *)c->d_chunk_off, pl.n_genomes, pl.n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
-                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status));
+                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status), c->d_scan_queue);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -1640,6 +1651,7 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.blk_info = c->d_blk_info;
+    a.queue = c->d_scan_queue;
     a.dynamic = 1;
 #ifdef KSSD_DEV
     if (getenv("KSSD_DEV_STATIC")) a.dynamic = 0;

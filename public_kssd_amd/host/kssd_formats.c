@@ -920,15 +920,20 @@ static int print_rows(const char *path, const uint32_t *shared, const uint64_t *
 }
 
 /* ---- kssd reverse ------------------------------------------------------------------------------------- */
+/* An id back to its canonical k-mer -- the inverse of the sketch's reduction (kssd_core.h kssd_s2_tuple; the reference:
+ * core_reverse2unituple, command_reverse.c:311-321).  Forwards, a canonical 2k-mer  L | M | R  (L, R: the k - subk bases on
+ * either side, M: the 2 subk bases of the sub-context) became   id = (((L | R) << 4 subk) >> 4 drlevel) + rank(M).
+ * Backwards: the rank is the id modulo 4096 (MIN_SUBCTX_DIM_SMP_SZ -- the reference's assumption, exact whenever
+ * 4 (subk - drlevel) <= 12; `kssd reverse` refuses other shuffles), M = accepted[rank], L | R = what stands above the
+ * 4 (subk - drlevel) rank bits, and the three pieces go back to their places. */
 uint64_t kssd_reverse_id(uint32_t full_id, int k, int subk, int drlevel, const uint32_t *accepted)
 {
-    const int inner_ctx_bits = subk * 4, half_outer_ctx_bits = (k - subk) * 2, pf_bits = (subk - drlevel) * 4;
-    const uint64_t drtuple = full_id;
-    const uint64_t ind = accepted[drtuple % 4096u]; /* MIN_SUBCTX_DIM_SMP_SZ, command_reverse.c:313 */
-    const uint64_t tuple = ((drtuple >> pf_bits) << inner_ctx_bits) + ind;
-    const uint64_t half_outer_ctx_mask = ((1ull << half_outer_ctx_bits) - 1ull) << inner_ctx_bits;
-    return (tuple & (half_outer_ctx_mask << half_outer_ctx_bits)) + ((tuple & half_outer_ctx_mask) >> inner_ctx_bits) +
-           ((tuple & ((1ull << inner_ctx_bits) - 1ull)) << half_outer_ctx_bits);
+    const int side = 2 * (k - subk);      /* bits of L, and of R */
+    const int mid = 4 * subk;             /* bits of M */
+    const uint64_t M = accepted[full_id % 4096u];
+    const uint64_t LR = (uint64_t)full_id >> (4 * (subk - drlevel));
+    const uint64_t L = LR >> side, R = LR & ((1ull << side) - 1ull);
+    return (L << (mid + side)) + (M << side) + R;
 }
 
 int kssd_shuf_accepted(const kssd_shuf *s, uint32_t *accepted)

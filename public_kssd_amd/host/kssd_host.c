@@ -367,7 +367,8 @@ typedef struct {
     uint64_t p;        /* positions written so far */
     int pending_break; /* a run-breaking byte was seen since the last base */
     uint32_t pw, mw;   /* the packed / mask word being put together (stored when full, gw_put) */
-    uint64_t limit;    /* fixed mode (kssd_batch_fill_text): the genome's reserved positions; 0 = growing mode */
+    uint64_t limit;    /* fixed mode (kssd_batch_fill_text): the genome's reserved positions (0: an empty reservation) */
+    int fixed;         /* 1 = fixed mode, 0 = growing mode */
     uint32_t genome;   /* fixed mode: which genome */
 } gwriter;
 
@@ -432,6 +433,7 @@ static void gw_start(gwriter *w, kssd_batch *b)
     w->pending_break = 0;
     w->pw = w->mw = 0;
     w->limit = 0;
+    w->fixed = 0;
     w->genome = 0;
 }
 
@@ -466,7 +468,7 @@ static void gw_finish(gwriter *w)
 static void gw_abort(gwriter *w)
 {
     kssd_batch *b = w->b;
-    if (w->limit) {
+    if (w->fixed) {
         const uint64_t c0 = b->chunk_off[w->genome], c1 = b->chunk_off[w->genome + 1];
         memset(b->packed + c0 * CHUNK_WORDS, 0, (size_t)(c1 - c0) * CHUNK_WORDS * 4);
         memset(b->mask + c0 * CHUNK_MASKW, 0, (size_t)(c1 - c0) * CHUNK_MASKW * 4);

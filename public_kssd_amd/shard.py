@@ -117,7 +117,12 @@ class ShardedSearch:
         max_ids: upper bound of the ids one rank holds (sizes the index).  tstream: the torch stream object that
         wraps `stream` (the collective is issued under it)."""
         w, G = self.world, self.G
+        if stream is not None and tstream is not None and int(tstream.cuda_stream) != int(stream):
+            raise ValueError("tstream must wrap `stream`: the engine calls and the collective have to be ordered on one stream")
         if self._overlap:
+            if stream is not None and tstream is None and int(stream) != int(torch.cuda.current_stream().cuda_stream):
+                raise ValueError("overlap mode: pass tstream= together with stream= (the exchange is ordered behind the rank's "
+                                 "sketches by an event recorded on that stream)")
             cur = tstream if tstream is not None else torch.cuda.current_stream()
             self._ev_ready.record(cur)                 # the rank's sketches are complete
             self._cstream.wait_event(self._ev_ready)

@@ -70,3 +70,19 @@ def test_fill_reports_malformed_input_and_leaves_the_slot_empty():
     b.fill_text(g + 1, b">ok\nACGTACGTACGTACGTACGTACGT\n")
     p0, m0 = _genome_words(b, g)
     assert not p0.any() and not m0.any() and b.n_positions(g) == 0 and b.n_positions(g + 1) == 24
+
+
+def test_an_empty_reservation_takes_no_bases():
+    """a genome reserved with no room must refuse text instead of writing into its neighbour's first chunk"""
+    b = K.Batch()
+    g = b.reserve([0, 100])
+    b.fill_text(g + 1, b">n\nACGTACGTACGTACGTACGTACGT\n")
+    before_p, before_m = [x.copy() for x in _genome_words(b, g + 1)]
+    b.fill_text(g, b">only a header\n")                      # nothing to write: fine
+    try:
+        b.fill_text(g, b">x\nACGTACGT\n")
+        assert False, "expected an error"
+    except K.KssdError as e:
+        assert e.code == -2 or e.code < 0
+    after_p, after_m = _genome_words(b, g + 1)
+    assert np.array_equal(before_p, after_p) and np.array_equal(before_m, after_m) and b.n_positions(g) == 0
