@@ -211,6 +211,23 @@ int kssd_gpu_sketch_fasta_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uin
                                uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                                uint32_t **out_pos, int64_t *bad_genome);
 /*
+ * The quality floor of the FASTQ calls below (fastq2co's -Q, iseq2comem.c:312: a base counts only if the byte in the same
+ * column of the record's fourth line is >= min_quality; 0 = none, the default; at most 127).  Stays set on the context.
+ * A file whose quality lines are shorter than their bases is handed back like the other cases only the reference's own
+ * fgets() sequence reproduces.
+ */
+int kssd_gpu_set_fastq_quality(kssd_gpu_ctx *ctx, int min_quality);
+
+/*
+ * on != 0: the FASTQ calls below frame their input as mt_shortreads2koc does (dist -A, iseq2comem.c:552-615): records of
+ * four lines, the second one scanned, no quality floor, line buffer of 4 096 bytes.  On complete files of ordinary reads
+ * that is fastq2co's framing; what differs -- a file that does not end with the line end of a complete record, a line of
+ * 4 000 bytes or more -- is handed back to the host tokeniser (kssd_batch_fill_text, kind 2).  The "lines" output of such
+ * a call is 4 x the records scanned.  Stays set on the context.
+ */
+int kssd_gpu_set_fastq_reads(kssd_gpu_ctx *ctx, int on);
+
+/*
  * The same two for FASTQ read sets as fastq2co reads them with -Q 0 (iseq2comem.c:274-330: records of four lines, only
  * the second one scanned, a read never continues the k-mer of the read in front of it, a final record its four lines
  * do not complete is not scanned).  An input the device cannot do exactly as the reference -- no complete record, a line

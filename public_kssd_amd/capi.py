@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads",
 ]
 
 
@@ -797,6 +797,14 @@ class GpuCtx:
     def set_lds_sort_limit(self, max_tuples):
         """genomes staging more tuples than this take the global-memory dedup path (0 = default); results unchanged"""
         _gck(gpu_lib().kssd_gpu_set_lds_sort_limit(self.h, max_tuples))
+
+    def set_fastq_quality(self, min_quality):
+        """the quality floor (fastq2co -Q) of the following FASTQ text calls; 0 = none"""
+        _gck(gpu_lib().kssd_gpu_set_fastq_quality(self.h, int(min_quality)))
+
+    def set_fastq_reads(self, on):
+        """FASTQ text calls frame their input like dist -A (mt_shortreads2koc); what only the host does exactly is handed back"""
+        _gck(gpu_lib().kssd_gpu_set_fastq_reads(self.h, int(bool(on))))
 
     def set_scan_grid(self, max_workgroups):
         """at most this many scan workgroups (0 = one per CU): longer chunk runs per wave; results unchanged"""

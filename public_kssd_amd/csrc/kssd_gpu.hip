@@ -152,6 +152,10 @@ struct kssd_gpu_ctx {
     size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text, cap_tok_sup;
     uint32_t tok_files;
     bool tok_fastq = false;
+    int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
+    bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
+    int *d_tok_q = nullptr;  // per tile: newlines around it (quality floor)
+    size_t cap_tok_q = 0;
     hipEvent_t text_ev[32];  // kssd_gpu_text_put: the last 32 copies
     uint64_t text_puts;
     std::vector<unsigned long long> h_tok_tab;
@@ -276,7 +280,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_scan_queue, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : c->text_ev)
@@ -578,7 +582,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // prologue: the block's first chunk through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
     kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
+#if defined(KSSD_SCAN_NOPRED)
     kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of the first chunk in flight
+#else
+    kssd_grp_issue_b_where_a<SUBK, KSSD_GW>(r0.W, T1, alo & r0.M[0], ahi & r0.M[1], raw);  // alignment B of the first chunk in flight
+#endif
 
     // one chunk.  The four register sets rotate by name (a block is four steps, written out): copying one
     // set into another would make every iteration wait for the reads it has just issued.
@@ -666,7 +674,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     if (!last) break;
                 }
             }
+#if defined(KSSD_SCAN_NOPRED)
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
+#else
+            kssd_grp_issue_b_where_a<SUBK, KSSD_GW>(nxt.W, T1, alo & nxt.M[0], ahi & nxt.M[1], raw);
+#endif
         }
     };
     static_assert(SCAN_BLOCK == 4, "a block is the four written-out steps below");
@@ -1652,9 +1664,9 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.blk_info = c->d_blk_info;
     a.queue = c->d_scan_queue;
-    a.dynamic = 1;
+    a.dynamic = 0;
 #ifdef KSSD_DEV
-    if (getenv("KSSD_DEV_STATIC")) a.dynamic = 0;
+    if (getenv("KSSD_DEV_QUEUE")) a.dynamic = 1;
 #endif
     a.status = c->d_status;
 #ifdef KSSD_DEV

@@ -490,7 +490,7 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     int rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
     if (rc == KSSD_ERR_UNSUPPORTED && (j->tx || j->streamed) && is_fq) {
         /* an input the device tokeniser does not do exactly as fastq2co (no complete record, a line its fgets() buffer
-         * splits, NUL or 8-bit bytes): the whole job through the host tokeniser */
+         * splits, NUL or 8-bit bytes, with -Q a quality line shorter than its bases): the whole job through the host tokeniser */
         j->own_b = kssd_batch_create();
         uint64_t *maxpos = malloc((size_t)n * sizeof *maxpos);
         if (!j->own_b || !maxpos) die(ENOMEM, "out of memory");
@@ -503,20 +503,20 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
             unsigned char *txt = NULL;
             size_t cap = 0, len = 0;
             trc = kssd_slurp_reuse(fl->path[first_file], &txt, &cap, &len);
-            if (!trc) trc = kssd_batch_fill_text(j->own_b, first, 1, txt, len, 0, &j->lines[0]);
+            if (!trc) trc = kssd_batch_fill_text(j->own_b, first, o->abundance ? 2 : 1, txt, len, o->kmerqlty, &j->lines[0]);
             if (trc == KSSD_HOST_ERR_EMPTY) trc = 0;
             free(txt);
         } else {
 #pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 1) reduction(| : trc)
             for (uint32_t g = 0; g < n; g++) {
-                const int r = kssd_batch_fill_text(j->own_b, first + g, 1, j->tx->p + j->toff[g], j->tlen[g], 0, &j->lines[g]);
+                const int r = kssd_batch_fill_text(j->own_b, first + g, o->abundance ? 2 : 1, j->tx->p + j->toff[g], j->tlen[g], o->kmerqlty, &j->lines[g]);
                 if (r && r != KSSD_HOST_ERR_EMPTY) trc |= 1;
             }
         }
         if (trc) die(EIO, "%s ...: the host tokeniser failed", fl->path[first_file]);
         rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
     }
-    if ((j->tx || j->streamed) && is_fq)
+    if ((j->tx || j->streamed) && is_fq && !o->abundance) /* (mt_shortreads2koc prints no count) */
         for (uint32_t g = 0; g < n; g++) printf("%llu reads detected\n", (unsigned long long)j->lines[g]);
     if (rc == KSSD_ERR_INPUT) /* the host tokeniser's KSSD_HOST_ERR_HEADER (iseq2comem.c:233) */
         die(EIO, "%s: %s", fl->path[first_file + (bad >= 0 ? bad : 0)], kssd_host_strerror(KSSD_HOST_ERR_HEADER));
@@ -630,6 +630,8 @@ static void *worker_main(void *arg)
     kssd_gpu_ctx *ctx = NULL;
     const double tc0 = now_s();
     gck(kssd_gpu_create_compact(&ctx, &pl->hdr, pl->accepted, pl->n_accepted, w->device), "kssd_gpu_create");
+    if (pl->o->abundance) gck(kssd_gpu_set_fastq_reads(ctx, 1), "kssd_gpu_set_fastq_reads");
+    else if (pl->o->kmerqlty > 0 && pl->o->kmerqlty <= 127) gck(kssd_gpu_set_fastq_quality(ctx, pl->o->kmerqlty), "kssd_gpu_set_fastq_quality");
     pthread_mutex_lock(&pl->mu);
     if (now_s() - tc0 > pl->t_ctx) pl->t_ctx = now_s() - tc0;
     pthread_mutex_unlock(&pl->mu);
@@ -816,8 +818,10 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     int *trc = calloc((size_t)threads, sizeof *trc);
     uint64_t *lines = calloc((size_t)threads, sizeof *lines);
     int *direct = calloc((size_t)threads, sizeof *direct); /* plain file for the device tokeniser: read straight into the job's text buffer */
-    /* fastq2co's quality rule (-Q > 0) and the read framing of -A stay with the host tokeniser */
-    const int fq_dev = !o->abundance && o->kmerqlty == 0 && !getenv("KSSD_HOST_FASTQ");
+    /* FASTQ text is tokenised on the device: fastq2co's framing with its quality rule (-Q) or, under -A, the framing of
+     * mt_shortreads2koc (kssd_gpu_set_fastq_quality / _reads in worker_main); inputs only the reference's own fgets()
+     * sequence reproduces come back (KSSD_ERR_UNSUPPORTED) and go through the host tokeniser */
+    const int fq_dev = (o->abundance || (o->kmerqlty >= 0 && o->kmerqlty <= 127)) && !getenv("KSSD_HOST_FASTQ");
     stream_env();
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
         const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;

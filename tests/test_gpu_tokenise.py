@@ -252,3 +252,93 @@ def test_device_tokenisers_fuzz(shuf_l3k10, kind):
         assert np.array_equal(gp, hb.packed()[:len(gp)])
     finally:
         ctx.close()
+
+
+# ---- the quality floor (fastq2co -Q, iseq2comem.c:312) on the device --------------------------------------------------------
+
+def _fastq_with_qualities(rng, n_reads, max_len, crlf=False, lower=False):
+    """well-formed records (quality line as long as the bases) with qualities scattered around every floor the test uses"""
+    out = []
+    nl = b"\r\n" if crlf else b"\n"
+    for i in range(n_reads):
+        ln = int(rng.integers(0, max_len))
+        al = np.frombuffer(b"ACGTacgtN" if lower else b"ACGTN", np.uint8)
+        w = np.array([1.0] * (len(al) - 1) + [0.03])
+        bases = bytes(al[rng.choice(len(al), size=ln, p=w / w.sum())])
+        mode = i % 4
+        if mode == 0:
+            q = rng.integers(33, 75, ln)                      # every quality
+        elif mode == 1:
+            q = np.full(ln, 73)                               # all high
+            q[rng.random(ln) < 0.05] = 35                     # a few low columns
+        elif mode == 2:
+            q = np.where(np.arange(ln) < ln // 2, 70, 40)     # a low tail
+        else:
+            q = rng.integers(1, 127, ln)
+            q[q == 10] = 11                                   # (no newline inside the quality line)
+            q[q == 13] = 14
+        out.append(b"@r%d some text" % i + nl + bases + nl + b"+" + (b"r%d" % i if i % 5 == 0 else b"") + nl + bytes(q.astype(np.uint8)) + nl)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("Q", [1, 40, 53, 74, 127])
+def test_device_fastq_quality_floor_equals_the_host_tokeniser(shuf_l3k10, Q):
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(900 + Q)
+    texts = [_fastq_with_qualities(rng, 300, 400), _fastq_with_qualities(rng, 40, 6000), _fastq_with_qualities(rng, 200, 160, crlf=True),
+             _fastq_with_qualities(rng, 500, 40, lower=True), _fastq_with_qualities(rng, 3, 18000), b"",
+             b"@a\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n",          # a quality line LONGER than the bases is fine
+             _fastq_with_qualities(rng, 50, 300)[:-1]]                                                   # the last record lacks its line end: not scanned
+    hb = K.Batch()
+    first = hb.reserve([len(t) for t in texts])
+    lines = [hb.fill_text(first + i, t, kind=1, Q=Q) if len(t) else 0 for i, t in enumerate(texts)]
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        ctx.set_fastq_quality(Q)
+        buf, offs, lens = ctx._text_layout(texts)
+        co = hb.chunk_off()
+        d_text = torch.from_numpy(buf).to(dev)
+        nchunks = int(co[-1])
+        d_packed = torch.full((nchunks * K.CHUNK_WORDS + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        d_mask = torch.full((nchunks * K.CHUNK_MASKW + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        rc, bad, npos, nlines = ctx.tokenise_fastq_device(d_text, offs, lens, d_packed, d_mask, co)
+        assert rc == 0 and bad == -1, (rc, bad)
+        assert np.array_equal(nlines, np.array(lines, dtype=np.uint64))
+        want_pos = np.array([hb.n_positions(first + i) for i in range(len(texts))], dtype=np.uint64)
+        assert np.array_equal(npos, want_pos), (npos, want_pos)
+        gp = d_packed.cpu().numpy().view(np.uint32)
+        gm = d_mask.cpu().numpy().view(np.uint32)
+        assert np.array_equal(gm, hb.mask()[:len(gm)])
+        assert np.array_equal(gp, hb.packed()[:len(gp)])
+        # and the sketches against the oracle's fastq2co
+        off, ids, lines2 = ctx.sketch_fastq_texts(texts)
+        sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+        for g, t in enumerate(texts):
+            assert np.array_equal(ids[int(off[g]):int(off[g + 1])], np.sort(sk.fastq(t, Q=Q))), (Q, g)
+        # the floor is part of the context: without it the same call gives the -Q 0 sketches
+        ctx.set_fastq_quality(0)
+        off0, ids0, _ = ctx.sketch_fastq_texts(texts[:2])
+        for g in range(2):
+            assert np.array_equal(ids0[int(off0[g]):int(off0[g + 1])], np.sort(sk.fastq(texts[g], Q=0)))
+    finally:
+        ctx.close()
+
+
+def test_a_quality_line_shorter_than_its_bases_goes_back_to_the_host(shuf_l3k10):
+    """the reference compares the columns behind the end of a short quality line with whatever an earlier line left in its
+    buffer: only its own fgets() sequence reproduces that"""
+    good = b"@r\nACGTTGCAACGTTGCAACGTTGCAAACCGGTT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"
+    short = b"@r\nACGTTGCAACGTTGCAACGTTGCAAACCGGTT\n+\nIIIIIIIIIIII\n" + good
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        off, ids, lines = ctx.sketch_fastq_texts([good, short])          # without a floor the quality line is never looked at
+        assert list(lines) == [4, 8]
+        ctx.set_fastq_quality(40)
+        with pytest.raises(K.KssdError) as e:
+            ctx.sketch_fastq_texts([good, short, good])
+        assert e.value.code == K.capi.ERR_UNSUPPORTED and e.value.bad_genome == 1
+        off, ids, lines = ctx.sketch_fastq_texts([good, good])
+        assert list(lines) == [4, 4]
+    finally:
+        ctx.close()
