@@ -251,3 +251,61 @@ def test_long_plain_files_are_streamed_to_the_device(tmp_path):
         a = open(os.path.join(d, "plain", fn), "rb").read()
         b = open(os.path.join(d, "streamed", fn), "rb").read()
         assert a == b and len(a) > 0, fn
+
+
+def test_quality_floor_and_abundance_inputs_through_the_device_tokeniser(tmp_path):
+    """`kssd dist -Q 45` and `kssd dist -A` on plain .fastq files: tokenised on the device (the quality column gathered two
+    lines down; the framing of mt_shortreads2koc), a file with a short quality line or an unterminated last record handed back to
+    the host tokeniser -- combco.0 is the oracle's either way, and KSSD_HOST_FASTQ=1 (host tokeniser for everything) agrees byte for
+    byte"""
+    from test_gpu_tokenise import _fastq_with_qualities
+    d = str(tmp_path)
+    rng = np.random.default_rng(45)
+    genome = rng.integers(0, 4, 80_000, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def reads_file(n, qual_of):
+        out = []
+        for i in range(n):
+            s = int(rng.integers(0, len(genome) - 150))
+            r = bytes(acgt[genome[s:s + 150]])
+            out.append(b"@r%d\n" % i + r + b"\n+\n" + bytes(qual_of(150)) + b"\n")
+        return b"".join(out)
+    files = {"hi.fastq": reads_file(3000, lambda n: np.full(n, 70, np.uint8)),
+             "mixed.fastq": reads_file(3000, lambda n: rng.integers(35, 75, n).astype(np.uint8)),
+             "tail.fastq": reads_file(3000, lambda n: np.where(np.arange(n) < 100, 72, 36).astype(np.uint8)),
+             "wild.fastq": _fastq_with_qualities(rng, 400, 500)}
+    files["short_q.fastq"] = files["hi.fastq"][:400] + b"@s\n" + bytes(acgt[genome[:120]]) + b"\n+\nIIII\n" + files["mixed.fastq"][:50_000]
+    for name, text in files.items():
+        open(os.path.join(d, name), "wb").write(text)
+    shuf = K.Shuf.generate(10, 6, 3, seed=12)
+    shuf.write(os.path.join(d, "s.shuf"))
+    sk = ko.Sketcher(shuf.table, 10, 6, 3)
+    names = sorted(files)
+    for Q in (45, 0):
+        run(["dist", "-Q", Q, "-L", "s.shuf", "-o", "dev%d" % Q] + names, d)
+        run(["dist", "-Q", Q, "-L", "s.shuf", "-o", "host%d" % Q] + names, d, env={"KSSD_HOST_FASTQ": "1"})
+        _, nm_d, off_d, ids_d = ko.read_sketch_dir(os.path.join(d, "dev%d" % Q))
+        _, nm_h, off_h, ids_h = ko.read_sketch_dir(os.path.join(d, "host%d" % Q))
+        assert list(nm_d) == list(nm_h) and np.array_equal(off_d, off_h) and np.array_equal(ids_d, ids_h)
+        for g, name in enumerate(nm_d):
+            assert np.array_equal(ids_d[int(off_d[g]):int(off_d[g + 1])], sk.fastq(files[os.path.basename(name)], Q=Q, M=1)), (Q, name)
+    _, nm45, off45, _ = ko.read_sketch_dir(os.path.join(d, "dev45"))
+    _, nm0, off0, _ = ko.read_sketch_dir(os.path.join(d, "dev0"))
+    assert int(off45[-1]) < int(off0[-1])                           # the floor removes k-mers
+    # -A: occurrences; the unterminated last record of open.fastq is scanned by mt_shortreads2koc (and handed back by the device)
+    afiles = {"a.fastq": files["hi.fastq"][:200_000], "open.fastq": files["mixed.fastq"][:100_000].rstrip(b"\n")}
+    os.mkdir(os.path.join(d, "ab"))
+    for name, text in afiles.items():
+        open(os.path.join(d, "ab", name), "wb").write(text)
+    run(["dist", "-A", "-L", "s.shuf", "-o", "koc_dev", "ab"], d)
+    run(["dist", "-A", "-L", "s.shuf", "-o", "koc_host", "ab"], d, env={"KSSD_HOST_FASTQ": "1"})
+    for fn in ("combco.0", "combco.0.a", "combco.index.0", "cofiles.stat"):
+        assert open(os.path.join(d, "koc_dev", fn), "rb").read() == open(os.path.join(d, "koc_host", fn), "rb").read(), fn
+    got = np.fromfile(os.path.join(d, "koc_dev", "combco.0"), np.uint32)
+    cnt = np.fromfile(os.path.join(d, "koc_dev", "combco.0.a"), np.uint16)
+    idx = np.fromfile(os.path.join(d, "koc_dev", "combco.index.0"), np.uint64)
+    for g, name in enumerate(sorted(afiles)):
+        wi, wc = sk.fastq_koc(afiles[name])
+        lo, hi = int(idx[g]), int(idx[g + 1])
+        assert np.array_equal(got[lo:hi], wi) and np.array_equal(cnt[lo:hi], wc), name

@@ -9,7 +9,7 @@ import pytest
 
 import kssd_oracle as ko
 import public_kssd_amd as K
-from synth import fasta_text
+from synth import fasta_text, fastq_text
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -340,5 +340,63 @@ def test_a_quality_line_shorter_than_its_bases_goes_back_to_the_host(shuf_l3k10)
         assert e.value.code == K.capi.ERR_UNSUPPORTED and e.value.bad_genome == 1
         off, ids, lines = ctx.sketch_fastq_texts([good, good])
         assert list(lines) == [4, 4]
+    finally:
+        ctx.close()
+
+
+# ---- the framing of dist -A (mt_shortreads2koc, iseq2comem.c:552-615) on the device ---------------------------------------
+
+def test_device_reads_framing_equals_the_host_tokeniser_and_the_oracle_counts(shuf_l3k10):
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    genome = rng.integers(0, 4, 150_000, dtype=np.uint8)
+    reads = []
+    for _ in range(6000):
+        s = int(rng.integers(0, len(genome) - 150))
+        r = genome[s:s + int(rng.integers(20, 151))].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(r)
+    texts = [fastq_text(reads), fastq_text(reads[:50], qual=b"#"), _fastq_with_qualities(rng, 200, 3000), b""]
+    hb = K.Batch()
+    first = hb.reserve([len(t) for t in texts])
+    for i, t in enumerate(texts):
+        if len(t):
+            hb.fill_text(first + i, t, kind=2)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        ctx.set_fastq_reads(True)
+        ctx.set_fastq_quality(60)                                   # ignored under the reads framing (dist -A has no quality floor)
+        buf, offs, lens = ctx._text_layout(texts)
+        co = hb.chunk_off()
+        d_text = torch.from_numpy(buf).to(dev)
+        nchunks = int(co[-1])
+        d_packed = torch.full((nchunks * K.CHUNK_WORDS + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        d_mask = torch.full((nchunks * K.CHUNK_MASKW + K.SLACK_WORDS,), -1, dtype=torch.int32, device=dev)
+        rc, bad, npos, nlines = ctx.tokenise_fastq_device(d_text, offs, lens, d_packed, d_mask, co)
+        assert rc == 0 and bad == -1, (rc, bad)
+        assert np.array_equal(npos, np.array([hb.n_positions(first + i) for i in range(len(texts))], dtype=np.uint64))
+        gp = d_packed.cpu().numpy().view(np.uint32)
+        gm = d_mask.cpu().numpy().view(np.uint32)
+        assert np.array_equal(gm, hb.mask()[:len(gm)]) and np.array_equal(gp, hb.packed()[:len(gp)])
+        # ids and occurrences against the oracle's mt_shortreads2koc
+        off, ids, cnt, lines = ctx.sketch_fastq_texts(texts, K.SKETCH_KEEP_ZERO | K.SKETCH_COUNTS, with_pos=True)
+        sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+        for g, t in enumerate(texts):
+            if not len(t):
+                assert off[g] == off[g + 1]
+                continue
+            wi, wc = sk.fastq_koc(t)
+            o = np.argsort(wi)
+            lo, hi = int(off[g]), int(off[g + 1])
+            assert np.array_equal(ids[lo:hi], wi[o]) and np.array_equal(cnt[lo:hi], wc[o].astype(np.uint32)), g
+        # what fastq2co and mt_shortreads2koc scan differently goes back to the host: an unterminated last line (dist -A
+        # scans that record, fastq2co drops it), a partial record, a line longer than the 4 096-byte buffer
+        good = fastq_text(reads[:3])
+        for t in (good[:-1], good + b"@x\nACGT\n", good + b"@x\n" + b"ACGT" * 1100 + b"\n+\n" + b"I" * 4400 + b"\n"):
+            with pytest.raises(K.KssdError) as e:
+                ctx.sketch_fastq_texts([good, t])
+            assert e.value.code == K.capi.ERR_UNSUPPORTED and e.value.bad_genome == 1
     finally:
         ctx.close()
