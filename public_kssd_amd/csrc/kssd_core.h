@@ -159,48 +159,6 @@ KSSD_HD void kssd_grp_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[K
     }
 }
 
-// Alignment B for the positions alignment A left standing only (device).  plo / phi = A's merged answer of the same chunk
-// (validity applied): a group of B in which none of its W positions passed A cannot change the outcome, so its lane does
-// not need the table's answer.  The lane still takes part in the wave's read -- there is no branch, no exec mask -- but
-// with address 0: all such lanes (68 % at L3K10) ask for the same byte, which the LDS serves as ONE broadcast, and the
-// bank conflicts are those of the remaining third of the lanes (~2 LDS cycles per 32 lanes instead of ~3.4).  What they read
-// is never looked at: their positions are zero in A's mask, and the candidate mask is the AND of both.
-// Cost: a 5-wide smear of A's mask (10 instructions per chunk) and two per group (sign-extended bit -> AND with the index).
-// (Round 2 measured the same idea with a branch per group: a third less LDS time, a quarter more instructions, 27 % slower.)
-#if defined(__HIPCC__)
-template <int SUBK, int GW, typename T1PTR>
-__device__ __forceinline__ void kssd_grp_issue_b_where_a(const uint32_t (&Wd)[5], T1PTR T1, uint32_t plo, uint32_t phi,
-                                                         uint32_t (&raw)[KssdGrp<SUBK, GW>::NMAX])
-{
-    typedef KssdGrp<SUBK, GW> Gp;
-    uint32_t V[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) V[i] = __builtin_amdgcn_alignbit(Wd[i], Wd[i + 1], 16);
-    // bit p of (shi:slo): some position of p .. p + W - 1 passed A  (m | m >> 1, then | that >> 2, then | m >> 4 ...)
-    static_assert(Gp::W == 3 || Gp::W == 5, "the smear below is written for groups of three or five windows");
-    const uint32_t tlo = plo | __builtin_amdgcn_alignbit(phi, plo, 1), thi = phi | (phi >> 1);  // 2 wide
-    uint32_t slo, shi;
-    if (Gp::W == 3) {
-        slo = tlo | __builtin_amdgcn_alignbit(phi, plo, 2);
-        shi = thi | (phi >> 2);
-    } else {
-        const uint32_t ulo = tlo | __builtin_amdgcn_alignbit(thi, tlo, 2), uhi = thi | (thi >> 2);  // 4 wide
-        slo = ulo | __builtin_amdgcn_alignbit(phi, plo, 4);
-        shi = uhi | (phi >> 4);
-    }
-#pragma unroll
-    for (int q = 0; q < Gp::NMAX; q++) {
-        if (q < Gp::NB) {
-            const int Q = Gp::QB0 + Gp::W * q, Q0 = Q < 0 ? 0 : Q;  // (a group that starts below the lane's positions: bit 0 covers it, and a little more)
-            const uint32_t need = (uint32_t)__builtin_amdgcn_sbfe((int)(Q0 < 32 ? slo : shi), Q0 & 31, 1);  // all ones / zero
-            raw[q] = T1[kssd_grp_field<Gp::IDXB>(Wd, V, 2 * (Q + Gp::W - 1)) & need];
-        } else {
-            raw[q] = 0;
-        }
-    }
-}
-#endif
-
 // merge the answers of one alignment into the 64-position masks (bit p <=> lane position p may be sampled)
 #if defined(__HIP_DEVICE_COMPILE__)
 // One v_alignbit_b32 per answer and mask word: the groups of a word are taken in ascending order and each one is pushed in

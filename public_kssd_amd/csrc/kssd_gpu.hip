@@ -57,7 +57,6 @@ extern "C" const char *kssd_gpu_strerror(int code)
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define SCAN_QUEUE_STRIDE 32  // u32 words between the block-queue heads of two scan workgroups (one 128-byte line each)
 #define CBUF 128          // per-wave buffer of stage-1 candidates waiting for the Bloom test (8 B each)
 #define SKETCH_TRACK_FILL 0x80000000u  // internal flag: record the fullest staging region even without an overflow
 #define DEDUP_THREADS 512
@@ -103,8 +102,6 @@ struct kssd_gpu_ctx {
     size_t cap_cand_count;
     unsigned long long *d_blk_info;  // per block of the last scan: where its candidates are (scan_blk_pack)
     size_t cap_blk_info;
-    uint32_t *d_scan_queue;          // per scan workgroup: head of its block queue
-    size_t cap_scan_queue;
     uint64_t last_cand_cap;
     uint64_t cand_floor;    // per-slice capacity an overflowed attempt asked for (kept for the retries)
     double cand_factor;
@@ -211,7 +208,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
     c->cu_count = prop.multiProcessorCount;
     c->P = P;
     c->region_factor = 2.0;
-    c->cand_factor = 2.0;  // waves work off different numbers of blocks: room for the busiest
+    c->cand_factor = 1.5;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     int rc = ctx_upload_tables(c, accepted);
     if (rc != KSSD_OK) { delete c; return rc; }
@@ -279,7 +276,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_scan_queue, c->d_big_alt, c->d_big_tmp,
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
                     c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -377,11 +374,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 // (it also zeroes the small per-call state: four separate memsets cost more than this whole kernel)
 __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes, uint64_t n_chunks,
                                  uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                 uint32_t n_slices, uint32_t *__restrict__ status_words, uint32_t *__restrict__ scan_queue)
+                                 uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < sizeof(SketchStatus) / 4) status_words[c] = 0;
-    if (c < n_slices / SCAN_WAVES) scan_queue[c * SCAN_QUEUE_STRIDE] = SCAN_WAVES;  // every workgroup's waves start with a block of their own
     if (c < n_genomes) cursor[c] = 0;
     if (c < n_slices) cand_count[c] = 0;
     if (c >= n_chunks) return;
@@ -398,12 +394,11 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
 // when genomes span many chunks.  The per-call state is zeroed by the first workgroups like above.
 __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes,
                                            uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                           uint32_t n_slices, uint32_t *__restrict__ status_words, uint32_t *__restrict__ scan_queue)
+                                           uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     // grid = (genomes or more, parts): workgroup (g, y) writes every gridDim.y-th run of 256 chunks of genome g
     const uint64_t t = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
     if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
-    for (uint64_t i = t; i < n_slices / SCAN_WAVES; i += nt) scan_queue[i * SCAN_QUEUE_STRIDE] = SCAN_WAVES;
     for (uint64_t i = t; i < n_genomes; i += nt) cursor[i] = 0;
     for (uint64_t i = t; i < n_slices; i += nt) cand_count[i] = 0;
     if (blockIdx.x >= n_genomes) return;
@@ -432,24 +427,23 @@ struct ScanArgs {
     unsigned long long cand_cap;    // per wave
     uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
     unsigned long long *blk_info;   // per block of SCAN_BLOCK chunks: where its candidates sit in the list (scan_blk_pack)
-    uint32_t *queue;                // per workgroup (SCAN_QUEUE_STRIDE words apart): the next block of its run nobody has taken
-    uint32_t dynamic;               // 1: blocks from the queue (the product); 0: a static round-robin (development A/B)
     SketchStatus *status;
 #ifdef KSSD_DEV
     unsigned long long *dev_times;  // development build: per wave {first instruction, tables in LDS, last chunk done} (s_memtime)
 #endif
 };
 
-// The scan's unit of work distribution: a block of SCAN_BLOCK consecutive chunks.  A workgroup owns one contiguous run of the
-// batch's blocks; its 16 waves take them from the workgroup's queue (the first one by their index, the following ones with
-// an atomic on the queue's head), so a wave that runs ahead simply works off more blocks and the workgroup ends when its run
-// is through instead of when its slowest wave has worked off a fixed share.  Measured on a static partition (equal shares
-// per wave): in EVERY workgroup the fastest wave finished its share at 70 % of the time the slowest one took -- the waves
-// of a CU do not get equal shares of its LDS and issue slots -- while the workgroups' means were equal to within 2 %: the
-// imbalance is inside the CU, and that is where it is levelled (a queue head per workgroup: 16 pullers on a line of its own;
-// ONE head for the whole grid was tried and saturates -- 305 000 atomics on one address take 3.6 ms).
-// A wave lists the survivors of a block contiguously in its own slice of the candidate list and leaves, per block, where:
+// The scan's unit of work: a block of SCAN_BLOCK consecutive chunks.  A workgroup owns one contiguous run of the batch's
+// blocks, its 16 waves take them in turn (wave w: blocks w, w + 16, ... of the run).  A wave lists the survivors of a block
+// contiguously in its own slice of the candidate list and leaves, per block, where (the per-genome kernel that evaluates
+// them reads exactly the blocks its genome's chunks lie in):
 //   bits 0-23 the number of records, bits 24-63 the index of the first one in the whole list
+// The buffer of stage-1 candidates is emptied at the end of every block, so an entry names its chunk relative to the block.
+// Measured and not kept (profiles/r03d_*, r03e_*): the same blocks handed out by a queue.  With equal shares the fastest wave of
+// EVERY workgroup is through at 70 % of the time its slowest one takes -- the waves of a CU do not get equal shares of its
+// LDS and issue slots -- while the workgroups' means agree to 2 %.  But a CU's throughput does not depend on which of its
+// waves get it: with a queue head per workgroup all waves finish together and the launch takes as long as before (0.621
+// against 0.598 ms); one head for the whole grid saturates (305 000 atomics on one address: 3.6 ms).
 #define SCAN_BLOCK 4
 __host__ __device__ __forceinline__ unsigned long long scan_blk_pack(unsigned long long first, uint32_t n) { return (first << 24) | n; }
 __host__ __device__ __forceinline__ uint32_t scan_blk_count(unsigned long long v) { return (uint32_t)(v & 0xFFFFFFull); }
@@ -531,7 +525,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates, see bloom_round
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
-    // work distribution: the workgroup's run of blocks, its waves take them from a queue (see SCAN_BLOCK)
+    // work distribution: the workgroup's run of blocks, its waves take them in turn (see SCAN_BLOCK)
     const uint32_t wid = blockIdx.x * SCAN_WAVES + wave;
     const unsigned long long clast = a.n_chunks - 1;  // reads past the end of the batch are clamped, their results unused
     const uint32_t n_blocks_all = (uint32_t)((a.n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK);
@@ -542,14 +536,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
 #ifdef KSSD_DEV
     const unsigned long long dev_t0 = __builtin_readcyclecounter();
 #endif
-    // the next block nobody has taken yet.  The atomic's answer is not needed before the wave is three chunks into the
-    // block it is working on: vector memory operations return in order, so by then the chunk loads issued behind it are in too
-    auto take = [&](uint32_t prev) -> uint32_t {
-        if (!a.dynamic) return prev >= n_blocks ? prev : prev + SCAN_WAVES;  // (development: a static round-robin of the blocks)
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&a.queue[blockIdx.x * SCAN_QUEUE_STRIDE], 1u);
-        return __builtin_amdgcn_readfirstlane(v);
-    };
+    auto take = [&](uint32_t prev) -> uint32_t { return prev >= n_blocks ? prev : prev + SCAN_WAVES; };  // the wave's next block of the run
     auto chunk_at = [&](unsigned long long c) -> unsigned long long { return c < clast ? c : clast; };
     uint32_t b_cur = wave, b_nxt = take(b_cur);  // indices into the workgroup's run
 
@@ -582,11 +569,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // prologue: the block's first chunk through both alignments
     kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
     kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
-#if defined(KSSD_SCAN_NOPRED)
     kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of the first chunk in flight
-#else
-    kssd_grp_issue_b_where_a<SUBK, KSSD_GW>(r0.W, T1, alo & r0.M[0], ahi & r0.M[1], raw);  // alignment B of the first chunk in flight
-#endif
 
     // one chunk.  The four register sets rotate by name (a block is four steps, written out): copying one
     // set into another would make every iteration wait for the reads it has just issued.
@@ -674,11 +657,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     if (!last) break;
                 }
             }
-#if defined(KSSD_SCAN_NOPRED)
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
-#else
-            kssd_grp_issue_b_where_a<SUBK, KSSD_GW>(nxt.W, T1, alo & nxt.M[0], ahi & nxt.M[1], raw);
-#endif
         }
     };
     static_assert(SCAN_BLOCK == 4, "a block is the four written-out steps below");
@@ -1595,7 +1574,6 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
     if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices * 2)) != KSSD_OK) return rc;  // 16-byte records
     if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
-    if ((rc = ensure(&c->d_scan_queue, &c->cap_scan_queue, (size_t)(grid > 0 ? grid : 1) * SCAN_QUEUE_STRIDE)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_blk_info, &c->cap_blk_info, (size_t)((n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK) + 1)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
     pl.big_min = big_min; pl.max_cap = max_cap; pl.max_big = max_big; pl.cand_cap = cand_cap; pl.n_slices = n_slices; pl.grid = grid;
@@ -1631,13 +1609,13 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
         if (parts > 1024) parts = 1024;
         hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64, (unsigned)(parts ? parts : 1)), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
-                           reinterpret_cast<uint32_t *>(c->d_status), c->d_scan_queue);
+                           reinterpret_cast<uint32_t *>(c->d_status));
         HIPCK(hipGetLastError());
         return KSSD_OK;
     }
     hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
                        (const uint64_t *)c->d_chunk_off, pl.n_genomes, pl.n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
-                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status), c->d_scan_queue);
+                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status));
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -1663,11 +1641,6 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.blk_info = c->d_blk_info;
-    a.queue = c->d_scan_queue;
-    a.dynamic = 0;
-#ifdef KSSD_DEV
-    if (getenv("KSSD_DEV_QUEUE")) a.dynamic = 1;
-#endif
     a.status = c->d_status;
 #ifdef KSSD_DEV
     {
