@@ -133,7 +133,7 @@ def _run_ours(args, cwd, env_extra=None, timeout=900):
     return dt, timing
 
 
-def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
+def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128):
     """The CPU comparators and the end-to-end leg, on the same inputs in the same run:
       port       oracle/kssd_oracle.c (our restatement) sketching the sample texts, OpenMP over genomes
       reference  oracle/_ref/kssd (the real reference, when the snapshot carries it): stage I on FASTA files in tmpfs,
@@ -176,6 +176,21 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
             for r in range(1, reps):   # the same genomes again under other names: whole-pipeline work, bounded setup time
                 os.symlink("r00_g%04d.fasta" % i, os.path.join(d, "fa", "r%02d_g%04d.fasta" % (r, i)))
                 nf += 1
+        # the same genomes gzip'ed (level 1: the setup stays in seconds), under as many names: zlib on our host threads against the
+        # reference's `zcat -fc` pipes
+        import zlib
+        os.mkdir(os.path.join(d, "gz"))
+        n_gz = min(n, gz_distinct)
+        gz_reps = max(1, min(reps, 8))
+        ngz = 0
+        for i in range(n_gz):
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(os.path.join(d, "gz", "r00_g%04d.fasta.gz" % i), "wb") as f:
+                f.write(co.compress(texts[i]) + co.flush())
+            ngz += 1
+            for r in range(1, gz_reps):
+                os.symlink("r00_g%04d.fasta.gz" % i, os.path.join(d, "gz", "r%02d_g%04d.fasta.gz" % (r, i)))
+                ngz += 1
         del texts
         shuf.write(os.path.join(d, "L3K10.shuf"))
         fa_desc = "%d FASTA files in tmpfs (%d distinct bench genomes of %.1f Mb x %d names, %.0f Mbase)" % (nf, n, nb / n / 1e6, reps, nb * reps / 1e6)
@@ -206,6 +221,14 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
                                      "sketches, the device search and the distance.out text (%d MB) on %d host threads -- the same command "
                                      "line the reference is timed with below; wall time of the command, the better of two runs"
                                      % (nf, nf, os.path.getsize(os.path.join(d, "our_dist", "distance.out")) >> 20, cores)}
+            if ngz:
+                dtg0, _ = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_gz0", "gz"], d)
+                dtg, tmg = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_gz", "gz"], d, {"KSSD_TIMING": "1"})
+                og = ko.sketch_sets_by_name(os.path.join(d, "our_gz"))
+                for i in range(n_gz):
+                    assert np.array_equal(og["r00_g%04d.fasta.gz" % i], gpu_sets[i]), "kssd CLI sketch of the gzip'ed genome != device-level sketch"
+                e2e["gzip"] = {"value": ngz / min(dtg, dtg0), "unit": "genomes/s", "seconds_runs": [dtg0, dtg], "stages": tmg,
+                               "sample": "%d .fasta.gz files in tmpfs (%d distinct genomes x %d names, gzip level 1)" % (ngz, n_gz, gz_reps)}
             out["end_to_end"] = e2e
         # ---- the real reference binary when the snapshot carries it ----
         if ko.have_ref() and shutil.which("zcat"):
@@ -233,6 +256,12 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files):
             t0 = time.time()
             ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", "ref_sk"], cwd=d, timeout=1800)
             t_srch = min(time.time() - t0, t_srch0)      # the better of two runs, like ours (the second one keeps sharedk_ct.dat for the parity check)
+            if ngz:
+                t0 = time.time()
+                ko.run_ref(["dist", "-p", max(1, min(cores, ngz - 1)), "-L", "L3K10.shuf", "-o", "ref_gz", "gz"], cwd=d, timeout=1800)
+                t_gz = time.time() - t0
+                out["reference_gz"] = {"value": ngz / t_gz, "unit": "genomes/s", "cores": max(1, min(cores, ngz - 1)), "kind": "reference", "seconds": t_gz,
+                                       "sample": "the same %d .fasta.gz files, `oracle/_ref/kssd dist` (zcat -fc pipes)" % ngz}
             out["dist_reference"] = {"value": nf * nf / t_srch, "unit": "pairs/s", "cores": p_srch, "kind": "reference",
                                      "sample": "%d x %d all-pairs of the reference's own sketches of those files: `kssd dist -r <mco> "
                                                "--keepskf <co>` wall time incl. distance.out text; its stage II (2 GiB mco.index, "
@@ -1168,6 +1197,8 @@ def main():
             res["cpu_baseline_dist_port"] = cb["dist_port"]
             if "end_to_end" in cb:
                 res["end_to_end"] = cb["end_to_end"]
+            if "reference_gz" in cb:
+                res["cpu_baseline_gz"] = cb["reference_gz"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and G == 1000 and L == 5_000_000:  # the PMC passes were collected on the default workload
             try:

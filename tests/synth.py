@@ -4,6 +4,26 @@ import numpy as np
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
+def host_cores():
+    """threads worth starting: the processors this process may run on, but not more than the CPU time its cgroup grants
+    (the measurement box shows 256 processors under a quota of 16: a pool of 256 oracle threads there is slow, not wrong)"""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def fasta_text(codes, name=b"seq", width=70, n_mask=None):
     """codes: uint8 array of 0..3; n_mask: optional bool array, True -> 'N'"""
     s = ACGT[codes]

@@ -22,11 +22,11 @@ import pytest
 
 import kssd_oracle as ko
 import public_kssd_amd as K
-from synth import fasta_text, fastq_records, sample_reads
+from synth import fasta_text, fastq_records, host_cores, sample_reads
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CORES = os.cpu_count() or 1
+CORES = host_cores()
 
 
 def _sketch_retry(ctx, packed, mask, chunk_off, off, ids, cap, flags=K.SKETCH_FASTA, min_occ=1):
