@@ -348,6 +348,19 @@ int kssd_gpu_dist_multi(const int *devices, int n_devices, int kmerlen, const ui
  */
 int kssd_gpu_concat_units_device(kssd_gpu_ctx *ctx, const uint64_t *d_off_all, const uint32_t *d_ids_all, uint32_t world,
                                  uint32_t n_per_unit, uint64_t cap, uint64_t *d_roff, uint32_t *d_rids, void *stream);
+/*
+ * The exchange itself inside ONE process that drives n devices (no counterpart in the reference: its threads share one
+ * address space; here the reference sketches are produced on different devices and every device's rows need all of
+ * them): an all-gather over RCCL -- xGMI between the GPUs of a node -- of every device's unit, then the unpacking above
+ * on every device.  ctxs[i] lives on its own device (one rank per device); d_off_l[i] = u64[n_per_rank + 1] and
+ * d_ids_l[i] = u32[unit_ids] are device i's unit, d_roff[i] (u64[n * n_per_rank + 1]) and d_rids[i] (u32[n * unit_ids])
+ * receive the CSR of all n * n_per_rank sketches on device i; streams[i] (NULL: the null stream) orders the work of
+ * device i.  Nothing is synchronised.  librccl.so is loaded by the first call (dlopen), the communicators are kept and
+ * remade when the device list changes.  KSSD_ERR_HIP with the RCCL error text in kssd_gpu_last_hip_error().
+ */
+int kssd_gpu_allgather_sketches(kssd_gpu_ctx *const *ctxs, int n, const uint64_t *const *d_off_l, const uint32_t *const *d_ids_l,
+                                uint32_t n_per_rank, uint64_t unit_ids, uint64_t *const *d_roff, uint32_t *const *d_rids,
+                                void *const *streams);
 /* how many gfx950 devices this process sees (0 without any; never an error) */
 int kssd_gpu_device_count(void);
 

@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches",
 ]
 
 
@@ -789,6 +789,16 @@ class GpuCtx:
         """the all-gathered sketch units of `world` ranks -> one CSR (device tensors; nothing is synchronised)"""
         _gck(gpu_lib().kssd_gpu_concat_units_device(self.h, _ptr(d_off_all), _ptr(d_ids_all), world, n_per_unit, cap,
                                                     _ptr(d_roff), _ptr(d_rids), stream))
+
+    @staticmethod
+    def allgather_sketches(ctxs, d_off_l, d_ids_l, n_per_rank, unit_ids, d_roff, d_rids, streams=None):
+        """the exchange inside one process: ctxs[i] / tensors[i] on device i (kssd_gpu_allgather_sketches, RCCL)"""
+        n = len(ctxs)
+        vp = C.c_void_p
+        arr = lambda xs: (vp * n)(*[vp(_ptr(x)) for x in xs])
+        hs = (vp * n)(*[c.h.value if isinstance(c.h, vp) else c.h for c in ctxs])
+        st = (vp * n)(*[vp(s) for s in streams]) if streams is not None else None
+        _gck(gpu_lib().kssd_gpu_allgather_sketches(hs, n, arr(d_off_l), arr(d_ids_l), n_per_rank, unit_ids, arr(d_roff), arr(d_rids), st))
 
     def index_set_filter(self, enable, skip_row_begin=0, skip_row_end=0):
         """negative filter in front of the index for searches whose rows mostly miss; rows [begin, end) bypass it"""

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -149,6 +150,9 @@ struct kssd_gpu_ctx {
     size_t cap_tok_tab, cap_tok_pos, cap_tok_sum, cap_tok_state, cap_text, cap_tok_sup;
     uint32_t tok_files;
     bool tok_fastq = false;
+    unsigned long long *d_x_off = nullptr;  // kssd_gpu_allgather_sketches: the gathered units of every rank
+    uint32_t *d_x_ids = nullptr;
+    size_t cap_x_off = 0, cap_x_ids = 0;
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
     bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
     int *d_tok_q = nullptr;  // per tile: newlines around it (quality floor)
@@ -277,7 +281,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : c->text_ev)
@@ -2048,3 +2052,4 @@ extern "C" int kssd_gpu_text_wait(kssd_gpu_ctx *c, int64_t ticket)
 // set operations on sketches (kssd set) live in kssd_set.inc
 // ---------------------------------------------------------------------------------------------------
 #include "kssd_set.inc"
+#include "kssd_xchg.inc"

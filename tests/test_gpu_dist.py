@@ -323,3 +323,32 @@ def test_negative_filter_in_front_of_the_index_changes_nothing(shuf_l3k10):
         assert np.array_equal(got, ko.shared_counts(roff2, r2, qoff2, q2))
     finally:
         ctx.close()
+
+
+def test_in_process_exchange_over_rccl_with_one_rank(shuf_l3k10):
+    """kssd_gpu_allgather_sketches (csrc/kssd_xchg.inc): the C product's exchange.  The box has one GPU, so the communicator has
+    one rank: librccl is opened, a communicator made, both all-gathers and the unpacking run -- the gathered CSR is the
+    rank's own, padding never surfaces, and a second call re-uses the communicator.  (N > 1 ranks: the N-GPU bench.)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    G, unit = 37, 5000
+    sizes = rng.integers(0, 120, G)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ids = np.full(unit, -7, dtype=np.int32)
+    ids[:off[-1]] = rng.integers(0, 1 << 28, int(off[-1]))
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        d_off, d_ids = torch.from_numpy(off).to(dev), torch.from_numpy(ids).to(dev)
+        roff = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        rids = torch.full((unit,), -1, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            K.GpuCtx.allgather_sketches([ctx], [d_off], [d_ids], G, unit, [roff], [rids])
+            torch.cuda.synchronize()
+            assert np.array_equal(roff.cpu().numpy(), off)
+            assert np.array_equal(rids.cpu().numpy()[:off[-1]], ids[:off[-1]])
+        # two ranks on one device: refused before RCCL is asked
+        with pytest.raises(K.KssdError):
+            K.GpuCtx.allgather_sketches([ctx, ctx], [d_off, d_off], [d_ids, d_ids], G, unit, [roff, roff], [rids, rids])
+    finally:
+        ctx.close()
