@@ -133,7 +133,7 @@ def _run_ours(args, cwd, env_extra=None, timeout=900):
     return dt, timing
 
 
-def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128):
+def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_search=1024):
     """The CPU comparators and the end-to-end leg, on the same inputs in the same run:
       port       oracle/kssd_oracle.c (our restatement) sketching the sample texts, OpenMP over genomes
       reference  oracle/_ref/kssd (the real reference, when the snapshot carries it): stage I on FASTA files in tmpfs,
@@ -176,6 +176,13 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128):
             for r in range(1, reps):   # the same genomes again under other names: whole-pipeline work, bounded setup time
                 os.symlink("r00_g%04d.fasta" % i, os.path.join(d, "fa", "r%02d_g%04d.fasta" % (r, i)))
                 nf += 1
+        # the search legs run on the first ns names (an all-pairs report is 114 bytes a pair: 10 000 x 10 000 would be 11 GB of text)
+        ns = min(nf, max(2, e2e_search))
+        sub = nf != ns
+        if sub:
+            os.mkdir(os.path.join(d, "fa_s"))
+            for nm in sorted(os.listdir(os.path.join(d, "fa")))[:ns]:
+                os.symlink(os.path.join("..", "fa", nm), os.path.join(d, "fa_s", nm))
         # the same genomes gzip'ed (level 1: the setup stays in seconds), under as many names: zlib on our host threads against the
         # reference's `zcat -fc` pipes
         import zlib
@@ -211,16 +218,20 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128):
                            "buffers on the host threads, raw text H2D, tokenised on the device, sketch kernels, D2H, slot order, "
                            "combco.* written -- wall time of the command, the better of two runs (HIP start-up varies by ~0.1 s from "
                            "process to process)", "sample": fa_desc, "stages": tm, "seconds_runs": runs}
-            dt2a, tm2a = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist0", "our_sk"], d, {"KSSD_TIMING": "1"})
-            dt2, tm2 = _run_ours(["dist", "-p", cores, "-r", "our_sk", "-o", "our_dist", "our_sk"], d, {"KSSD_TIMING": "1"})
+            sk_s = "our_sk"
+            if sub:
+                _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_sk_s", "fa_s"], d)
+                sk_s = "our_sk_s"
+            dt2a, tm2a = _run_ours(["dist", "-p", cores, "-r", sk_s, "-o", "our_dist0", sk_s], d, {"KSSD_TIMING": "1"})
+            dt2, tm2 = _run_ours(["dist", "-p", cores, "-r", sk_s, "-o", "our_dist", sk_s], d, {"KSSD_TIMING": "1"})
             runs2 = [dt2a, dt2]
             if dt2a < dt2:
                 dt2, tm2 = dt2a, tm2a
-            e2e["search"] = {"value": nf * nf / dt2, "unit": "pairs/s", "seconds": dt2, "seconds_runs": runs2, "stages": tm2,
+            e2e["search"] = {"value": ns * ns / dt2, "unit": "pairs/s", "seconds": dt2, "seconds_runs": runs2, "stages": tm2,
                              "what": "`kssd dist -r <sketches> -o <dir> <sketches>`: %d x %d all-pairs incl. process start, reading the "
                                      "sketches, the device search and the distance.out text (%d MB) on %d host threads -- the same command "
                                      "line the reference is timed with below; wall time of the command, the better of two runs"
-                                     % (nf, nf, os.path.getsize(os.path.join(d, "our_dist", "distance.out")) >> 20, cores)}
+                                     % (ns, ns, os.path.getsize(os.path.join(d, "our_dist", "distance.out")) >> 20, cores)}
             if ngz:
                 dtg0, _ = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_gz0", "gz"], d)
                 dtg, tmg = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_gz", "gz"], d, {"KSSD_TIMING": "1"})
@@ -248,13 +259,18 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128):
             # command_dist.c:1238; measured on a 256-thread box: 118 s at -p 256): they run with at most 16
             p_srch = max(1, min(p_ref, 16))
             t0 = time.time()
-            ko.run_ref(["dist", "-p", p_srch, "-o", "ref_idx", "ref_sk"], cwd=d, timeout=1800)
+            rs = "ref_sk"
+            if sub:
+                ko.run_ref(["dist", "-p", max(1, min(cores, ns - 1)), "-L", "L3K10.shuf", "-o", "ref_sk_s", "fa_s"], cwd=d, timeout=1800)
+                rs = "ref_sk_s"
+                t0 = time.time()
+            ko.run_ref(["dist", "-p", p_srch, "-o", "ref_idx", rs], cwd=d, timeout=1800)
             t_idx = time.time() - t0
             t0 = time.time()
-            ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist0", "ref_sk"], cwd=d, timeout=1800)
+            ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist0", rs], cwd=d, timeout=1800)
             t_srch0 = time.time() - t0
             t0 = time.time()
-            ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", "ref_sk"], cwd=d, timeout=1800)
+            ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx", "-o", "ref_dist", "--keepskf", rs], cwd=d, timeout=1800)
             t_srch = min(time.time() - t0, t_srch0)      # the better of two runs, like ours (the second one keeps sharedk_ct.dat for the parity check)
             if ngz:
                 t0 = time.time()
@@ -262,15 +278,15 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128):
                 t_gz = time.time() - t0
                 out["reference_gz"] = {"value": ngz / t_gz, "unit": "genomes/s", "cores": max(1, min(cores, ngz - 1)), "kind": "reference", "seconds": t_gz,
                                        "sample": "the same %d .fasta.gz files, `oracle/_ref/kssd dist` (zcat -fc pipes)" % ngz}
-            out["dist_reference"] = {"value": nf * nf / t_srch, "unit": "pairs/s", "cores": p_srch, "kind": "reference",
+            out["dist_reference"] = {"value": ns * ns / t_srch, "unit": "pairs/s", "cores": p_srch, "kind": "reference",
                                      "sample": "%d x %d all-pairs of the reference's own sketches of those files: `kssd dist -r <mco> "
                                                "--keepskf <co>` wall time incl. distance.out text; its stage II (2 GiB mco.index, "
-                                               "co2mco.c:57-62) took %.1f s on top and is not in the figure" % (nf, nf, t_idx),
+                                               "co2mco.c:57-62) took %.1f s on top and is not in the figure" % (ns, ns, t_idx),
                                      "stage2_seconds": t_idx, "seconds": t_srch}
             if "end_to_end" in out:
                 # parity of the whole product path at this size: our command line, fed the REFERENCE's sketch directory, must
                 # leave the reference's sharedk_ct.dat and distance.out byte for byte
-                _run_ours(["dist", "-p", cores, "-r", "ref_sk", "-o", "our_dist_on_ref", "--keepskf", "ref_sk"], d)
+                _run_ours(["dist", "-p", cores, "-r", rs, "-o", "our_dist_on_ref", "--keepskf", rs], d)
                 for fn in ("sharedk_ct.dat", "distance.out"):
                     a = open(os.path.join(d, "our_dist_on_ref", fn), "rb").read()
                     b = open(os.path.join(d, "ref_dist", fn), "rb").read()
@@ -834,6 +850,7 @@ def main():
                          "transpose = own sketches indexed, all gathered sketches as query rows (all-pairs only, the index build stays "
                          "constant per rank); both (default) = query as the headline value, transpose measured beside it")
     ap.add_argument("--e2e-files", type=int, default=1024, help="files of the end-to-end / reference leg (the CPU sample under several names)")
+    ap.add_argument("--e2e-search", type=int, default=1024, help="sketches of the end-to-end search leg (all-pairs among the first N files)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="fastq workload: reads of 150 bp")
     ap.add_argument("--parity-reads", type=int, default=10_000_000, help="fastq workload: reads of the oracle slice (0 = skip)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
@@ -1190,7 +1207,7 @@ def main():
             ol, il = m["off"], m["ids"]
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
             cores = host_cores()
-            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files)
+            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files, e2e_search=a.e2e_search)
             res["cpu_baseline"] = cb.get("reference", cb["port"])
             res["cpu_baseline_port"] = cb["port"]
             res["cpu_baseline_dist"] = cb.get("dist_reference", cb["dist_port"])
