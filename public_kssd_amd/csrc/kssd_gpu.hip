@@ -114,6 +114,12 @@ struct kssd_gpu_ctx {
     uint32_t scan_grid_limit; // kssd_gpu_set_scan_grid (0 = one workgroup per CU)
     std::vector<uint64_t> h_reg_off;
     std::vector<uint32_t> h_big;  // genomes of the last batch that take the global-memory dedup path
+    std::vector<uint2> h_med, dev_med;  // ... that are sorted in LDS in parts (genome, log2 parts): planned / what d_med holds
+    uint2 *d_med = nullptr;
+    void *d_med_out = nullptr;
+    uint32_t *d_med_cnt = nullptr;
+    size_t cap_med = 0, cap_med_out = 0, cap_med_cnt = 0;
+    uint32_t med_part_cap = 0;
     // the planned call (kssd_gpu_sketch_plan), executed phase by phase (kssd_gpu_sketch_phase)
     struct {
         bool valid;
@@ -281,7 +287,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : c->text_ev)
@@ -1018,23 +1024,98 @@ struct FuseArgs {
 };
 #define FUSE_PER 4  // candidates a thread evaluates at a time (six spill at 64 VGPRs)
 
-template <typename K, bool FUSED>
+// PARTS: a genome whose staged tuples do not fit one workgroup's LDS sort, but whose ids split by their top bits into 2, 4,
+// 8 or 16 ranges that do (a 3 Gb record at -s 7 -l 5 stages ~45 000 tuples; chromosomes).  Workgroup (m, p) of the launch
+// takes the tuples of medium genome m whose id lies in range p out of the genome's staging region into LDS, sorts them and
+// applies the keep rules like any small genome; the ranges are disjoint and ordered, so their results, one behind the other,
+// are the genome's sorted sketch (dedup_parts_finish_kernel puts them back into the region and adds up the counts).
+// Two launches for all such genomes of a batch, where the global-memory path takes seven per genome.
+#define DEDUP_MAX_PARTS_LOG2 4
+struct PartArgs {
+    const uint2 *list;   // per medium genome: genome index, log2 of its number of parts
+    void *out;           // [n_medium][1 << DEDUP_MAX_PARTS_LOG2][part_cap] kept keys per part
+    uint32_t *cnt;       // [n_medium][1 << DEDUP_MAX_PARTS_LOG2][4]: kept, distinct, occurrences of id 0, overflowed
+    uint32_t part_cap;   // keys one part may hold (the LDS array)
+    uint32_t id_bits;    // ids are below 2^id_bits (a little above it where the rank is ADDED over the outer bases: clamped)
+};
+enum { DEDUP_STAGED = 0, DEDUP_FUSED = 1, DEDUP_PARTS = 2 };
+
+template <typename K, int MODE>
 __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
                                                                       const uint32_t *__restrict__ cursor,
                                                                       K *__restrict__ regions, uint32_t *__restrict__ kept,
                                                                       uint32_t flags, uint32_t min_occ, uint32_t big_min,
-                                                                      SketchStatus *st, FuseArgs fx)
+                                                                      SketchStatus *st, FuseArgs fx, PartArgs px)
 {
+    constexpr bool FUSED = MODE == DEDUP_FUSED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K *a = reinterpret_cast<K *>(smem);
-    if (reg_off[blockIdx.x + 1] - reg_off[blockIdx.x] > big_min) return;  // too large for LDS: the global-memory path below
+    uint32_t g = blockIdx.x, part = 0, lg_parts = 0;
+    if (MODE == DEDUP_PARTS) {
+        const uint2 md = px.list[blockIdx.x];
+        g = md.x;
+        lg_parts = md.y;
+        part = blockIdx.y;
+        if (part >> lg_parts) return;  // this genome has fewer parts than the launch is wide
+    } else if (reg_off[blockIdx.x + 1] - reg_off[blockIdx.x] > big_min) {
+        return;  // too large for one workgroup's LDS: the parts launch or the global-memory path below
+    }
     __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
     __shared__ uint32_t s_distinct, s_zero_occ;
-    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const unsigned long long r0 = reg_off[g];
     const uint32_t cap = (uint32_t)(reg_off[g + 1] - r0);
+    uint32_t *pcnt = MODE == DEDUP_PARTS ? px.cnt + ((size_t)blockIdx.x << (DEDUP_MAX_PARTS_LOG2 + 2)) + part * 4u : nullptr;
     uint32_t n;
-    if (FUSED) {
+    if (MODE == DEDUP_PARTS) {
+        __shared__ uint32_t s_np;
+        const uint32_t lane = lane_id();
+        if (tid == 0) s_np = 0;
+        __syncthreads();
+        const uint32_t staged = cursor[g];
+        if (staged > cap) {  // the exact stage wanted to stage more than the region holds: the call is repeated larger
+            if (tid == 0) {
+                if (part == 0) {
+                    atomicOr(&st->region_overflow, 1u);
+                    unsigned long long need = ((unsigned long long)staged * 256ull + cap - 1) / (cap ? cap : 1);
+                    atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
+                }
+                pcnt[0] = pcnt[1] = pcnt[2] = 0;
+                pcnt[3] = 1;
+            }
+            return;
+        }
+        const uint32_t shift = px.id_bits - lg_parts, last_part = (1u << lg_parts) - 1u;
+        for (uint32_t i0 = 0; i0 < staged; i0 += DEDUP_THREADS) {
+            const uint32_t i = i0 + tid;
+            bool mine = false;
+            K kv = 0;
+            if (i < staged) {
+                kv = regions[r0 + i];
+                const uint32_t pp = KeyOps<K>::id(kv) >> shift;
+                mine = (pp < last_part ? pp : last_part) == part;
+            }
+            const uint64_t bal = __ballot(mine);
+            if (bal) {  // one LDS atomic per wave reserves room for its tuples
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&s_np, (uint32_t)__builtin_popcountll(bal));
+                at = __builtin_amdgcn_readfirstlane(at) + rank_in(bal);
+                if (mine && at < px.part_cap) a[at] = kv;
+            }
+        }
+        __syncthreads();
+        n = s_np;
+        if (n > px.part_cap) {  // this id range holds more than the LDS sort takes: larger regions mean more, narrower parts
+            if (tid == 0) {
+                atomicOr(&st->region_overflow, 1u);
+                const unsigned long long need = ((unsigned long long)n * 256ull + px.part_cap - 1) / px.part_cap;
+                atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
+                pcnt[0] = pcnt[1] = pcnt[2] = 0;
+                pcnt[3] = 1;
+            }
+            return;
+        }
+    } else if (FUSED) {
         __shared__ uint32_t s_n, s_pref[DEDUP_THREADS];
         __shared__ unsigned long long s_first[DEDUP_THREADS];
         const uint32_t lane = lane_id();
@@ -1133,8 +1214,10 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     } else {
         n = cursor[g];
     }
-    const K *src = FUSED ? a : regions + r0;
-    if (n > cap) {
+    const K *src = MODE != DEDUP_STAGED ? a : regions + r0;
+    K *outp = regions + r0;  // where the kept keys go
+    if (MODE == DEDUP_PARTS) outp = reinterpret_cast<K *>(px.out) + (((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) + part) * px.part_cap;
+    if (MODE != DEDUP_PARTS && n > cap) {
         if (tid == 0) {
             atomicOr(&st->region_overflow, 1u);
             unsigned long long need = ((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1);
@@ -1153,7 +1236,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     else if (np == 8 * DEDUP_THREADS) sort_in_registers<K, 8>(a, src, n, tid);
     else {
     for (uint32_t i = tid; i < np; i += DEDUP_THREADS)
-        if (!FUSED || i >= n) a[i] = i < n ? src[i] : KeyOps<K>::pad();  // (fused: the keys are in place already)
+        if (MODE == DEDUP_STAGED || i >= n) a[i] = i < n ? src[i] : KeyOps<K>::pad();  // (fused, parts: the keys are in place already)
     __syncthreads();
     for (uint32_t k = 2; k <= np; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -1206,16 +1289,59 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         }
         uint32_t tot;
         const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
-        if (keep) regions[r0 + out_base + pos] = kv;  // out_base+pos <= i: never overtakes unread input (input is in LDS)
+        if (keep) outp[out_base + pos] = kv;  // out_base+pos <= i: never overtakes unread input (input is in LDS)
         out_base += tot;
     }
     __syncthreads();
     if (tid == 0) {
-        kept[g] = out_base;
-        if (!(flags & KSSD_SKETCH_NO_CAPACITY) && s_distinct + s_zero_occ > P.hashlimit) {
-            // keycount > hashlimit (iseq2comem.c:261-263)
-            atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
+        if (MODE == DEDUP_PARTS) {  // the genome's totals (and its capacity rule) are the finish kernel's
+            pcnt[0] = out_base;
+            pcnt[1] = s_distinct;
+            pcnt[2] = s_zero_occ;
+            pcnt[3] = 0;
+        } else {
+            kept[g] = out_base;
+            if (!(flags & KSSD_SKETCH_NO_CAPACITY) && s_distinct + s_zero_occ > P.hashlimit) {
+                // keycount > hashlimit (iseq2comem.c:261-263)
+                atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
+            }
         }
+    }
+}
+
+// the parts of a medium genome back into its staging region, one behind the other (ascending: the parts are id ranges), and
+// the genome's totals: kept ids, the capacity rule over all its distinct ids (iseq2comem.c:261-263)
+template <typename K>
+__global__ __launch_bounds__(256) void dedup_parts_finish_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off, K *__restrict__ regions,
+                                                                 uint32_t *__restrict__ kept, uint32_t flags, SketchStatus *st, PartArgs px)
+{
+    __shared__ uint32_t s_pre[(1 << DEDUP_MAX_PARTS_LOG2) + 1];
+    __shared__ uint32_t s_bad;
+    const uint2 md = px.list[blockIdx.x];
+    const uint32_t g = md.x, n_parts = 1u << md.y;
+    const uint32_t *cnt = px.cnt + ((size_t)blockIdx.x << (DEDUP_MAX_PARTS_LOG2 + 2));
+    if (threadIdx.x == 0) {
+        uint32_t run = 0, distinct = 0, zero_occ = 0, bad = 0;
+        for (uint32_t p = 0; p < n_parts; p++) {
+            s_pre[p] = run;
+            run += cnt[p * 4];
+            distinct += cnt[p * 4 + 1];
+            zero_occ += cnt[p * 4 + 2];
+            bad |= cnt[p * 4 + 3];
+        }
+        s_pre[n_parts] = run;
+        s_bad = bad;
+        kept[g] = bad ? 0u : run;
+        if (!bad && !(flags & KSSD_SKETCH_NO_CAPACITY) && (unsigned long long)distinct + zero_occ > P.hashlimit)
+            atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
+    }
+    __syncthreads();
+    if (s_bad) return;
+    const unsigned long long r0 = reg_off[g];
+    const K *out = reinterpret_cast<const K *>(px.out) + ((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) * px.part_cap;
+    for (uint32_t p = 0; p < n_parts; p++) {
+        const uint32_t b = s_pre[p], m = s_pre[p + 1] - b;
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) regions[r0 + b + i] = out[(size_t)p * px.part_cap + i];
     }
 }
 
@@ -1422,8 +1548,10 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     const size_t dlds = (size_t)np * sizeof(K);
     FuseArgs fx;
     memset(&fx, 0, sizeof fx);
-    if (c->h_big.empty()) {
-        // no genome needs the global-memory sort: exact stage and per-genome sort in one kernel, straight from the candidate list
+    PartArgs px;
+    memset(&px, 0, sizeof px);
+    if (c->h_big.empty() && c->h_med.empty()) {
+        // no genome needs staged tuples: exact stage and per-genome sort in one kernel, straight from the candidate list
         const auto &pl = c->plan;
         fx.cand = reinterpret_cast<const ulonglong2 *>(c->d_cand);
         fx.blk_info = c->d_blk_info;
@@ -1434,17 +1562,35 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         fx.carry = kssd_carry_ok(c->P) ? 1u : 0u;
         fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
         fx.lds_keys = np;
-        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, true>),
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
-        hipLaunchKernelGGL((sketch_dedup_kernel<K, true>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
+        hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_FUSED>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
                            (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
-                           flags, min_occ, big_min, c->d_status, fx);
+                           flags, min_occ, big_min, c->d_status, fx, px);
     } else {
-        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, false>),
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_STAGED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
-        hipLaunchKernelGGL((sketch_dedup_kernel<K, false>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
+        hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_STAGED>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
                            (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
-                           flags, min_occ, big_min, c->d_status, fx);
+                           flags, min_occ, big_min, c->d_status, fx, px);
+    }
+    if (!c->h_med.empty()) {
+        // genomes between one LDS sort and sixteen: sorted in LDS in parts (ranges of the ids' top bits), two launches for all of them
+        uint32_t lg_max = 1;
+        for (const uint2 &m : c->h_med) lg_max = m.y > lg_max ? m.y : lg_max;
+        px.list = c->d_med;
+        px.out = c->d_med_out;
+        px.cnt = c->d_med_cnt;
+        px.part_cap = c->med_part_cap;
+        px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
+        const size_t plds = (size_t)px.part_cap * sizeof(K);
+        HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_PARTS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(plds < 65536 ? 65536 : plds)));
+        hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_PARTS>), dim3((unsigned)c->h_med.size(), 1u << lg_max), dim3(DEDUP_THREADS), plds, s, c->P,
+                           (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
+                           flags, min_occ, big_min, c->d_status, fx, px);
+        hipLaunchKernelGGL((dedup_parts_finish_kernel<K>), dim3((unsigned)c->h_med.size()), dim3(256), 0, s, c->P,
+                           (const unsigned long long *)c->d_reg_off, regions, c->d_kept, flags, c->d_status, px);
     }
     if (!c->h_big.empty()) {
         const size_t n_tiles_max = (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
@@ -1479,7 +1625,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     }
     hipLaunchKernelGGL(sketch_offsets_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)c->d_kept, n_genomes,
                        (unsigned long long *)d_out_off, (unsigned long long)out_cap, c->d_status);
-    hipLaunchKernelGGL((sketch_gather_kernel<K>), dim3(n_genomes, c->h_big.empty() ? 1u : (n_genomes < 64u ? 256u : 16u)), dim3(256), 0, s,
+    hipLaunchKernelGGL((sketch_gather_kernel<K>), dim3(n_genomes, c->h_big.empty() ? (c->h_med.empty() ? 1u : 16u) : (n_genomes < 64u ? 256u : 16u)), dim3(256), 0, s,
                        (const unsigned long long *)c->d_reg_off,
                        (const K *)regions, (const uint32_t *)c->d_kept, (const unsigned long long *)d_out_off,
                        d_out_ids, d_out_pos, (const SketchStatus *)c->d_status);
@@ -1530,6 +1676,8 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     c->h_reg_off.resize((size_t)n_genomes + 1);
     c->h_big.clear();
+    c->h_med.clear();
+    uint64_t med_part = 0;
     uint32_t big_min = c->lds_sort_limit && c->lds_sort_limit < DEDUP_MAX_N ? c->lds_sort_limit : DEDUP_MAX_N;
     if (with_pos && big_min > DEDUP_MAX_N / 2) big_min = DEDUP_MAX_N / 2;  // 8-byte keys: half as many fit the LDS sort
     uint64_t acc = 0, max_cap = 0, max_big = 0;
@@ -1543,19 +1691,48 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
             // a genome expected to fit the LDS sort keeps that path -- unless an earlier attempt has shown that this
             // batch emits far more than the sampling rate predicts (low-complexity sequence): then the factor decides
             if (c->region_factor <= 2.0 && (uint64_t)((double)pos * rate * 1.25) + 64 <= big_min) cap = big_min;
-            else {
+            else if (!(flags & KSSD_SKETCH_BY_POS) && cap <= ((uint64_t)big_min << DEDUP_MAX_PARTS_LOG2)) {
+                // sorted in LDS in parts: ranges of the ids' top bits, narrow enough for the register sort where that is possible
+                // (~4 096 expected tuples per part) and never wider than the LDS array
+                uint32_t lg = 1;
+                while (lg < DEDUP_MAX_PARTS_LOG2 && ((cap >> lg) > 8192 || (cap >> lg) > big_min)) lg++;
+                c->h_med.push_back(make_uint2(g, lg));
+                if ((cap >> lg) + 1 > med_part) med_part = (cap >> lg) + 1;
+            } else {
                 if (cap >= (1ull << 31)) { c->last_launch_rc = KSSD_ERR_UNSUPPORTED; return KSSD_ERR_UNSUPPORTED; }
                 c->h_big.push_back(g);  // global-memory sort path
             }
         }
         c->h_reg_off[g] = acc;
         acc += cap;
+        const bool is_med = !c->h_med.empty() && c->h_med.back().x == g;
         if (cap <= big_min && cap > max_cap) max_cap = cap;
-        if (cap > big_min && cap > max_big) max_big = cap;
+        if (cap > big_min && !is_med && cap > max_big) max_big = cap;
     }
     c->h_reg_off[n_genomes] = acc;
     c->h_chunk_off.assign(h_chunk_off, h_chunk_off + n_genomes + 1);
     int rc;
+    if (!c->h_med.empty()) {
+        uint32_t pc = 1024;
+        while (pc < med_part) pc <<= 1;
+        if (pc > big_min) pc = big_min;
+        c->med_part_cap = pc;
+        const size_t nm = c->h_med.size();
+        {
+            const size_t before = c->cap_med;
+            if ((rc = ensure(&c->d_med, &c->cap_med, nm)) != KSSD_OK) return rc;
+            if (c->cap_med != before) c->dev_med.clear();
+        }
+        if ((rc = ensure(&c->d_med_cnt, &c->cap_med_cnt, nm << (DEDUP_MAX_PARTS_LOG2 + 2))) != KSSD_OK) return rc;
+        const size_t out_bytes = (nm << DEDUP_MAX_PARTS_LOG2) * (size_t)pc * (with_pos ? 8 : 4);
+        if (out_bytes > c->cap_med_out) {
+            if (c->d_med_out) hipFree(c->d_med_out);
+            c->d_med_out = nullptr;
+            c->cap_med_out = 0;
+            if (hipMalloc(&c->d_med_out, out_bytes + out_bytes / 4) != hipSuccess) return KSSD_ERR_NOMEM;
+            c->cap_med_out = out_bytes + out_bytes / 4;
+        }
+    }
     if ((rc = ensure(&c->d_chunk_gid, &c->cap_chunks, (size_t)n_chunks + 1)) != KSSD_OK) return rc;
     {
         const size_t before = c->cap_chunk_off;
@@ -1603,6 +1780,14 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
     if (c->dev_reg_off != c->h_reg_off) {
         HIPCK(hipMemcpyAsync(c->d_reg_off, c->h_reg_off.data(), nb, hipMemcpyHostToDevice, s));
         c->dev_reg_off = c->h_reg_off;
+    }
+    if (!c->h_med.empty()) {
+        bool same = c->dev_med.size() == c->h_med.size();
+        for (size_t i = 0; same && i < c->h_med.size(); i++) same = c->dev_med[i].x == c->h_med[i].x && c->dev_med[i].y == c->h_med[i].y;
+        if (!same) {
+            c->dev_med = c->h_med;  // (the copy reads dev_med: it stays as it is until the next plan that differs)
+            HIPCK(hipMemcpyAsync(c->d_med, c->dev_med.data(), c->dev_med.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
+        }
     }
     uint64_t init_n = pl.n_chunks > pl.n_genomes ? pl.n_chunks : pl.n_genomes;
     if (init_n < pl.n_slices) init_n = pl.n_slices;
@@ -1684,7 +1869,7 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
 {
     const auto &pl = c->plan;
     if (pl.n_genomes == 0 || pl.n_chunks == 0) return KSSD_OK;
-    if (c->h_big.empty()) return KSSD_OK;  // the FINISH phase evaluates the candidates itself (sketch_dedup_kernel<K, true>)
+    if (c->h_big.empty() && c->h_med.empty()) return KSSD_OK;  // the FINISH phase evaluates the candidates itself (sketch_dedup_kernel<K, DEDUP_FUSED>)
     ExactArgs x;
     x.packed = pl.d_packed; x.mask = pl.d_mask; x.chunk_gid = c->d_chunk_gid;
     x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G;

@@ -486,3 +486,48 @@ def test_a_wave_that_owns_more_than_2048_chunks(shuf_l3k10):
     finally:
         ctx.set_scan_grid(0)
         ctx.close()
+
+
+def test_genomes_sorted_in_lds_in_parts(shuf_l3k10):
+    """genomes whose staged tuples exceed one LDS sort but split by their ids' top bits into up to 16 ranges that fit
+    (DEDUP_PARTS: a 150 Mb record here, the 3 Gb records of BASELINE configs[4] at -s 7): id sets against the oracle, next
+    to small genomes and an empty one in the same batch; first positions and occurrence counts through the same path;
+    the same genomes with kssd_gpu_set_lds_sort_limit(4096): more genomes take the parts path, the largest the global-memory one"""
+    rng = np.random.default_rng(150)
+    big = rng.integers(0, 4, 150_000_000, dtype=np.uint8)
+    nm = np.zeros(len(big), dtype=bool)
+    nm[rng.integers(0, len(big), 500)] = True
+    texts = [fasta_text(rng.integers(0, 4, 300_000, dtype=np.uint8), b"small0"), fasta_text(big, b"chr", n_mask=nm), b">empty\n",
+             fasta_text(big[:40_000_000], b"arm"), fasta_text(rng.integers(0, 4, 2_000_000, dtype=np.uint8), b"small1")]
+    del big, nm
+    sk = ko.Sketcher(shuf_l3k10.table, 10, 6, 3)
+    want = [np.sort(sk.fasta(t)) for t in texts]
+    assert len(want[1]) > 32768
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        b = K.Batch()
+        for t in texts:
+            b.add_fasta(t)
+        for limit in (0, 4096):
+            ctx.set_lds_sort_limit(limit)
+            off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+            for g in range(len(texts)):
+                assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want[g]), (limit, g)
+            off, ids, pos = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY | K.SKETCH_FIRST_POS)
+            for g in range(len(texts)):
+                assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want[g]), (limit, g, "pos")
+            off, ids, cnt = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY | K.SKETCH_COUNTS)
+            for g in range(len(texts)):
+                assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want[g]) and (cnt[int(off[g]):int(off[g + 1])] >= 1).all(), (limit, g, "counts")
+        # first positions: the k-mer at that position reduces to that id (checked on the 40 Mb arm through the oracle's position list)
+        ctx.set_lds_sort_limit(0)
+        off, ids, pos = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY | K.SKETCH_FIRST_POS)
+        order = K.slot_order_pos(ids[int(off[3]):int(off[4])], pos[int(off[3]):int(off[4])], 2097143)
+        assert np.array_equal(order, sk.fasta(texts[3]))            # the reference's file order: needs every first position right
+        # without the flag the 150 Mb record is still below the reference's capacity limit (1 258 285): no abort either way
+        off2, ids2 = ctx.sketch_batch(b)
+        assert np.array_equal(ids2, ids)
+        b.close()
+    finally:
+        ctx.set_lds_sort_limit(0)
+        ctx.close()
