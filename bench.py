@@ -705,7 +705,7 @@ def run_mammal(a, dev, world, rank):
                        "k": 10, "subk": 7, "drlevel": 5, "records_per_gpu": G, "record_len": L,
                        "parallelism": "single GPU" if world == 1 else "%d replicas, records sharded, no collective" % world},
             "genomes_per_s": world * G * a.steps / dt, "ids_per_batch": int(total), "ids_per_record": int(total) / G,
-            "phase_ms_last_step": dict(zip(["prep", "scan", "exact", "dedup_finish(rocPRIM sort path)"], [float(x) for x in phases])),
+            "phase_ms_last_step": dict(zip(["prep", "scan", "exact", "dedup_finish (LDS sort in parts, offsets, gather)"], [float(x) for x in phases])),
             "kernels": {"sketch_scan_ms": scan_ms, "launches_timed": scan_n,
                         "scan_positions_past_stage1": n_stage1 / n_pos, "scan_positions_past_bloom": n_bloom / n_pos},
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<7>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
