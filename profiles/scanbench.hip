@@ -16,6 +16,7 @@
 
 #include "../include/kssd_gpu.h"
 extern "C" int kssd_gpu_dev_wavetimes(unsigned long long *out, uint32_t n_waves);  // libkssd_gpu_dev.so only
+extern "C" int kssd_gpu_dev_deduptimes(unsigned long long *out, uint32_t n_genomes);
 
 #define CK(x)                                                                         \
     do {                                                                              \
@@ -224,6 +225,14 @@ int main(int argc, char **argv)
             double mean = 0, mx = 0;
             for (uint32_t w = 0; w < nw; w++) { mean += loop[w] / nw; mx = std::max(mx, loop[w]); }
             printf("\n  mean / max of the chunk loops: %.3f (what a launch that ended with its average wave would take)\n", mean / mx);
+        }
+    }
+    if (getenv("KSSD_DEV_DEDUPTIME")) {
+        std::vector<unsigned long long> t((size_t)G * 4);
+        if (kssd_gpu_dev_deduptimes(t.data(), G) == 0) {
+            double a = 0, b = 0, c = 0;
+            for (uint32_t g = 0; g < G; g++) { a += (double)(t[4 * g + 1] - t[4 * g]); b += (double)(t[4 * g + 2] - t[4 * g + 1]); c += (double)(t[4 * g + 3] - t[4 * g + 2]); }
+            printf("per-genome kernel, mean ticks per workgroup: candidates -> keys in LDS %.0f, sort %.0f, runs + keep rules + write %.0f\n", a / G, b / G, c / G);
         }
     }
     kssd_gpu_destroy(ctx);

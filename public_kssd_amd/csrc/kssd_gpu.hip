@@ -561,8 +561,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         load_chunk(a, chunk_at(c0 + 1), lane, r1);
         load_chunk(a, chunk_at(c0 + 2), lane, r2);
     }
-    for (uint32_t i = threadIdx.x * 16; i < SCAN_TAB_BYTES; i += SCAN_THREADS * 16)
-        *reinterpret_cast<uint4 *>(smem + i) = *reinterpret_cast<const uint4 *>(a.tab + i);
+    {   // 144 KiB = nine 16-byte pieces per thread: all nine requested before the first one is stored
+        static_assert(SCAN_TAB_BYTES % (SCAN_THREADS * 16) == 0, "the table copy is written for whole rounds");
+        constexpr int TAB_ROUNDS = SCAN_TAB_BYTES / (SCAN_THREADS * 16);
+        uint4 t[TAB_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < TAB_ROUNDS; r++) t[r] = *reinterpret_cast<const uint4 *>(a.tab + (size_t)(r * SCAN_THREADS + threadIdx.x) * 16);
+#pragma unroll
+        for (int r = 0; r < TAB_ROUNDS; r++) *reinterpret_cast<uint4 *>(smem + (size_t)(r * SCAN_THREADS + threadIdx.x) * 16) = t[r];
+    }
     __syncthreads();
 #ifdef KSSD_DEV
     const unsigned long long dev_t1 = __builtin_readcyclecounter();
@@ -1021,6 +1028,9 @@ struct FuseArgs {
     const uint32_t *packed, *mask;
     const KssdG *G;
     uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
+#ifdef KSSD_DEV
+    unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memtime)
+#endif
 };
 #define FUSE_PER 4  // candidates a thread evaluates at a time (six spill at 64 VGPRs)
 
@@ -1048,6 +1058,10 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                                                                       SketchStatus *st, FuseArgs fx, PartArgs px)
 {
     constexpr bool FUSED = MODE == DEDUP_FUSED;
+#ifdef KSSD_DEV
+    const unsigned long long dev_t0 = __builtin_readcyclecounter();
+    unsigned long long dev_t1 = 0, dev_t2 = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K *a = reinterpret_cast<K *>(smem);
     uint32_t g = blockIdx.x, part = 0, lg_parts = 0;
@@ -1224,6 +1238,9 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     } else {
         n = cursor[g];
     }
+#ifdef KSSD_DEV
+    dev_t1 = __builtin_readcyclecounter();
+#endif
     const K *src = MODE != DEDUP_STAGED ? a : regions + r0;
     K *outp = regions + r0;  // where the kept keys go
     if (MODE == DEDUP_PARTS) outp = reinterpret_cast<K *>(px.out) + (((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) + part) * px.part_cap;
@@ -1262,6 +1279,9 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         }
     }
     }
+#ifdef KSSD_DEV
+    dev_t2 = __builtin_readcyclecounter();
+#endif
     // runs of equal tuples; only the first n entries are real (in first-position mode the first entry of a run is
     // the tuple's first occurrence)
     uint32_t out_base = 0;
@@ -1303,6 +1323,14 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         out_base += tot;
     }
     __syncthreads();
+#ifdef KSSD_DEV
+    if (FUSED && fx.dev_times && tid == 0) {
+        fx.dev_times[blockIdx.x * 4] = dev_t0;
+        fx.dev_times[blockIdx.x * 4 + 1] = dev_t1;
+        fx.dev_times[blockIdx.x * 4 + 2] = dev_t2;
+        fx.dev_times[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+    }
+#endif
     if (tid == 0) {
         if (MODE == DEDUP_PARTS) {  // the genome's totals (and its capacity rule) are the finish kernel's
             pcnt[0] = out_base;
@@ -1547,6 +1575,17 @@ static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t
     return KSSD_OK;
 }
 
+#ifdef KSSD_DEV
+static unsigned long long *g_dev_dedup_times;
+extern "C" int kssd_gpu_dev_deduptimes(unsigned long long *out, uint32_t n_genomes)
+{
+    if (!g_dev_dedup_times) return KSSD_ERR_PARAM;
+    HIPCK(hipDeviceSynchronize());
+    HIPCK(hipMemcpy(out, g_dev_dedup_times, (size_t)n_genomes * 4 * 8, hipMemcpyDeviceToHost));
+    return KSSD_OK;
+}
+#endif
+
 // per-genome dedup (LDS sort or, for large genomes, rocPRIM sort + run kernels), CSR offsets, gather; K = key type
 template <typename K>
 static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint32_t big_min, uint64_t max_cap,
@@ -1574,6 +1613,14 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         fx.carry = kssd_carry_ok(c->P) ? 1u : 0u;
         fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
         fx.lds_keys = np;
+#ifdef KSSD_DEV
+        {
+            static unsigned long long *d_dt = nullptr;
+            if (!d_dt && getenv("KSSD_DEV_DEDUPTIME")) hipMalloc(&d_dt, 65536 * 4 * 8);
+            fx.dev_times = n_genomes <= 65536 ? d_dt : nullptr;
+            g_dev_dedup_times = fx.dev_times;
+        }
+#endif
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
         hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_FUSED>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
