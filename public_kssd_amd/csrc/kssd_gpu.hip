@@ -1017,6 +1017,75 @@ __device__ __forceinline__ void sort_in_registers(K *a, const K *src /* may be a
     __syncthreads();
 }
 
+// Sort of one genome's keys by bucket counting in LDS, for the sizes the per-genome kernel mostly sees (up to
+// DEDUP_BSORT_MAX keys).  The bitonic network in registers moves every key through the LDS crossbar once per pass -- ~45
+// `ds_bpermute` per key at 2 048 keys, and a `ds_bpermute` costs what a conflicted LDS read costs (profiles/r03b_valu_probe.txt):
+// with four workgroups per CU the sort took 45 000 of the kernel's 118 000 cycles.  The ids are reduced tuples -- the
+// outermost bases of the canonical k-mer in their top bits -- so they spread over the id range: as many buckets as key
+// slots (one LDS atomic per key to count, one to place), a workgroup scan of the counters, and an insertion sort of
+// every bucket by the thread that owns it (most hold none or one; the canonical strand makes low prefixes more likely,
+// a bucket of a dozen is rare).  Equal ids (repeats) meet in one bucket.  A batch whose ids do not spread -- low-complexity
+// sequence, crafted input -- shows up as a bucket above DEDUP_BSORT_BUCKET keys: the function says no and the bitonic sort
+// runs as before.  Returns true with the sorted keys in b[0 .. n).
+#define DEDUP_BSORT_MAX 4096u     // key slots (= buckets) at most
+#define DEDUP_BSORT_BUCKET 24u    // a fuller bucket sends the genome to the bitonic sort
+template <typename K>
+__device__ __forceinline__ bool lds_bucket_sort(const K *src, K *b, uint32_t *cnt, uint32_t n, uint32_t nb /*pow2*/, uint32_t id_bits, uint32_t tid,
+                                                uint32_t *wsum)
+{
+    uint32_t lg = 0;
+    while ((1u << lg) < nb) lg++;
+    const uint32_t shift = id_bits > lg ? id_bits - lg : 0u, last = nb - 1u;
+    for (uint32_t i = tid; i < nb; i += DEDUP_THREADS) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += DEDUP_THREADS) {
+        const uint32_t bk = KeyOps<K>::id(src[i]) >> shift;
+        atomicAdd(&cnt[bk < last ? bk : last], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the counters: every thread owns nb / DEDUP_THREADS consecutive ones (or none)
+    const uint32_t per = nb >= DEDUP_THREADS ? nb / DEDUP_THREADS : 1u, b0 = tid * per;
+    uint32_t sum = 0, mx = 0;
+    if (b0 < nb)
+        for (uint32_t k = 0; k < per; k++) { const uint32_t c = cnt[b0 + k]; sum += c; mx = c > mx ? c : mx; }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, wsum, total);
+    // the fullest bucket decides (workgroup-uniform): packed into the scan's scratch words by a second tiny reduction
+    uint32_t mx_all;
+    {
+        const uint32_t lane = lane_id(), wave = tid >> 6;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
+        if (lane == 0) wsum[wave] = mx;
+        __syncthreads();
+        mx_all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < DEDUP_THREADS / 64; w++) mx_all = wsum[w] > mx_all ? wsum[w] : mx_all;
+        __syncthreads();
+    }
+    if (mx_all > DEDUP_BSORT_BUCKET) return false;
+    if (b0 < nb)
+        for (uint32_t k = 0; k < per; k++) { const uint32_t c = cnt[b0 + k]; cnt[b0 + k] = run; run += c; }  // the bucket's first slot
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += DEDUP_THREADS) {
+        const K kv = src[i];
+        const uint32_t bk = KeyOps<K>::id(kv) >> shift;
+        b[atomicAdd(&cnt[bk < last ? bk : last], 1u)] = kv;
+    }
+    __syncthreads();
+    for (uint32_t bk = tid; bk < nb; bk += DEDUP_THREADS) {  // (after the scatter cnt[bk] is the bucket's end = the next bucket's first slot)
+        const uint32_t s0 = bk ? cnt[bk - 1] : 0u, e0 = cnt[bk];
+        for (uint32_t i = s0 + 1; i < e0; i++) {
+            const K x = b[i];
+            uint32_t j = i;
+            while (j > s0 && b[j - 1] > x) { b[j] = b[j - 1]; j--; }
+            b[j] = x;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 // FUSED: the workgroup takes its genome's candidates straight from the scan's candidate list (the slices of the scan
 // waves whose chunk runs overlap the genome), evaluates them (stage 2, as sketch_exact_kernel does) and collects the
 // survivors in LDS, where the sort needs them anyway: no staging region is written and read back, no cursor atomics, no
@@ -1028,6 +1097,7 @@ struct FuseArgs {
     const uint32_t *packed, *mask;
     const KssdG *G;
     uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
+    uint32_t id_bits, bsort_keys;      // ids are below 2^id_bits (roughly); bsort_keys: key slots of the bucket sort's LDS arrays (0: none)
 #ifdef KSSD_DEV
     unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memtime)
 #endif
@@ -1258,7 +1328,17 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     uint32_t np = 1;
     while (np < n) np <<= 1;
     if (tid == 0) { s_distinct = 0; s_zero_occ = 0; }
-    if (np == 2 * DEDUP_THREADS) sort_in_registers<K, 2>(a, src, n, tid);
+    // dynamic LDS: a[lds_keys] | b[bsort_keys] | counters[bsort_keys]  (lds_keys: the launch's array -- part_cap in PARTS mode)
+    const K *sorted = a;
+    bool bsorted = false;
+    if (fx.bsort_keys && n > 64 && np <= fx.bsort_keys) {
+        K *b = a + (MODE == DEDUP_PARTS ? px.part_cap : fx.lds_keys);
+        uint32_t *bcnt = reinterpret_cast<uint32_t *>(b + fx.bsort_keys);
+        bsorted = lds_bucket_sort<K>(src, b, bcnt, n, np, fx.id_bits, tid, wsum);
+        if (bsorted) sorted = b;
+    }
+    if (bsorted) {
+    } else if (np == 2 * DEDUP_THREADS) sort_in_registers<K, 2>(a, src, n, tid);
     else if (np == 4 * DEDUP_THREADS) sort_in_registers<K, 4>(a, src, n, tid);
     else if (np == 8 * DEDUP_THREADS) sort_in_registers<K, 8>(a, src, n, tid);
     else {
@@ -1290,15 +1370,15 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         bool keep = false, counted = false;
         K kv = 0;
         if (i < n) {
-            kv = a[i];
+            kv = sorted[i];
             const uint32_t v = KeyOps<K>::id(kv);
-            const bool start = (i == 0) || (KeyOps<K>::id(a[i - 1]) != v);
+            const bool start = (i == 0) || (KeyOps<K>::id(sorted[i - 1]) != v);
             if (start) {
                 uint32_t lo = i + 1, hi = n;  // first index > i with a different tuple
-                if (lo < n && KeyOps<K>::id(a[lo]) != v) hi = lo;  // the common case: a run of one
+                if (lo < n && KeyOps<K>::id(sorted[lo]) != v) hi = lo;  // the common case: a run of one
                 while (lo < hi) {
                     uint32_t mid = (lo + hi) >> 1;
-                    if (KeyOps<K>::id(a[mid]) == v) lo = mid + 1;
+                    if (KeyOps<K>::id(sorted[mid]) == v) lo = mid + 1;
                     else hi = mid;
                 }
                 const uint32_t len = lo - i;
@@ -1596,11 +1676,20 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     K *regions = reinterpret_cast<K *>(c->d_regions);
     uint32_t np = 1;
     while (np < max_cap) np <<= 1;
-    const size_t dlds = (size_t)np * sizeof(K);
     FuseArgs fx;
     memset(&fx, 0, sizeof fx);
     PartArgs px;
     memset(&px, 0, sizeof px);
+    // the bucket sort's LDS arrays behind the key array (lds_bucket_sort): as many key slots as the key array has, up to
+    // DEDUP_BSORT_MAX; by-position keys lead with the position, which does not spread over the id range: bitonic only
+    bool bsort = !(c->plan.flags & KSSD_SKETCH_BY_POS);
+#ifdef KSSD_DEV
+    if (getenv("KSSD_DEV_NO_BUCKET_SORT")) bsort = false;  // (development A/B: the bitonic network for every genome)
+#endif
+    fx.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
+    fx.lds_keys = np;
+    fx.bsort_keys = bsort ? (np < DEDUP_BSORT_MAX ? np : DEDUP_BSORT_MAX) : 0u;
+    const size_t dlds = (size_t)np * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
     if (c->h_big.empty() && c->h_med.empty()) {
         // no genome needs staged tuples: exact stage and per-genome sort in one kernel, straight from the candidate list
         const auto &pl = c->plan;
@@ -1642,7 +1731,8 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         px.cnt = c->d_med_cnt;
         px.part_cap = c->med_part_cap;
         px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
-        const size_t plds = (size_t)px.part_cap * sizeof(K);
+        fx.bsort_keys = bsort ? (px.part_cap < DEDUP_BSORT_MAX ? px.part_cap : DEDUP_BSORT_MAX) : 0u;
+        const size_t plds = (size_t)px.part_cap * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_PARTS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(plds < 65536 ? 65536 : plds)));
         hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_PARTS>), dim3((unsigned)c->h_med.size(), 1u << lg_max), dim3(DEDUP_THREADS), plds, s, c->P,
