@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: bucket sort in the per-genome kernel, CSR written by the kernel itself (look-back), index plan in idx_hist: A/B (development build),
+# round 3: the per-genome kernel's sort by bucket counting in LDS against the bitonic network (A/B in the development build),
 # parity suite, default line, configs[4]
 tag=${1:-r03k}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -7,8 +7,7 @@ mkdir -p gpurun_out
 {
 for g in 400 1000; do
   echo "== genomes $g, bucket sort"; KSSD_DEV_DEDUPTIME=1 timeout 300 profiles/scanbench $g 5000000 10 | grep -v "^stats"
-  echo "== genomes $g, bucket sort, offsets + gather kernels"; KSSD_DEV_NO_DIRECT=1 KSSD_DEV_DEDUPTIME=1 timeout 300 profiles/scanbench $g 5000000 10 | grep -v "^stats"
-  echo "== genomes $g, bitonic, offsets + gather kernels"; KSSD_DEV_NO_DIRECT=1 KSSD_DEV_NO_BUCKET_SORT=1 KSSD_DEV_DEDUPTIME=1 timeout 300 profiles/scanbench $g 5000000 10 | grep -v "^stats"
+  echo "== genomes $g, bitonic"; KSSD_DEV_NO_BUCKET_SORT=1 KSSD_DEV_DEDUPTIME=1 timeout 300 profiles/scanbench $g 5000000 10 | grep -v "^stats"
 done
 } > gpurun_out/${tag}_scanbench.txt 2>&1
 cat gpurun_out/${tag}_scanbench.txt

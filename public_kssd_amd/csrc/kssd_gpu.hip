@@ -76,7 +76,6 @@ struct SketchStatus {
     unsigned long long n_stage1, n_bloom;
     unsigned int cand_overflow;    // a shard of the candidate list was too small
     unsigned int cand_need;        // entries the fullest shard wanted
-    unsigned int lookback_stuck;   // a per-genome workgroup waited for a predecessor that never published (see DIRECT): host falls back
 };
 
 struct kssd_gpu_ctx {
@@ -104,9 +103,6 @@ struct kssd_gpu_ctx {
     size_t cap_cand_count;
     unsigned long long *d_blk_info;  // per block of the last scan: where its candidates are (scan_blk_pack)
     size_t cap_blk_info;
-    unsigned long long *d_lb_state;  // per genome: look-back state of the fused per-genome kernel (DIRECT)
-    size_t cap_lb_state;
-    bool no_direct;                  // a look-back once waited in vain: offsets + gather kernels from then on
     uint64_t last_cand_cap;
     uint64_t cand_floor;    // per-slice capacity an overflowed attempt asked for (kept for the retries)
     double cand_factor;
@@ -290,7 +286,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_lb_state, c->d_big_alt, c->d_big_tmp,
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
                     c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -388,11 +384,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 // (it also zeroes the small per-call state: four separate memsets cost more than this whole kernel)
 __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes, uint64_t n_chunks,
                                  uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                 uint32_t n_slices, uint32_t *__restrict__ status_words, unsigned long long *__restrict__ lb_state)
+                                 uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < sizeof(SketchStatus) / 4) status_words[c] = 0;
-    if (c < n_genomes) { cursor[c] = 0; lb_state[c] = 0; }
+    if (c < n_genomes) cursor[c] = 0;
     if (c < n_slices) cand_count[c] = 0;
     if (c >= n_chunks) return;
     uint32_t lo = 0, hi = n_genomes;  // last g with chunk_off[g] <= c
@@ -408,12 +404,12 @@ __global__ void chunk_gid_kernel(const uint64_t *__restrict__ chunk_off, uint32_
 // when genomes span many chunks.  The per-call state is zeroed by the first workgroups like above.
 __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_off, uint32_t n_genomes,
                                            uint32_t *__restrict__ chunk_gid, uint32_t *__restrict__ cursor, uint32_t *__restrict__ cand_count,
-                                           uint32_t n_slices, uint32_t *__restrict__ status_words, unsigned long long *__restrict__ lb_state)
+                                           uint32_t n_slices, uint32_t *__restrict__ status_words)
 {
     // grid = (genomes or more, parts): workgroup (g, y) writes every gridDim.y-th run of 256 chunks of genome g
     const uint64_t t = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x, nt = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
     if (t < sizeof(SketchStatus) / 4) status_words[t] = 0;
-    for (uint64_t i = t; i < n_genomes; i += nt) { cursor[i] = 0; lb_state[i] = 0; }
+    for (uint64_t i = t; i < n_genomes; i += nt) cursor[i] = 0;
     for (uint64_t i = t; i < n_slices; i += nt) cand_count[i] = 0;
     if (blockIdx.x >= n_genomes) return;
     const uint32_t g = blockIdx.x;
@@ -1102,13 +1098,6 @@ struct FuseArgs {
     const KssdG *G;
     uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
     uint32_t id_bits, bsort_keys;      // ids are below 2^id_bits (roughly); bsort_keys: key slots of the bucket sort's LDS arrays (0: none)
-    // DIRECT (fused launches): the workgroup writes its genome's ids straight into the CSR -- its offset is the sum of the
-    // kept counts of the genomes in front of it, found by a look-back over lb_state (no offsets kernel, no gather kernel)
-    unsigned long long *lb_state;      // per genome: 0 = nothing yet | 1 << 62 | kept | 2 << 62 | kept of all genomes up to it
-    unsigned long long *out_off;
-    uint32_t *out_ids, *out_pos;
-    unsigned long long out_cap;
-    uint32_t n_genomes, direct;
 #ifdef KSSD_DEV
     unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memtime)
 #endif
@@ -1331,10 +1320,6 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
             unsigned long long need = ((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1);
             atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
             kept[g] = 0;
-            if (FUSED && fx.direct) {  // the genomes behind this one look back through it (the call fails anyway)
-                fx.out_off[g] = 0;
-                __hip_atomic_store(&fx.lb_state[g], 3ull << 62, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "broken chain": stop here
-            }
         }
         return;
     }
@@ -1414,12 +1399,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         }
         uint32_t tot;
         const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
-        // out_base + pos <= i: never overtakes unread input.  DIRECT: compacted in place in the key array (its only reader
-        // left is the run test of the next round, which looks at the id of a[i0 - 1] -- rewritten, if at all, with itself)
-        if (keep) {
-            if (FUSED && fx.direct) a[out_base + pos] = kv;
-            else outp[out_base + pos] = kv;
-        }
+        if (keep) outp[out_base + pos] = kv;  // out_base+pos <= i: never overtakes unread input (input is in LDS)
         out_base += tot;
     }
     __syncthreads();
@@ -1443,55 +1423,6 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                 // keycount > hashlimit (iseq2comem.c:261-263)
                 atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
             }
-        }
-    }
-    if (FUSED && fx.direct) {
-        // Where the genome's ids go in the CSR: behind those of the genomes in front of it.  Workgroup g publishes its
-        // count, then walks back over its predecessors' states until it meets one that already knows its prefix (a
-        // decoupled look-back; workgroups are dispatched in index order, so a predecessor is running or done -- and if that
-        // ever failed to hold, the bounded wait below reports it instead of hanging: the host then falls back to the
-        // offsets + gather kernels).  Only counters travel: relaxed agent-scope atomics are all the ordering needed.
-        __shared__ unsigned long long s_lb_off;
-        __shared__ uint32_t s_lb_ok;
-        const unsigned long long VAL = (1ull << 62) - 1ull;
-        if (tid == 0) {
-            __hip_atomic_store(&fx.lb_state[g], (1ull << 62) | out_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long sum = 0;
-            uint32_t ok = 1;
-            for (long long j = (long long)g - 1; j >= 0 && ok;) {
-                unsigned long long v = 0;
-                uint32_t spins = 0;
-                while (((v = __hip_atomic_load(&fx.lb_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 24)) { ok = 0; break; }
-                }
-                if (!ok) break;
-                if ((v >> 62) == 3) { ok = 2; break; }  // a genome in front overflowed its region: the call is repeated, nothing to place
-                sum += v & VAL;
-                if ((v >> 62) == 2) break;
-                j--;
-            }
-            if (ok == 0) atomicOr(&st->lookback_stuck, 1u);
-            __hip_atomic_store(&fx.lb_state[g], ok == 1 ? ((2ull << 62) | (sum + out_base)) : (3ull << 62), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_lb_off = sum;
-            s_lb_ok = ok == 1 ? 1u : 0u;
-            fx.out_off[g] = sum;
-            if (g + 1 == fx.n_genomes) {
-                fx.out_off[g + 1] = sum + out_base;
-                st->total_ids = ok == 1 ? sum + out_base : 0ull;
-                if (ok == 1 && sum + out_base > fx.out_cap) st->out_overflow = 1;
-            }
-        }
-        __syncthreads();
-        const unsigned long long o0 = s_lb_off;
-        if (s_lb_ok && o0 + out_base <= fx.out_cap) {
-            for (uint32_t i = tid; i < out_base; i += DEDUP_THREADS) {
-                const K kv = a[i];
-                fx.out_ids[o0 + i] = KeyOps<K>::id(kv);
-                if (fx.out_pos) fx.out_pos[o0 + i] = KeyOps<K>::pos(kv);
-            }
-        } else if (s_lb_ok && tid == 0) {
-            st->out_overflow = 1;
         }
     }
 }
@@ -1749,22 +1680,15 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     memset(&fx, 0, sizeof fx);
     PartArgs px;
     memset(&px, 0, sizeof px);
-    bool direct = false;  // the fused kernel writes the CSR itself
     // the bucket sort's LDS arrays behind the key array (lds_bucket_sort): as many key slots as the key array has, up to
     // DEDUP_BSORT_MAX; by-position keys lead with the position, which does not spread over the id range: bitonic only
     bool bsort = !(c->plan.flags & KSSD_SKETCH_BY_POS);
 #ifdef KSSD_DEV
     if (getenv("KSSD_DEV_NO_BUCKET_SORT")) bsort = false;  // (development A/B: the bitonic network for every genome)
-    if (getenv("KSSD_DEV_NO_DIRECT")) c->no_direct = true;  // (... the offsets + gather kernels instead of the look-back)
 #endif
     fx.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
     fx.lds_keys = np;
-    auto bsort_slots = [&](uint32_t key_slots) -> uint32_t {  // what fits beside the key array and the kernel's static LDS
-        if (!bsort) return 0u;
-        const uint32_t bs = key_slots < DEDUP_BSORT_MAX ? key_slots : DEDUP_BSORT_MAX;
-        return (size_t)key_slots * sizeof(K) + (size_t)bs * (sizeof(K) + 4) <= (size_t)144 * 1024 ? bs : 0u;
-    };
-    fx.bsort_keys = bsort_slots(np);
+    fx.bsort_keys = bsort ? (np < DEDUP_BSORT_MAX ? np : DEDUP_BSORT_MAX) : 0u;
     const size_t dlds = (size_t)np * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
     if (c->h_big.empty() && c->h_med.empty()) {
         // no genome needs staged tuples: exact stage and per-genome sort in one kernel, straight from the candidate list
@@ -1778,14 +1702,6 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         fx.carry = kssd_carry_ok(c->P) ? 1u : 0u;
         fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
         fx.lds_keys = np;
-        direct = !c->no_direct;
-        fx.direct = direct ? 1u : 0u;
-        fx.lb_state = c->d_lb_state;
-        fx.out_off = (unsigned long long *)d_out_off;
-        fx.out_ids = d_out_ids;
-        fx.out_pos = d_out_pos;
-        fx.out_cap = out_cap;
-        fx.n_genomes = n_genomes;
 #ifdef KSSD_DEV
         {
             static unsigned long long *d_dt = nullptr;
@@ -1815,7 +1731,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         px.cnt = c->d_med_cnt;
         px.part_cap = c->med_part_cap;
         px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
-        fx.bsort_keys = bsort_slots(px.part_cap);
+        fx.bsort_keys = bsort ? (px.part_cap < DEDUP_BSORT_MAX ? px.part_cap : DEDUP_BSORT_MAX) : 0u;
         const size_t plds = (size_t)px.part_cap * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_PARTS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(plds < 65536 ? 65536 : plds)));
@@ -1856,7 +1772,6 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
                                (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, region);
         }
     }
-    if (direct) return KSSD_OK;
     hipLaunchKernelGGL(sketch_offsets_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t *)c->d_kept, n_genomes,
                        (unsigned long long *)d_out_off, (unsigned long long)out_cap, c->d_status);
     hipLaunchKernelGGL((sketch_gather_kernel<K>), dim3(n_genomes, c->h_big.empty() ? (c->h_med.empty() ? 1u : 16u) : (n_genomes < 64u ? 256u : 16u)), dim3(256), 0, s,
@@ -1978,7 +1893,6 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     }
     if ((rc = ensure(&c->d_cursor, &c->cap_cursor, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_kept, &c->cap_kept, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
-    if ((rc = ensure(&c->d_lb_state, &c->cap_lb_state, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_regions, &c->cap_regions, ((size_t)acc + 1) * (with_pos ? 2 : 1))) != KSSD_OK) return rc;
     // candidate list between the scan and the exact stage: patterns of S (both strands) + Bloom false positives
     // (one private slice per wave of the scan grid)
@@ -2033,13 +1947,13 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
         if (parts > 1024) parts = 1024;
         hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64, (unsigned)(parts ? parts : 1)), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
-                           reinterpret_cast<uint32_t *>(c->d_status), c->d_lb_state);
+                           reinterpret_cast<uint32_t *>(c->d_status));
         HIPCK(hipGetLastError());
         return KSSD_OK;
     }
     hipLaunchKernelGGL(chunk_gid_kernel, dim3((unsigned)((init_n + 255) / 256)), dim3(256), 0, s,
                        (const uint64_t *)c->d_chunk_off, pl.n_genomes, pl.n_chunks, c->d_chunk_gid, c->d_cursor, c->d_cand_count,
-                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status), c->d_lb_state);
+                       pl.n_slices, reinterpret_cast<uint32_t *>(c->d_status));
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -2203,10 +2117,6 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
                 st.cand_need, (unsigned long long)c->last_cand_cap, st.region_overflow, st.max_need_q8 / 256.0, c->region_factor,
                 st.out_overflow, st.capacity_genome_p1);
 #endif
-    if (st.lookback_stuck) {  // (never seen; see DIRECT in sketch_dedup_kernel) -- the repeated call takes the offsets + gather kernels
-        c->no_direct = true;
-        return KSSD_ERR_OVERFLOW;
-    }
     if (st.cand_overflow) {
         c->cand_floor = (uint64_t)st.cand_need + st.cand_need / 4 + 64;
         return KSSD_ERR_OVERFLOW;
