@@ -234,7 +234,7 @@ int kssd_gpu_set_fastq_reads(kssd_gpu_ctx *ctx, int on);
  * of 19 000 bytes or more (the reference's fgets() buffer splits lines at 19 999), a NUL or a byte >= 0x80 -- is handed
  * back: kssd_gpu_tokenise_fastq_status / kssd_gpu_sketch_fastq_text return KSSD_ERR_UNSUPPORTED with its index, and the
  * caller runs libkssd_host.so's kssd_batch_add_fastq for it.  h_lines (HOST u64[n_files], may be NULL) receives the
- * line count the reference reports per file (4 x complete records).  -Q > 0 and dist -A stay on the host tokeniser.
+ * line count the reference reports per file (4 x complete records).  The quality floor and the dist -A framing: kssd_gpu_set_fastq_quality / kssd_gpu_set_fastq_reads above.
  */
 int kssd_gpu_tokenise_fastq_device(kssd_gpu_ctx *ctx, const uint8_t *d_text, const uint64_t *h_text_off, const uint64_t *h_text_len,
                                    uint32_t n_files, uint32_t *d_packed, uint32_t *d_mask, const uint64_t *h_chunk_off, void *stream);
@@ -242,6 +242,14 @@ int kssd_gpu_tokenise_fastq_status(kssd_gpu_ctx *ctx, int64_t *bad_file, uint64_
 int kssd_gpu_sketch_fastq_text(kssd_gpu_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_len,
                                uint32_t n_files, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
                                uint32_t **out_pos, uint64_t *h_lines, int64_t *bad_genome);
+/*
+ * dist --byread (reads2mco, iseq2comem.c:78-186): where the reads of FASTA file `file` of the batch this context tokenised
+ * LAST (kssd_gpu_sketch_fasta_text / kssd_gpu_tokenise_fasta_device, nothing tokenised in between) begin in the file's
+ * position stream -- at every '>' met outside a header the position the next base gets, exactly what libkssd_host.so's
+ * kssd_batch_add_fasta_reads returns.  read_start: malloc'd HOST u64[*n_reads], ascending (kssd_gpu_free).  Together with
+ * the KSSD_SKETCH_BY_POS stream of the same call this is all kssd_byread_write needs.
+ */
+int kssd_gpu_fasta_read_starts(kssd_gpu_ctx *ctx, uint32_t file, uint64_t **read_start, uint64_t *n_reads);
 /*
  * Streaming a long input in without a host buffer of its size: reserve the context's device text buffer (reserving more
  * later keeps what has been put: an input of unknown size -- a gzip'ed file -- starts from an estimate), copy

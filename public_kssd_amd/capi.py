@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts",
 ]
 
 
@@ -811,6 +811,16 @@ class GpuCtx:
     def set_fastq_quality(self, min_quality):
         """the quality floor (fastq2co -Q) of the following FASTQ text calls; 0 = none"""
         _gck(gpu_lib().kssd_gpu_set_fastq_quality(self.h, int(min_quality)))
+
+    def fasta_read_starts(self, file=0):
+        """read starts (u64 array) of FASTA file `file` of the batch tokenised last on this context (dist --byread)"""
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _gck(gpu_lib().kssd_gpu_fasta_read_starts(self.h, file, C.byref(p), C.byref(n)))
+        try:
+            return np.frombuffer((C.c_char * (8 * n.value)).from_address(p.value), dtype=np.uint64).copy() if n.value else np.zeros(0, np.uint64)
+        finally:
+            if p.value:
+                gpu_lib().kssd_gpu_free(p)
 
     def set_fastq_reads(self, on):
         """FASTQ text calls frame their input like dist -A (mt_shortreads2koc); what only the host does exactly is handed back"""

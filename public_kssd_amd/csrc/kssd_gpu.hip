@@ -159,6 +159,10 @@ struct kssd_gpu_ctx {
     unsigned long long *d_x_off = nullptr;  // kssd_gpu_allgather_sketches: the gathered units of every rank
     uint32_t *d_x_ids = nullptr;
     size_t cap_x_off = 0, cap_x_ids = 0;
+    void *tok_args_saved = nullptr;  // the tokeniser's kernel arguments of the last call (malloc; kssd_gpu_fasta_read_starts)
+    uint32_t *d_hdr_cnt = nullptr;
+    unsigned long long *d_hdr_pre = nullptr, *d_hdr_out = nullptr;
+    size_t cap_hdr_cnt = 0, cap_hdr_pre = 0, cap_hdr_out = 0;
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
     bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
     int *d_tok_q = nullptr;  // per tile: newlines around it (quality floor)
@@ -287,9 +291,10 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    free(c->tok_args_saved);
     for (hipEvent_t e : c->text_ev)
         if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -1688,7 +1693,12 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
 #endif
     fx.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
     fx.lds_keys = np;
-    fx.bsort_keys = bsort ? (np < DEDUP_BSORT_MAX ? np : DEDUP_BSORT_MAX) : 0u;
+    auto bsort_slots = [&](uint32_t key_slots) -> uint32_t {  // what fits beside the key array and the kernel's static LDS
+        if (!bsort) return 0u;
+        const uint32_t bs = key_slots < DEDUP_BSORT_MAX ? key_slots : DEDUP_BSORT_MAX;
+        return (size_t)key_slots * sizeof(K) + (size_t)bs * (sizeof(K) + 4) <= (size_t)144 * 1024 ? bs : 0u;
+    };
+    fx.bsort_keys = bsort_slots(np);
     const size_t dlds = (size_t)np * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
     if (c->h_big.empty() && c->h_med.empty()) {
         // no genome needs staged tuples: exact stage and per-genome sort in one kernel, straight from the candidate list
@@ -1731,7 +1741,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         px.cnt = c->d_med_cnt;
         px.part_cap = c->med_part_cap;
         px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
-        fx.bsort_keys = bsort ? (px.part_cap < DEDUP_BSORT_MAX ? px.part_cap : DEDUP_BSORT_MAX) : 0u;
+        fx.bsort_keys = bsort_slots(px.part_cap);
         const size_t plds = (size_t)px.part_cap * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_PARTS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(plds < 65536 ? 65536 : plds)));

@@ -702,35 +702,48 @@ static void sketch_files_byread(const dist_opt *o, filelist *fl, const char *out
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
     gck(kssd_gpu_create_compact(&g_ctx, &hdr, sc.accepted, sc.n_accepted, o->device), "kssd_gpu_create");
     free(sc.accepted);
+    /* the device tokenises the text and says where the reads begin (kssd_gpu_fasta_read_starts); KSSD_HOST_BYREAD=1 keeps the
+     * host scanner (kssd_batch_add_fasta_reads), the two are compared by tests/test_gpu_cli.py */
+    const int on_host = getenv("KSSD_HOST_BYREAD") != NULL;
     kssd_batch *b = kssd_batch_create();
+    unsigned char *txt = NULL;
+    size_t cap = 0;
     for (int i = 0; i < fl->n; i++) {
         printf("decomposing %s by reads\n", fl->path[i]);
-        unsigned char *txt = NULL;
         size_t len = 0;
-        int rc = kssd_slurp(fl->path[i], &txt, &len);
+        int rc = kssd_slurp_reuse(fl->path[i], &txt, &cap, &len);
         if (rc) die(EIO, "reads2mco():%s: %s", fl->path[i], kssd_host_strerror(rc));
+        if (len == 0) die(EIO, "reads2mco():eof or fread error file=%s", fl->path[i]);
         uint64_t *cuts = NULL, n_reads = 0;
-        rc = kssd_batch_add_fasta_reads(b, txt, len, &cuts, &n_reads);
-        free(txt);
-        if (rc == KSSD_HOST_ERR_EMPTY) die(EIO, "reads2mco():eof or fread error file=%s", fl->path[i]);
-        if (rc == KSSD_HOST_ERR_HEADER) die(EIO, "fasta2co(): can not find seqences head start from '>' 0");
-        if (rc) die(EIO, "%s: %s", fl->path[i], kssd_host_strerror(rc));
         uint64_t *off = NULL;
         uint32_t *ids = NULL, *pos = NULL;
         int64_t bad = -1;
-        gck(kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), 1, KSSD_SKETCH_BY_POS,
-                                      1u, &off, &ids, &pos, &bad),
-            "sketch (by read)");
+        if (on_host) {
+            rc = kssd_batch_add_fasta_reads(b, txt, len, &cuts, &n_reads);
+            if (rc == KSSD_HOST_ERR_HEADER) die(EIO, "fasta2co(): can not find seqences head start from '>' 0");
+            if (rc) die(EIO, "%s: %s", fl->path[i], kssd_host_strerror(rc));
+            gck(kssd_gpu_sketch_batch_pos(g_ctx, kssd_batch_packed(b), kssd_batch_mask(b), kssd_batch_chunk_off(b), 1, KSSD_SKETCH_BY_POS,
+                                          1u, &off, &ids, &pos, &bad),
+                "sketch (by read)");
+        } else {
+            const uint64_t t_off = 0, t_len = len;
+            rc = kssd_gpu_sketch_fasta_text(g_ctx, txt, &t_off, &t_len, 1, KSSD_SKETCH_BY_POS, 1u, &off, &ids, &pos, &bad);
+            if (rc == KSSD_ERR_INPUT) die(EIO, "fasta2co(): can not find seqences head start from '>' 0");
+            gck(rc, "sketch (by read)");
+            gck(kssd_gpu_fasta_read_starts(g_ctx, 0, &cuts, &n_reads), "read starts");
+        }
         rc = kssd_byread_write(outdir, (uint32_t)hdr.id, hdr.k, hdr.drlevel, (const char (*)[KSSD_PATHLEN])fl->path, (uint32_t)fl->n, ids,
                                pos, off[1], cuts, n_reads);
         if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
         kssd_gpu_free(off);
         kssd_gpu_free(ids);
         kssd_gpu_free(pos);
-        kssd_host_free(cuts);
+        if (on_host) kssd_host_free(cuts);
+        else kssd_gpu_free(cuts);
         kssd_batch_clear(b);
         printf("decomposing %s by reads is complete!\n", fl->path[i]);
     }
+    free(txt);
     kssd_batch_destroy(b);
     kssd_gpu_destroy(g_ctx);
     g_ctx = NULL;

@@ -1,4 +1,6 @@
 """-m gpu: inverted index + intersection + distances on the device against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -352,3 +354,36 @@ def test_in_process_exchange_over_rccl_with_one_rank(shuf_l3k10):
             K.GpuCtx.allgather_sketches([ctx, ctx], [d_off, d_off], [d_ids, d_ids], G, unit, [roff, roff], [rids, rids])
     finally:
         ctx.close()
+
+
+def test_sketch_gather_over_the_rccl_backend_with_one_rank(shuf_l3k10):
+    """torch.distributed's `nccl` backend IS RCCL on this box: the exchange code of the N-GPU bench (shard.SketchGather: two
+    all_gather_into_tensor + the unpacking kernel) run through it with a world of one -- the backend initialises, the
+    collectives run on device tensors, the CSR comes out.  (More ranks need more GPUs: the driver's scaling run.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from public_kssd_amd.shard import SketchGather
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        assert dist.get_backend() == "nccl"
+        rng = np.random.default_rng(9)
+        G, unit = 50, 4096
+        sizes = rng.integers(0, 80, G)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        ids = np.full(unit, -3, dtype=np.int32)
+        ids[:off[-1]] = rng.integers(0, 1 << 28, int(off[-1]))
+        g = SketchGather(1, G, unit, dev, ctx)
+        roff, rids = g(torch.from_numpy(off).to(dev), torch.from_numpy(ids).to(dev))
+        torch.cuda.synchronize()
+        assert np.array_equal(roff.cpu().numpy(), off) and np.array_equal(rids.cpu().numpy()[:off[-1]], ids[:off[-1]])
+    finally:
+        ctx.close()
+        dist.destroy_process_group()

@@ -400,3 +400,41 @@ def test_device_reads_framing_equals_the_host_tokeniser_and_the_oracle_counts(sh
             assert e.value.code == K.capi.ERR_UNSUPPORTED and e.value.bad_genome == 1
     finally:
         ctx.close()
+
+
+def test_device_read_starts_equal_the_host_scanner(shuf_l3k10):
+    """dist --byread: kssd_gpu_fasta_read_starts (positions of the reads of one file of the batch tokenised last) against
+    kssd_batch_add_fasta_reads on the same bytes -- headers across tile and thread borders, '>' inside a header and
+    mid-line, reads without bases, text before the first header, CRLF, several files in one batch; and the by-position
+    k-mer stream of the same call against the host-tokenised one"""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+
+    def rnd(n):
+        return bytes(acgt[rng.integers(0, 4, n, dtype=np.uint8)])
+    many = b"".join(b">r%d len\n" % i + rnd(int(rng.integers(0, 300))) + (b"\n" if i % 7 else b"\r\n") for i in range(20_000))
+    texts = [
+        _cases()[1],                                                                # edge.fa
+        many,
+        rnd(500) + b"\n>a\n>b>c\n" + rnd(40) + b">mid line\nNN" + rnd(30) + b"\n>empty\n>last\n" + rnd(9) + b"\n",
+        b">" + b"h" * 8190 + b"\n" + rnd(8192 - 3) + b"\n>" + b"x" * 4094 + b"\n" + rnd(1) + b"\n>z\n",   # markers on tile borders
+        b"".join(b">\n" + rnd(1) + b"\n" for _ in range(9000)),                       # one base per read
+        b">only\n",
+        b"ACGT\n",                                                                  # no read at all
+    ]
+    ctx, ctx2 = K.GpuCtx(shuf_l3k10, 0), K.GpuCtx(shuf_l3k10, 0)
+    try:
+        off, ids, pos = ctx.sketch_fasta_texts(texts, flags=K.SKETCH_BY_POS, with_pos=True)
+        for f, t in enumerate(texts):
+            hb = K.Batch()
+            want = hb.add_fasta_reads(t)
+            got = ctx.fasta_read_starts(f)
+            assert np.array_equal(got, want), (f, len(got), len(want))
+            h_off, h_ids, h_pos = ctx2.sketch_batch_pos(hb, K.SKETCH_BY_POS)
+            assert np.array_equal(ids[off[f]:off[f + 1]], h_ids) and np.array_equal(pos[off[f]:off[f + 1]], h_pos)
+        assert len(ctx.fasta_read_starts(1)) == 20_000 and len(ctx.fasta_read_starts(6)) == 0
+        with pytest.raises(K.KssdError):
+            ctx.fasta_read_starts(len(texts))
+    finally:
+        ctx.close()
+        ctx2.close()
