@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""development tool (GPU box): where dist_rows_kernel's time goes, per row, on the bench's batch (configs[1]).
+Needs the -DKSSD_DEV build (make -C public_kssd_amd tools); run as
+    KSSD_GPU_LIB=public_kssd_amd/libkssd_gpu_dev.so KSSD_DEV_DISTTIME=1 python3 profiles/dist_phases.py [genomes]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import public_kssd_amd as K
+from public_kssd_amd import capi
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+L = 5_000_000
+dev = torch.device("cuda", 0)
+shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
+packed, mask, chunk_off, _ = bench.make_batch(G, L, max(G // 20, 1), 20260101, dev)
+ctx = K.GpuCtx(shuf, 0)
+cap = int(G * L / 4096 * 1.25) + 4096
+off = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+shared = torch.zeros(G * G, dtype=torch.int32, device=dev)
+planes = [torch.zeros(G * G, dtype=torch.float64, device=dev) for _ in range(4)]
+for rep in range(4):
+    ctx.sketch_device(packed, mask, chunk_off, off, ids, cap)
+    ctx.index_build_device(off, ids, G, cap)
+    ctx.dist_device(off, ids, G, 0, G, shared, *planes)
+torch.cuda.synchronize()
+for which, name in ((1, "dist_rows"),):
+    print(name, "kernel_time", ctx.kernel_time(which, reset=True))
+ctx.kernel_time(1, reset=True)
+for rep in range(10):
+    ctx.dist_device(off, ids, G, 0, G, shared, *planes)
+torch.cuda.synchronize()
+print("dist_rows avg ms over 10 launches", ctx.kernel_time(1))
+lib = capi.gpu_lib()
+print("matrix checksum", int(shared.to(torch.int64).sum()), float(planes[1].sum()))
+if not hasattr(lib, "kssd_gpu_dev_disttimes") or not os.environ.get("KSSD_DEV_DISTTIME"):
+    sys.exit(0)
+t = np.zeros(G * 4, dtype=np.uint64)
+lib.kssd_gpu_dev_disttimes.argtypes = [C.c_void_p, C.c_uint32]
+rc = lib.kssd_gpu_dev_disttimes(t.ctypes.data, G)
+assert rc == 0, rc
+t = t.reshape(G, 4).astype(np.int64)
+d = np.diff(t, axis=1)
+tot = t[:, 3] - t[:, 0]
+for i, nm in enumerate(("start -> ids probed (first pass)", "postings counted (+ later passes)", "epilogue (metrics, 36 KB of stores)")):
+    v = np.sort(d[:, i])
+    print("  %-40s min %7d  median %7d  mean %9.0f  p90 %7d  max %7d ticks" % (nm, v[0], v[len(v) // 2], v.mean(), v[len(v) * 9 // 10], v[-1]))
+v = np.sort(tot)
+print("  %-40s min %7d  median %7d  mean %9.0f  p90 %7d  max %7d ticks" % ("whole workgroup", v[0], v[len(v) // 2], v.mean(), v[len(v) * 9 // 10], v[-1]))
+print("  (ticks: shader clock)")

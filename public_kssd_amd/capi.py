@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GPU_LIB = os.path.join(HERE, "libkssd_gpu.so")
+GPU_LIB = os.environ.get("KSSD_GPU_LIB", os.path.join(HERE, "libkssd_gpu.so"))  # (profiles/: the -DKSSD_DEV build with its time stamps)
 HOST_LIB = os.environ.get("KSSD_HOST_LIB", os.path.join(HERE, "libkssd_host.so"))  # (the sanitizer run points this at its own build)
 
 CHUNK_BASES = 4096
