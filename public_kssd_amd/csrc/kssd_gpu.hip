@@ -76,6 +76,8 @@ struct SketchStatus {
     unsigned long long n_stage1, n_bloom;
     unsigned int cand_overflow;    // a shard of the candidate list was too small
     unsigned int cand_need;        // entries the fullest shard wanted
+    unsigned int ranges_skew;      // a large genome's keys do not spread over its id ranges (one id tens of thousands of times, crafted
+                                   // ids): the call is repeated with the global-memory sort for large genomes
 };
 
 struct kssd_gpu_ctx {
@@ -163,6 +165,7 @@ struct kssd_gpu_ctx {
     uint32_t *d_hdr_cnt = nullptr;
     unsigned long long *d_hdr_pre = nullptr, *d_hdr_out = nullptr;
     size_t cap_hdr_cnt = 0, cap_hdr_pre = 0, cap_hdr_out = 0;
+    bool ranges_off = false; // a batch of this context has shown keys that do not spread over id ranges: large genomes take the global-memory sort
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
     bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
     int *d_tok_q = nullptr;  // per tile: newlines around it (quality floor)
@@ -1034,9 +1037,15 @@ __device__ __forceinline__ void sort_in_registers(K *a, const K *src /* may be a
 // runs as before.  Returns true with the sorted keys in b[0 .. n).
 #define DEDUP_BSORT_MAX 4096u     // key slots (= buckets) at most
 #define DEDUP_BSORT_BUCKET 24u    // a fuller bucket sends the genome to the bitonic sort
+// The ids lie in [id_base, id_base + 2^id_bits) (roughly: beyond it they share the last bucket).  max_bucket: a fuller bucket
+// sends the keys to the bitonic sort up front (DEDUP_BSORT_BUCKET for a genome's keys; none for an item of a large genome,
+// whose ids repeat by the read set's coverage -- equal keys cost an insertion sort nothing); a thread that has MOVED
+// DEDUP_BSORT_MOVES keys in its buckets gives up for the workgroup either way (src is untouched).
+#define DEDUP_BSORT_MOVES 256u
+#define DEDUP_BSORT_HEAVY 256u    // full buckets (more than 16 keys) a workgroup lists at most
 template <typename K>
-__device__ __forceinline__ bool lds_bucket_sort(const K *src, K *b, uint32_t *cnt, uint32_t n, uint32_t nb /*pow2*/, uint32_t id_bits, uint32_t tid,
-                                                uint32_t *wsum)
+__device__ __forceinline__ bool lds_bucket_sort(const K *src, K *b, uint32_t *cnt, uint32_t n, uint32_t nb /*pow2*/, uint32_t id_base, uint32_t id_bits,
+                                                uint32_t max_bucket, uint32_t tid, uint32_t *wsum)
 {
     uint32_t lg = 0;
     while ((1u << lg) < nb) lg++;
@@ -1044,7 +1053,7 @@ __device__ __forceinline__ bool lds_bucket_sort(const K *src, K *b, uint32_t *cn
     for (uint32_t i = tid; i < nb; i += DEDUP_THREADS) cnt[i] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += DEDUP_THREADS) {
-        const uint32_t bk = KeyOps<K>::id(src[i]) >> shift;
+        const uint32_t bk = (KeyOps<K>::id(src[i]) - id_base) >> shift;
         atomicAdd(&cnt[bk < last ? bk : last], 1u);
     }
     __syncthreads();
@@ -1068,27 +1077,94 @@ __device__ __forceinline__ bool lds_bucket_sort(const K *src, K *b, uint32_t *cn
         for (uint32_t w = 0; w < DEDUP_THREADS / 64; w++) mx_all = wsum[w] > mx_all ? wsum[w] : mx_all;
         __syncthreads();
     }
-    if (mx_all > DEDUP_BSORT_BUCKET) return false;
+    if (mx_all > max_bucket) return false;
     if (b0 < nb)
         for (uint32_t k = 0; k < per; k++) { const uint32_t c = cnt[b0 + k]; cnt[b0 + k] = run; run += c; }  // the bucket's first slot
     __syncthreads();
     for (uint32_t i = tid; i < n; i += DEDUP_THREADS) {
         const K kv = src[i];
-        const uint32_t bk = KeyOps<K>::id(kv) >> shift;
+        const uint32_t bk = (KeyOps<K>::id(kv) - id_base) >> shift;
         b[atomicAdd(&cnt[bk < last ? bk : last], 1u)] = kv;
     }
     __syncthreads();
+    // small buckets: an insertion sort by the thread that owns the bucket.  A full bucket is nearly always a few ids many
+    // times over (a read set's coverage): those go on a list and a whole wave takes each (below)
+    uint32_t moves = 0;
+    if (tid == 0) wsum[0] = 0;  // the list's length; the list itself: the scan's scratch words do not hold it -> the counters' tail
+    __syncthreads();
+    uint32_t *heavy = cnt + nb;  // [DEDUP_BSORT_HEAVY] bucket numbers (the caller's counter array has this room)
     for (uint32_t bk = tid; bk < nb; bk += DEDUP_THREADS) {  // (after the scatter cnt[bk] is the bucket's end = the next bucket's first slot)
         const uint32_t s0 = bk ? cnt[bk - 1] : 0u, e0 = cnt[bk];
-        for (uint32_t i = s0 + 1; i < e0; i++) {
+        if (e0 - s0 > 16u) {
+            const uint32_t at = atomicAdd(&wsum[0], 1u);
+            if (at < DEDUP_BSORT_HEAVY) heavy[at] = bk;
+            continue;
+        }
+        for (uint32_t i = s0 + 1; i < e0 && moves < DEDUP_BSORT_MOVES; i++) {
             const K x = b[i];
             uint32_t j = i;
-            while (j > s0 && b[j - 1] > x) { b[j] = b[j - 1]; j--; }
+            while (j > s0 && b[j - 1] > x) { b[j] = b[j - 1]; j--; moves++; }
             b[j] = x;
         }
     }
     __syncthreads();
-    return true;
+    const uint32_t n_heavy = wsum[0];
+    bool fail = moves >= DEDUP_BSORT_MOVES || n_heavy > DEDUP_BSORT_HEAVY;
+    if (!fail && n_heavy) {
+        // a wave per full bucket: its distinct ids (up to eight), how often each is there and the smallest key of each, then the
+        // bucket rewritten as runs in id order -- every run as copies of its SMALLEST key, which is all the keep rules look at
+        // (the run's first entry: the tuple's first position; the run's length)
+        const uint32_t lane = lane_id(), wave = tid >> 6;
+        for (uint32_t hi = wave; hi < n_heavy; hi += DEDUP_THREADS / 64) {
+            const uint32_t bk = heavy[hi];
+            const uint32_t s0 = bk ? cnt[bk - 1] : 0u, e0 = cnt[bk];
+            K mk[8];
+            uint32_t c[8], nd = 0;
+            bool many = false;
+#pragma unroll
+            for (uint32_t d = 0; d < 8; d++) { mk[d] = KeyOps<K>::pad(); c[d] = 0; }
+            for (uint32_t base = s0; base < e0 && !many; base += 64) {
+                const bool valid = base + lane < e0;
+                const K x = valid ? b[base + lane] : KeyOps<K>::pad();
+                uint64_t pending = __ballot(valid);
+                while (pending && !many) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(pending);
+                    const uint32_t idl = (uint32_t)__builtin_amdgcn_readlane((int)KeyOps<K>::id(x), (int)l);
+                    const bool same = valid && KeyOps<K>::id(x) == idl;
+                    const uint64_t sb = __ballot(same);
+                    K mn = same ? x : KeyOps<K>::pad();
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) { const K o = shfl_xor_key(mn, m); mn = o < mn ? o : mn; }
+                    const uint32_t add = (uint32_t)__builtin_popcountll(sb);
+                    bool found = false;
+#pragma unroll
+                    for (uint32_t d = 0; d < 8; d++)
+                        if (!found && d < nd && KeyOps<K>::id(mk[d]) == idl) { c[d] += add; mk[d] = mn < mk[d] ? mn : mk[d]; found = true; }
+                    if (!found) {
+                        if (nd == 8) many = true;
+#pragma unroll
+                        for (uint32_t d = 0; d < 8; d++)
+                            if (d == nd) { mk[d] = mn; c[d] = add; }
+                        nd++;
+                    }
+                    pending &= ~sb;
+                }
+            }
+            if (many) { fail = true; continue; }
+#pragma unroll
+            for (uint32_t r = 0; r < 7; r++)  // the (up to eight) runs by key; unused entries hold the pad key and stay behind
+#pragma unroll
+                for (uint32_t d = 0; d + 1 < 8; d++)
+                    if (mk[d + 1] < mk[d]) { const K tk = mk[d]; mk[d] = mk[d + 1]; mk[d + 1] = tk; const uint32_t tc = c[d]; c[d] = c[d + 1]; c[d + 1] = tc; }
+            uint32_t p = s0;
+#pragma unroll
+            for (uint32_t d = 0; d < 8; d++) {
+                for (uint32_t t = lane; t < c[d]; t += 64) b[p + t] = mk[d];
+                p += c[d];
+            }
+        }
+    }
+    return __syncthreads_or(fail) == 0;
 }
 
 // FUSED: the workgroup takes its genome's candidates straight from the scan's candidate list (the slices of the scan
@@ -1122,8 +1198,21 @@ struct PartArgs {
     uint32_t *cnt;       // [n_medium][1 << DEDUP_MAX_PARTS_LOG2][4]: kept, distinct, occurrences of id 0, overflowed
     uint32_t part_cap;   // keys one part may hold (the LDS array)
     uint32_t id_bits;    // ids are below 2^id_bits (a little above it where the rank is ADDED over the outer bases: clamped)
+    // RANGES (one large genome per launch, see big_rng_* below): the genome's keys partitioned by ranges of their leading
+    // field; workgroup k sorts the whole bins that begin inside [k RNG_T, (k+1) RNG_T) of the partitioned array, in place
+    const void *parted;        // partitioned keys (the sort's kept keys go back to the head of the item's span)
+    const uint32_t *bin_start; // [rng_bins + 1]
+    uint32_t *item_cnt;        // [items]: kept keys of the item
+    uint32_t *item_s0;         // [items]: where the item's span begins
+    const uint32_t *item_bin;  // [items + 1]: the item's first bin
+    uint32_t *acc;             // [2]: the genome's distinct tuples, occurrences of id 0
+    uint32_t rng_bins, rng_g;
 };
-enum { DEDUP_STAGED = 0, DEDUP_FUSED = 1, DEDUP_PARTS = 2 };
+enum { DEDUP_STAGED = 0, DEDUP_FUSED = 1, DEDUP_PARTS = 2, DEDUP_RANGES = 3 };
+#define RNG_T 1024u             // span of the partitioned array an item begins in
+#define RNG_BIN_MEAN 512u      // keys per bin aimed at
+#define RNG_MAX_LOG2_BINS 14u
+#define RNG_PART_CAP 4096u      // keys an item may hold (its LDS array): RNG_T + the largest bin, i.e. a bin six times the mean
 
 template <typename K, int MODE>
 __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
@@ -1140,7 +1229,9 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K *a = reinterpret_cast<K *>(smem);
     uint32_t g = blockIdx.x, part = 0, lg_parts = 0;
-    if (MODE == DEDUP_PARTS) {
+    if (MODE == DEDUP_RANGES) {
+        g = px.rng_g;
+    } else if (MODE == DEDUP_PARTS) {
         const uint2 md = px.list[blockIdx.x];
         g = md.x;
         lg_parts = md.y;
@@ -1156,7 +1247,44 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     const uint32_t cap = (uint32_t)(reg_off[g + 1] - r0);
     uint32_t *pcnt = MODE == DEDUP_PARTS ? px.cnt + ((size_t)blockIdx.x << (DEDUP_MAX_PARTS_LOG2 + 2)) + part * 4u : nullptr;
     uint32_t n;
-    if (MODE == DEDUP_PARTS) {
+    unsigned long long rng_s0 = 0;
+    uint32_t rng_id_base = 0, rng_id_bits = 0;  // the item's ids lie in [base, base + 2^bits)
+    if (MODE == DEDUP_RANGES) {
+        __shared__ uint32_t s_span[4];
+        const uint32_t staged = cursor[g];
+        if (staged > cap) return;  // (big_rng_hist_kernel has reported the overflow)
+        const unsigned long long lo = (unsigned long long)blockIdx.x * RNG_T;
+        if (tid == 0) {  // the bins whose first key lies in [lo, hi) (big_rng_binscan_kernel has looked them up)
+            const uint32_t b0 = px.item_bin[blockIdx.x], b1 = px.item_bin[blockIdx.x + 1];
+            s_span[0] = px.bin_start[b0];
+            s_span[1] = px.bin_start[b1];  // (bin_start[rng_bins] = all keys)
+            s_span[2] = b0;
+            s_span[3] = b1 > b0 ? b1 - b0 : 1u;
+        }
+        __syncthreads();
+        rng_s0 = s_span[0];
+        {
+            uint32_t lgb = 0;
+            while ((1u << lgb) < px.rng_bins) lgb++;
+            const uint32_t bin_shift = px.id_bits - lgb;  // (big_rng_hist_kernel's shift)
+            uint32_t wb = 0;
+            while ((1u << wb) < s_span[3]) wb++;
+            rng_id_base = s_span[2] << bin_shift;
+            rng_id_bits = wb + bin_shift;
+        }
+        n = lo < staged ? s_span[1] - s_span[0] : 0u;
+        if (n > px.part_cap) {  // the keys do not spread (or one id is there tens of thousands of times): the caller repeats with the global sort
+            if (tid == 0) atomicOr(&st->ranges_skew, 1u);
+            n = 0;
+        }
+        if (n == 0) {
+            if (tid == 0) { px.item_cnt[blockIdx.x] = 0; px.item_s0[blockIdx.x] = 0; }
+            return;
+        }
+        const K *src_g = reinterpret_cast<const K *>(px.parted) + rng_s0;
+        for (uint32_t i = tid; i < n; i += DEDUP_THREADS) a[i] = src_g[i];
+        __syncthreads();
+    } else if (MODE == DEDUP_PARTS) {
         __shared__ uint32_t s_np;
         const uint32_t lane = lane_id();
         if (tid == 0) s_np = 0;
@@ -1319,7 +1447,8 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     const K *src = MODE != DEDUP_STAGED ? a : regions + r0;
     K *outp = regions + r0;  // where the kept keys go
     if (MODE == DEDUP_PARTS) outp = reinterpret_cast<K *>(px.out) + (((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) + part) * px.part_cap;
-    if (MODE != DEDUP_PARTS && n > cap) {
+    if (MODE == DEDUP_RANGES) outp = reinterpret_cast<K *>(const_cast<void *>(px.parted)) + rng_s0;
+    if (MODE != DEDUP_PARTS && MODE != DEDUP_RANGES && n > cap) {
         if (tid == 0) {
             atomicOr(&st->region_overflow, 1u);
             unsigned long long need = ((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1);
@@ -1328,7 +1457,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         }
         return;
     }
-    if ((flags & SKETCH_TRACK_FILL) && tid == 0)  // only while the regions are oversized after an overflow (see sketch_status)
+    if (MODE != DEDUP_RANGES && (flags & SKETCH_TRACK_FILL) && tid == 0)  // only while the regions are oversized after an overflow (see sketch_status)
         atomicMax(&st->max_need_q8, (uint32_t)(((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1)));
     uint32_t np = 1;
     while (np < n) np <<= 1;
@@ -1336,10 +1465,11 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     // dynamic LDS: a[lds_keys] | b[bsort_keys] | counters[bsort_keys]  (lds_keys: the launch's array -- part_cap in PARTS mode)
     const K *sorted = a;
     bool bsorted = false;
-    if (fx.bsort_keys && n > 64 && np <= fx.bsort_keys) {
-        K *b = a + (MODE == DEDUP_PARTS ? px.part_cap : fx.lds_keys);
+    if (fx.bsort_keys && n > 64 && np <= fx.bsort_keys && !(MODE == DEDUP_RANGES && fx.by_pos)) {
+        K *b = a + (MODE == DEDUP_PARTS || MODE == DEDUP_RANGES ? px.part_cap : fx.lds_keys);
         uint32_t *bcnt = reinterpret_cast<uint32_t *>(b + fx.bsort_keys);
-        bsorted = lds_bucket_sort<K>(src, b, bcnt, n, np, fx.id_bits, tid, wsum);
+        if (MODE == DEDUP_RANGES) bsorted = lds_bucket_sort<K>(src, b, bcnt, n, np, rng_id_base, rng_id_bits, 0xFFFFFFFFu, tid, wsum);
+        else bsorted = lds_bucket_sort<K>(src, b, bcnt, n, np, 0u, fx.id_bits, DEDUP_BSORT_BUCKET, tid, wsum);
         if (bsorted) sorted = b;
     }
     if (bsorted) {
@@ -1409,7 +1539,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     }
     __syncthreads();
 #ifdef KSSD_DEV
-    if (FUSED && fx.dev_times && tid == 0) {
+    if ((FUSED || MODE == DEDUP_RANGES) && fx.dev_times && tid == 0 && blockIdx.x < 65536) {
         fx.dev_times[blockIdx.x * 4] = dev_t0;
         fx.dev_times[blockIdx.x * 4 + 1] = dev_t1;
         fx.dev_times[blockIdx.x * 4 + 2] = dev_t2;
@@ -1417,7 +1547,12 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     }
 #endif
     if (tid == 0) {
-        if (MODE == DEDUP_PARTS) {  // the genome's totals (and its capacity rule) are the finish kernel's
+        if (MODE == DEDUP_RANGES) {  // the genome's totals and its capacity rule: big_scan_kernel
+            px.item_cnt[blockIdx.x] = out_base;
+            px.item_s0[blockIdx.x] = (uint32_t)rng_s0;
+            if (s_distinct) atomicAdd(&px.acc[0], s_distinct);
+            if (s_zero_occ) atomicAdd(&px.acc[1], s_zero_occ);
+        } else if (MODE == DEDUP_PARTS) {  // the genome's totals (and its capacity rule) are the finish kernel's
             pcnt[0] = out_base;
             pcnt[1] = s_distinct;
             pcnt[2] = s_zero_occ;
@@ -1562,6 +1697,155 @@ __global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const K *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// kernel 2c: a large genome sorted in LDS after all (RANGES) -- the way read sets, chromosomes and --byread files take.
+// The staged keys are partitioned by ranges of their leading field (id: its top bits are the canonical k-mer's outermost
+// bases; --byread: the position), RNG_BIN_MEAN keys per bin on average:
+//   big_rng_hist     every workgroup counts its share of the region per bin in LDS and writes its row of counts
+//   big_rng_colscan  per bin: exclusive prefix over the workgroups' rows (where a workgroup's keys of the bin go), bin totals
+//   big_rng_binscan  one workgroup: bin starts
+//   big_rng_scatter  the same shares again: keys to their places (LDS cursors, no global atomic anywhere)
+//   sketch_dedup_kernel<K, RANGES>  item k = the whole bins that begin in [k RNG_T, (k+1) RNG_T): LDS sort, keep rules, in place
+//   big_scan_kernel  the items' kept counts -> offsets, the genome's total and capacity rule
+//   big_rng_copy     the items' kept keys, one behind the other (the bins are ordered ranges: ascending), into the region
+// Seven short launches (~50 us at 3.7 M staged keys) where the device radix sort of the whole region took four passes over
+// all keys (0.2 ms).  Keys that do not spread -- ONE id tens of thousands of times (an amplicon, a spike-in), crafted ids --
+// overflow an item's LDS array: the status says so (ranges_skew) and the repeated call sorts in global memory as before.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rng_bin(uint32_t lead, uint32_t shift, uint32_t last)
+{
+    const uint32_t b = lead >> shift;
+    return b < last ? b : last;
+}
+__device__ __forceinline__ void rng_share(unsigned long long n, unsigned long long &lo, unsigned long long &hi)
+{
+    const unsigned long long per = (((n + gridDim.x - 1) / gridDim.x) + 1023ull) & ~1023ull;
+    lo = (unsigned long long)blockIdx.x * per;
+    hi = lo + per < n ? lo + per : n;
+    if (lo > n) lo = n;
+}
+
+template <typename K>
+__global__ __launch_bounds__(1024) void big_rng_hist_kernel(const K *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
+                                                            uint32_t *__restrict__ kept_g, uint32_t *__restrict__ acc, SketchStatus *st,
+                                                            uint32_t nb, uint32_t shift, uint32_t *__restrict__ wg_hist /*[gridDim.x][nb]*/)
+{
+    extern __shared__ uint32_t rng_h[];
+    const unsigned long long n = *cursor_g;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        acc[0] = acc[1] = 0;
+        const unsigned long long need = (n * 256ull + cap - 1) / (cap ? cap : 1);
+        atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
+        if (n > cap) {
+            atomicOr(&st->region_overflow, 1u);
+            *kept_g = 0;
+        }
+    }
+    if (n > cap) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) rng_h[b] = 0;
+    __syncthreads();
+    unsigned long long lo, hi;
+    rng_share(n, lo, hi);
+    for (unsigned long long i0 = lo + threadIdx.x; i0 < hi; i0 += 4ull * blockDim.x) {
+        K kv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) kv[j] = i0 + (unsigned long long)j * blockDim.x < hi ? region[i0 + (unsigned long long)j * blockDim.x] : (K)0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (i0 + (unsigned long long)j * blockDim.x < hi) atomicAdd(&rng_h[rng_bin(KeyOps<K>::id(kv[j]), shift, nb - 1u)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) wg_hist[(size_t)blockIdx.x * nb + b] = rng_h[b];
+}
+
+__global__ __launch_bounds__(256) void big_rng_colscan_kernel(unsigned long long cap, const uint32_t *__restrict__ cursor_g, uint32_t nb, uint32_t rows,
+                                                               uint32_t *__restrict__ wg_hist, uint32_t *__restrict__ bin_tot)
+{
+    if (*cursor_g > cap) return;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t run = 0;
+    for (uint32_t w0 = 0; w0 < rows; w0 += 8) {  // eight rows' counts in flight
+        uint32_t t[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) t[j] = w0 + j < rows ? wg_hist[(size_t)(w0 + j) * nb + b] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            if (w0 + j < rows) wg_hist[(size_t)(w0 + j) * nb + b] = run;
+            run += t[j];
+        }
+    }
+    bin_tot[b] = run;
+}
+
+__global__ __launch_bounds__(DEDUP_THREADS) void big_rng_binscan_kernel(unsigned long long cap, const uint32_t *__restrict__ cursor_g, uint32_t nb,
+                                                                         const uint32_t *__restrict__ bin_tot, uint32_t *__restrict__ bin_start /*nb+1*/,
+                                                                         uint32_t *__restrict__ item_bin /*n_items+1*/, uint32_t n_items)
+{
+    extern __shared__ uint32_t rng_h[];  // nb + 1 bin starts
+    __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
+    if (*cursor_g > cap) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += DEDUP_THREADS) rng_h[b] = bin_tot[b];  // coalesced in, scanned in LDS, coalesced out
+    __syncthreads();
+    // tiles of DEDUP_THREADS consecutive bins, one per thread (a thread that walks its own run of the array meets every other
+    // lane of its wave in one LDS bank)
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < nb; t0 += DEDUP_THREADS) {
+        const uint32_t b = t0 + threadIdx.x;
+        const uint32_t v = b < nb ? rng_h[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, wsum, total);
+        if (b < nb) rng_h[b] = carry + ex;
+        carry += total;
+    }
+    const uint32_t total = carry;
+    if (threadIdx.x == 0) rng_h[nb] = total;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b <= nb; b += DEDUP_THREADS) bin_start[b] = rng_h[b];
+    // item k = the whole bins that begin in [k RNG_T, (k+1) RNG_T): item_bin[k] = the first bin whose start is >= k RNG_T
+    // (bin b is that bin for every k with start[b-1] < k RNG_T <= start[b]); beyond the last bin: nb
+    for (uint32_t b = threadIdx.x; b <= nb; b += DEDUP_THREADS) {
+        const uint32_t s1 = rng_h[b];
+        uint32_t k0 = b ? rng_h[b - 1] / RNG_T + 1u : 0u;  // first k with k RNG_T > start[b-1]
+        for (uint32_t k = k0; k <= n_items && (unsigned long long)k * RNG_T <= s1; k++) item_bin[k] = b;
+    }
+    for (uint32_t k = total / RNG_T + 1u + threadIdx.x; k <= n_items; k += DEDUP_THREADS) item_bin[k] = nb;
+}
+
+template <typename K>
+__global__ __launch_bounds__(1024) void big_rng_scatter_kernel(const K *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
+                                                               uint32_t nb, uint32_t shift, const uint32_t *__restrict__ wg_hist,
+                                                               const uint32_t *__restrict__ bin_start, K *__restrict__ parted)
+{
+    extern __shared__ uint32_t rng_h[];
+    const unsigned long long n = *cursor_g;
+    if (n > cap) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) rng_h[b] = bin_start[b] + wg_hist[(size_t)blockIdx.x * nb + b];
+    __syncthreads();
+    unsigned long long lo, hi;
+    rng_share(n, lo, hi);
+    for (unsigned long long i0 = lo + threadIdx.x; i0 < hi; i0 += 4ull * blockDim.x) {
+        K kv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) kv[j] = i0 + (unsigned long long)j * blockDim.x < hi ? region[i0 + (unsigned long long)j * blockDim.x] : (K)0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (i0 + (unsigned long long)j * blockDim.x < hi) parted[atomicAdd(&rng_h[rng_bin(KeyOps<K>::id(kv[j]), shift, nb - 1u)], 1u)] = kv[j];
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void big_rng_copy_kernel(unsigned long long cap, const uint32_t *__restrict__ cursor_g, const K *__restrict__ parted,
+                                                            const uint32_t *__restrict__ item_off /*scanned*/, const uint32_t *__restrict__ item_s0,
+                                                            uint32_t n_items, const uint32_t *__restrict__ kept_g, K *__restrict__ region)
+{
+    if (*cursor_g > cap) return;
+    const uint32_t k = blockIdx.x;
+    const uint32_t o0 = item_off[k], o1 = k + 1 < n_items ? item_off[k + 1] : *kept_g;
+    const K *src = parted + item_s0[k];
+    for (uint32_t i = threadIdx.x; i < o1 - o0; i += blockDim.x) region[o0 + i] = src[i];
+}
+
 // one workgroup: exclusive scan of the tile counts, kept[g], the capacity rule (iseq2comem.c:261-263)
 __global__ __launch_bounds__(1024) void big_scan_kernel(uint32_t *__restrict__ tile_cnt, uint32_t n_tiles, const uint32_t *__restrict__ acc,
                                                          uint32_t hashlimit, uint32_t flags, uint32_t g, unsigned long long cap,
@@ -1662,6 +1946,14 @@ static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t
 
 #ifdef KSSD_DEV
 static unsigned long long *g_dev_dedup_times;
+static unsigned long long *dev_dedup_times()
+{
+    if (!g_dev_dedup_times && getenv("KSSD_DEV_DEDUPTIME")) {
+        hipMalloc(&g_dev_dedup_times, 65536 * 4 * 8);
+        hipMemset(g_dev_dedup_times, 0, 65536 * 4 * 8);
+    }
+    return g_dev_dedup_times;
+}
 extern "C" int kssd_gpu_dev_deduptimes(unsigned long long *out, uint32_t n_genomes)
 {
     if (!g_dev_dedup_times) return KSSD_ERR_PARAM;
@@ -1696,10 +1988,10 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     auto bsort_slots = [&](uint32_t key_slots) -> uint32_t {  // what fits beside the key array and the kernel's static LDS
         if (!bsort) return 0u;
         const uint32_t bs = key_slots < DEDUP_BSORT_MAX ? key_slots : DEDUP_BSORT_MAX;
-        return (size_t)key_slots * sizeof(K) + (size_t)bs * (sizeof(K) + 4) <= (size_t)144 * 1024 ? bs : 0u;
+        return (size_t)key_slots * sizeof(K) + (size_t)bs * (sizeof(K) + 4) + DEDUP_BSORT_HEAVY * 4 <= (size_t)144 * 1024 ? bs : 0u;
     };
     fx.bsort_keys = bsort_slots(np);
-    const size_t dlds = (size_t)np * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
+    const size_t dlds = (size_t)np * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4) + (fx.bsort_keys ? DEDUP_BSORT_HEAVY * 4 : 0);
     if (c->h_big.empty() && c->h_med.empty()) {
         // no genome needs staged tuples: exact stage and per-genome sort in one kernel, straight from the candidate list
         const auto &pl = c->plan;
@@ -1713,12 +2005,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
         fx.lds_keys = np;
 #ifdef KSSD_DEV
-        {
-            static unsigned long long *d_dt = nullptr;
-            if (!d_dt && getenv("KSSD_DEV_DEDUPTIME")) hipMalloc(&d_dt, 65536 * 4 * 8);
-            fx.dev_times = n_genomes <= 65536 ? d_dt : nullptr;
-            g_dev_dedup_times = fx.dev_times;
-        }
+        fx.dev_times = n_genomes <= 65536 ? dev_dedup_times() : nullptr;
 #endif
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
@@ -1742,7 +2029,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         px.part_cap = c->med_part_cap;
         px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
         fx.bsort_keys = bsort_slots(px.part_cap);
-        const size_t plds = (size_t)px.part_cap * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4);
+        const size_t plds = (size_t)px.part_cap * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4) + (fx.bsort_keys ? DEDUP_BSORT_HEAVY * 4 : 0);
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_PARTS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(plds < 65536 ? 65536 : plds)));
         hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_PARTS>), dim3((unsigned)c->h_med.size(), 1u << lg_max), dim3(DEDUP_THREADS), plds, s, c->P,
@@ -1752,24 +2039,88 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
                            (const unsigned long long *)c->d_reg_off, regions, c->d_kept, flags, c->d_status, px);
     }
     if (!c->h_big.empty()) {
-        const size_t n_tiles_max = (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
         const size_t kw = sizeof(K) / 4;  // u32 words per key
-        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, (size_t)max_big * kw + n_tiles_max + 8)) != KSSD_OK) return rc;
-        size_t tmp_bytes = 0;
-        HIPCK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (K *)nullptr, (K *)nullptr, (size_t)max_big, 0u, (unsigned)(8 * sizeof(K)), s));
-        if (tmp_bytes > c->cap_big_tmp) {
-            if (c->d_big_tmp) hipFree(c->d_big_tmp);
-            c->d_big_tmp = nullptr;
-            c->cap_big_tmp = 0;
-            if (hipMalloc(&c->d_big_tmp, tmp_bytes) != hipSuccess) return KSSD_ERR_NOMEM;
-            c->cap_big_tmp = tmp_bytes;
+        // RANGES (kernel 2c) unless an earlier attempt of this context has met keys that do not spread, or the genome is beyond
+        // what 2^RNG_MAX_LOG2_BINS bins of twice the mean hold (hundreds of millions of staged keys)
+        const bool ranges = !c->ranges_off && max_big <= ((uint64_t)(2 * RNG_BIN_MEAN) << RNG_MAX_LOG2_BINS);
+        const size_t n_tiles_max = ranges ? (size_t)(max_big / RNG_T + 2) : (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
+        const size_t rng_words = ranges ? 2 * n_tiles_max + 2 + 2 * ((size_t)1 << RNG_MAX_LOG2_BINS) + 2 + (size_t)256 * ((size_t)1 << RNG_MAX_LOG2_BINS) : 0;
+        // keys (sort output | partitioned keys) | item / tile counts | 8 accumulator words | RANGES: item starts, bin totals, bin starts, rows of counts
+        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, (size_t)max_big * kw + n_tiles_max + 8 + rng_words)) != KSSD_OK) return rc;
+        if (!ranges) {
+            size_t tmp_bytes = 0;
+            HIPCK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (K *)nullptr, (K *)nullptr, (size_t)max_big, 0u, (unsigned)(8 * sizeof(K)), s));
+            if (tmp_bytes > c->cap_big_tmp) {
+                if (c->d_big_tmp) hipFree(c->d_big_tmp);
+                c->d_big_tmp = nullptr;
+                c->cap_big_tmp = 0;
+                if (hipMalloc(&c->d_big_tmp, tmp_bytes) != hipSuccess) return KSSD_ERR_NOMEM;
+                c->cap_big_tmp = tmp_bytes;
+            }
         }
         for (uint32_t g : c->h_big) {
             const uint64_t r0 = c->h_reg_off[g], cap = c->h_reg_off[g + 1] - r0;
-            const uint32_t n_tiles = (uint32_t)((cap + BIG_TILE - 1) / BIG_TILE);
             K *region = regions + r0, *sorted = reinterpret_cast<K *>(c->d_big_alt);
             uint32_t *tile_cnt = c->d_big_alt + (size_t)max_big * kw, *accum = tile_cnt + n_tiles_max;
             const uint32_t *cur = c->d_cursor + g;
+            if (ranges) {
+                // the keys' leading field: the id, or (--byread) the position inside the genome
+                uint32_t lead_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
+                if (c->plan.flags & KSSD_SKETCH_BY_POS) {
+                    const uint64_t positions = (c->h_chunk_off[g + 1] - c->h_chunk_off[g]) * KSSD_CHUNK;
+                    lead_bits = 1;
+                    while (lead_bits < 32 && (1ull << lead_bits) < positions) lead_bits++;
+                }
+                uint32_t lg = 4;
+                while (lg < RNG_MAX_LOG2_BINS && ((uint64_t)RNG_BIN_MEAN << lg) < cap) lg++;
+                if (lg > lead_bits) lg = lead_bits;
+                const uint32_t nb = 1u << lg, shift = lead_bits - lg;
+                uint64_t rows64 = cap / 16384ull;  // a workgroup's share: at least 16 384 keys
+                const uint32_t rows = (uint32_t)(rows64 < 1 ? 1 : rows64 > 256 ? 256 : rows64);
+                const uint32_t n_items = (uint32_t)(cap / RNG_T + 2);
+                uint32_t *item_s0 = accum + 8, *item_bin = item_s0 + n_tiles_max, *bin_tot = item_bin + n_tiles_max + 2,
+                         *bin_start = bin_tot + ((size_t)1 << RNG_MAX_LOG2_BINS), *wg_hist = bin_start + ((size_t)1 << RNG_MAX_LOG2_BINS) + 2;
+                hipLaunchKernelGGL((big_rng_hist_kernel<K>), dim3(rows), dim3(1024), (size_t)nb * 4, s, (const K *)region, (unsigned long long)cap, cur,
+                                   c->d_kept + g, accum, c->d_status, nb, shift, wg_hist);
+                hipLaunchKernelGGL(big_rng_colscan_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, (unsigned long long)cap, cur, nb, rows, wg_hist, bin_tot);
+                if ((size_t)(nb + 1) * 4 > 65536)
+                    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(big_rng_binscan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)((nb + 1) * 4)));
+                hipLaunchKernelGGL(big_rng_binscan_kernel, dim3(1), dim3(DEDUP_THREADS), (size_t)(nb + 1) * 4, s, (unsigned long long)cap, cur, nb,
+                                   (const uint32_t *)bin_tot, bin_start, item_bin, n_items);
+                hipLaunchKernelGGL((big_rng_scatter_kernel<K>), dim3(rows), dim3(1024), (size_t)nb * 4, s, (const K *)region, (unsigned long long)cap, cur,
+                                   nb, shift, (const uint32_t *)wg_hist, (const uint32_t *)bin_start, sorted);
+                PartArgs rx = px;
+                rx.parted = sorted;
+                rx.bin_start = bin_start;
+                rx.item_cnt = tile_cnt;
+                rx.item_s0 = item_s0;
+                rx.item_bin = item_bin;
+                rx.acc = accum;
+                rx.rng_bins = nb;
+                rx.rng_g = g;
+                rx.part_cap = RNG_PART_CAP;
+                rx.id_bits = lead_bits;
+                FuseArgs rf = fx;
+                rf.id_bits = lead_bits;
+                rf.lds_keys = RNG_PART_CAP;
+                rf.bsort_keys = bsort_slots(RNG_PART_CAP);
+#ifdef KSSD_DEV
+                rf.dev_times = dev_dedup_times();  // (per item here)
+#endif
+                const size_t rlds = (size_t)RNG_PART_CAP * sizeof(K) + (size_t)rf.bsort_keys * (sizeof(K) + 4) + (rf.bsort_keys ? DEDUP_BSORT_HEAVY * 4 : 0);
+                HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_RANGES>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(rlds < 65536 ? 65536 : rlds)));
+                hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_RANGES>), dim3(n_items), dim3(DEDUP_THREADS), rlds, s, c->P,
+                                   (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
+                                   flags, min_occ, big_min, c->d_status, rf, rx);
+                hipLaunchKernelGGL(big_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_items, (const uint32_t *)accum, c->P.hashlimit,
+                                   flags, g, (unsigned long long)cap, cur, c->d_kept + g, c->d_status);
+                hipLaunchKernelGGL((big_rng_copy_kernel<K>), dim3(n_items), dim3(256), 0, s, (unsigned long long)cap, cur, (const K *)sorted,
+                                   (const uint32_t *)tile_cnt, (const uint32_t *)item_s0, n_items, (const uint32_t *)(c->d_kept + g), region);
+                continue;
+            }
+            const uint32_t n_tiles = (uint32_t)((cap + BIG_TILE - 1) / BIG_TILE);
             hipLaunchKernelGGL((big_pad_kernel<K>), dim3(1024), dim3(256), 0, s, region, (unsigned long long)cap, cur, c->d_kept + g, accum,
                                c->d_status);
             size_t tb = c->cap_big_tmp;
@@ -2129,6 +2480,10 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
 #endif
     if (st.cand_overflow) {
         c->cand_floor = (uint64_t)st.cand_need + st.cand_need / 4 + 64;
+        return KSSD_ERR_OVERFLOW;
+    }
+    if (st.ranges_skew && !st.region_overflow) {
+        c->ranges_off = true;
         return KSSD_ERR_OVERFLOW;
     }
     if (st.region_overflow) {

@@ -531,3 +531,69 @@ def test_genomes_sorted_in_lds_in_parts(shuf_l3k10):
     finally:
         ctx.set_lds_sort_limit(0)
         ctx.close()
+
+
+def test_large_genomes_sorted_by_ranges_of_their_keys():
+    """genomes beyond sixteen LDS sorts (read sets, chromosomes, --byread files): staged keys partitioned by ranges of their
+    leading field and sorted in LDS (DEDUP_RANGES, big_rng_* kernels) -- ids, minimum occurrence, first positions -> the
+    reference's file order, occurrence counts, the by-position stream; and keys that do NOT spread (one unit 8 000 times:
+    a handful of ids, each thousands of times) overflow an item, the status says so, and the repeated call sorts in global
+    memory.  -k 8 -s 5 -l 2 samples every 256th position and kssd_gpu_set_lds_sort_limit(1024) makes 12 Mb large."""
+    rng = np.random.default_rng(2048)
+    shuf = K.Shuf.generate(8, 5, 2, seed=5)
+    sk = ko.Sketcher(shuf.table, 8, 5, 2)
+    hashsize = K.derive(8, 5, 2).hashsize
+    big = rng.integers(0, 4, 12_000_000, dtype=np.uint8)
+    nm = np.zeros(len(big), dtype=bool)
+    nm[rng.integers(0, len(big), 300)] = True
+    part = rng.integers(0, 4, 2_500_000, dtype=np.uint8)
+    six = np.concatenate([part[o:] for o in (0, 11, 5, 300, 7, 2)] + [rng.integers(0, 4, 1_000_000, dtype=np.uint8)])
+    unit = rng.integers(0, 4, 2_000, dtype=np.uint8)
+    texts = [fasta_text(big, b"big", n_mask=nm), fasta_text(rng.integers(0, 4, 100_000, dtype=np.uint8), b"small"), b">empty\n",
+             fasta_text(six, b"six copies")]
+    heavy = fasta_text(np.tile(unit, 8_000), b"one unit 8000 times")
+    del big, nm, six
+    ctx, plain = K.GpuCtx(shuf, 0), K.GpuCtx(shuf, 0)
+    try:
+        ctx.set_lds_sort_limit(1024)
+        b = K.Batch()
+        for t in texts:
+            b.add_fasta(t)
+        F = K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY
+        want = [np.sort(sk.fasta(t)) for t in texts]
+        assert len(want[0]) > 16 * 1024
+        off, ids = ctx.sketch_batch(b, F)
+        for g in range(len(texts)):
+            assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want[g]), g
+        off, ids, pos = ctx.sketch_batch_pos(b, F | K.SKETCH_FIRST_POS)
+        for g in (0, 3):
+            lo, hi = int(off[g]), int(off[g + 1])
+            assert np.array_equal(K.slot_order_pos(ids[lo:hi], pos[lo:hi], hashsize), sk.fasta(texts[g])), g    # the reference's file order
+        off_c, ids_c, cnt_c = ctx.sketch_batch_pos(b, F | K.SKETCH_COUNTS)
+        off_p, ids_p, cnt_p = plain.sketch_batch_pos(b, F | K.SKETCH_COUNTS)
+        assert np.array_equal(off_c, off_p) and np.array_equal(ids_c, ids_p) and np.array_equal(cnt_c, cnt_p)
+        assert np.array_equal(ids_c, ids) and cnt_c[int(off_c[3]):int(off_c[4])].max() >= 6
+        for M in (2, 6, 7):
+            off_m, ids_m = ctx.sketch_batch(b, F | K.SKETCH_KEEP_ZERO, min_occ=M)
+            keep = cnt_c >= M
+            per_genome = [int(keep[int(off_c[g]):int(off_c[g + 1])].sum()) for g in range(len(texts))]
+            assert np.array_equal(ids_m, ids_c[keep]) and np.array_equal(np.diff(off_m.astype(np.int64)), per_genome), M
+        off_b, ids_b, pos_b = ctx.sketch_batch_pos(b, K.SKETCH_BY_POS)
+        off_q, ids_q, pos_q = plain.sketch_batch_pos(b, K.SKETCH_BY_POS)
+        assert np.array_equal(off_b, off_q) and np.array_equal(ids_b, ids_q) and np.array_equal(pos_b, pos_q)
+        assert (np.diff(pos_b[int(off_b[0]):int(off_b[1])].astype(np.int64)) > 0).all() and off_b[1] > 16 * 1024
+        b.close()
+        # keys that do not spread
+        hb = K.Batch()
+        hb.add_fasta(heavy)
+        hb.add_fasta(texts[1])
+        w = np.sort(sk.fasta(heavy))
+        off, ids, cnt = ctx.sketch_batch_pos(hb, F | K.SKETCH_COUNTS)
+        assert np.array_equal(ids[:int(off[1])], w) and cnt[:int(off[1])].max() >= 7_999 and len(w) < 64
+        assert np.array_equal(ids[int(off[1]):], want[1])
+        off, ids = ctx.sketch_batch(hb, F)                      # (the context remembers: global-memory sort at once)
+        assert np.array_equal(ids[:int(off[1])], w)
+        hb.close()
+    finally:
+        ctx.close()
+        plain.close()
