@@ -19,8 +19,9 @@ rx='sketch_scan_kernel|sketch_exact_kernel'
 {
 profiles/pmc_pass.sh ${tag}_sq1 "$rx" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 profiles/pmc_pass.sh ${tag}_sq2 "$rx" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE
-profiles/pmc_pass.sh ${tag}_fetch "$rx" FETCH_SIZE
-profiles/pmc_pass.sh ${tag}_write "$rx" WRITE_SIZE
+rx2='sketch_scan_kernel|sketch_dedup_kernel|idx_|dist_rows_kernel'
+profiles/pmc_pass.sh ${tag}_fetch "$rx2" FETCH_SIZE
+profiles/pmc_pass.sh ${tag}_write "$rx2" WRITE_SIZE
 echo "--- FETCH_SIZE calibration: every calib_read* launch reads exactly 2^30 bytes (profiles/scanbench calib)"
 SB_ARGS=calib profiles/pmc_sb.sh ${tag}_calib FETCH_SIZE
 } > gpurun_out/${tag}_pmc_scan.txt 2>&1

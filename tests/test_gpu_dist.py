@@ -1,5 +1,6 @@
 """-m gpu: inverted index + intersection + distances on the device against the CPU oracle."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -205,7 +206,7 @@ def _sketchset(names, off, ids, kmerlen=20, dim_rd_len=6):
 def test_report_selection_on_the_device_leaves_the_same_text(gpu_ctx, tmp_path, opts):
     """kssd_gpu_dist_select + kssd_distance_print_pairs against the dense report (whose text the golden tests pin to the
     reference's): byte-identical distance.out for -N, -D, --correction, both metrics, and far fewer pairs formatted"""
-    rng = np.random.default_rng(hash(str(sorted(opts.items()))) % (2 ** 32))
+    rng = np.random.default_rng(zlib.crc32(str(sorted(opts.items())).encode()))   # (hash() of a str differs from process to process)
     roff, rids = random_sketches(rng, 60, 800, 1300, 1 << 28, clades=6)
     qoff, qids = random_sketches(rng, 25, 0, 1200, 1 << 28, clades=6)
     n = len(qids) // 3
