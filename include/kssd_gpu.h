@@ -122,6 +122,7 @@ int kssd_gpu_sketch_device(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const ui
 #define KSSD_PHASE_SCAN 1   /* the scan kernel: every CU's LDS                             */
 #define KSSD_PHASE_EXACT 2  /* exact evaluation of the candidates: no LDS, random HBM reads */
 #define KSSD_PHASE_FINISH 3 /* per-genome dedup (LDS sort), CSR offsets, gather            */
+#define KSSD_PHASE_REPASS 4 /* instead of PREP + SCAN: the next tuple pass over the candidates of the last scan (below) */
 int kssd_gpu_sketch_plan(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
                          const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
                          uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap);
@@ -165,6 +166,21 @@ int kssd_gpu_warm_up(int device);
  * The results do not depend on it; the parity tests use it to send small genomes down the large-genome path.
  */
 int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *ctx, uint32_t max_tuples);
+
+/*
+ * Parameter sets with k - drlevel = 9 (e.g. -k 12 -L 3): the reduced tuple has 36 bits; the reference spreads it over
+ * 16^(k - drlevel - 7) = 256 component files of 28-bit ids (iseq2comem.c:63-64,527,542-543; hash table: 4 GiB per thread).
+ * The device keeps its 32-bit ids and works in kssd_gpu_tuple_passes() = 16 passes over the candidates of ONE scan: pass s
+ * keeps the tuples whose low four bits are s, the id it writes is tuple >> 4.  Component file of such an id:
+ * ((id & 15) << 4) | s, stored id: id >> 4; the id 0 rule applies to pass 0 alone; the capacity rule (hashlimit of distinct
+ * tuples per genome) is per pass on the device -- the caller adds the passes' sketch sizes up.
+ *   kssd_gpu_set_tuple_pass(ctx, 0); kssd_gpu_sketch_plan(..out buffers of pass 0..); phases PREP, SCAN, EXACT, FINISH
+ *   for s = 1 .. 15: kssd_gpu_set_tuple_pass(ctx, s); kssd_gpu_sketch_plan(..same batch, out buffers of pass s..);
+ *                    phases REPASS, EXACT, FINISH
+ * Every other parameter set has one pass and nothing changes (kssd_gpu_tuple_passes() = 1).
+ */
+uint32_t kssd_gpu_tuple_passes(const kssd_gpu_ctx *ctx);
+int kssd_gpu_set_tuple_pass(kssd_gpu_ctx *ctx, uint32_t pass);
 
 /*
  * Tuning knob of the scan: at most max_workgroups workgroups of 16 waves (0 = default, one per compute unit).  Every wave

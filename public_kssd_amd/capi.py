@@ -28,7 +28,7 @@ SKETCH_NO_CAPACITY = 4
 SKETCH_FIRST_POS = 8
 SKETCH_COUNTS = 16
 SKETCH_BY_POS = 32
-PHASE_PREP, PHASE_SCAN, PHASE_EXACT, PHASE_FINISH = 0, 1, 2, 3
+PHASE_PREP, PHASE_SCAN, PHASE_EXACT, PHASE_FINISH, PHASE_REPASS = 0, 1, 2, 3, 4
 
 OK, ERR_HIP, ERR_PARAM, ERR_CAPACITY, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_NOMEM, ERR_NO_DEVICE, ERR_INPUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts", "kssd_gpu_tuple_passes", "kssd_gpu_set_tuple_pass",
 ]
 
 
@@ -68,7 +68,7 @@ class GpuInfo(C.Structure):
 class _SketchSet(C.Structure):
     _fields_ = [("shuf_id", C.c_uint32), ("koc", C.c_int), ("kmerlen", C.c_int), ("dim_rd_len", C.c_int),
                 ("comp_num", C.c_int), ("n", C.c_uint32), ("off", C.c_void_p), ("ids", C.c_void_p),
-                ("names", C.c_void_p), ("counts", C.c_void_p)]
+                ("names", C.c_void_p), ("counts", C.c_void_p), ("sub", C.c_void_p)]
 
 
 class _PrintOpt(C.Structure):
@@ -200,6 +200,8 @@ def host_lib():
         L.kssd_derive.argtypes = [C.POINTER(_Derived), i32, i32, i32]
         L.kssd_sketchset_release.argtypes = [C.POINTER(_SketchSet)]
         L.kssd_sketchset_release.restype = None
+        L.kssd_slot_order_pos64.argtypes = [vp, vp, u64, u32]
+        L.kssd_slot_order_pos64.restype = None
         L.kssd_slot_order.argtypes = [vp, u64, u32]
         L.kssd_slot_order.restype = None
         L.kssd_slot_order_pos.argtypes = [vp, vp, u64, u32]
@@ -280,6 +282,14 @@ class Shuf:
 # ------------------------------------------------------------------------------------------------------
 # on-disk sketch / index formats and the distance report (host C, kssd_formats.c)
 # ------------------------------------------------------------------------------------------------------
+def slot_order_pos64(tuples, first_pos, hashsize):
+    """tuples of more than 32 bits (k - drlevel = 9) in the reference's file order (kssd_slot_order_pos64)"""
+    t = np.ascontiguousarray(tuples, dtype=np.uint64).copy()
+    p = np.ascontiguousarray(first_pos, dtype=np.uint32)
+    host_lib().kssd_slot_order_pos64(t.ctypes.data, p.ctypes.data, len(t), hashsize)
+    return t
+
+
 def derive(k, subk, drlevel):
     d = _Derived()
     _hck(host_lib().kssd_derive(C.byref(d), k, subk, drlevel))
@@ -289,8 +299,10 @@ def derive(k, subk, drlevel):
 class SketchSet:
     """Sketches of n genomes: CSR of full reduced tuples + the header fields of cofiles.stat."""
 
-    def __init__(self, shuf_id, kmerlen, dim_rd_len, comp_num, names, off, ids, counts=None):
+    def __init__(self, shuf_id, kmerlen, dim_rd_len, comp_num, names, off, ids, counts=None, sub=None):
         self.shuf_id, self.kmerlen, self.dim_rd_len, self.comp_num = shuf_id, kmerlen, dim_rd_len, comp_num
+        # k - drlevel = 9 (256 components): the tuples' low four bits, ids = tuple >> 4 (write only)
+        self.sub = None if sub is None else np.ascontiguousarray(sub, dtype=np.uint8).copy()
         self.names = list(names)
         self.off = np.ascontiguousarray(off, dtype=np.uint64)
         self.ids = np.ascontiguousarray(ids, dtype=np.uint32).copy()
@@ -309,7 +321,8 @@ class SketchSet:
         self._cnt = (self.counts if len(self.counts) else np.zeros(1, np.uint16)) if koc else None
         return _SketchSet(self.shuf_id, int(koc), self.kmerlen, self.dim_rd_len, self.comp_num, len(self.names),
                           self.off.ctypes.data, self._ids.ctypes.data, C.addressof(self._nmbuf),
-                          self._cnt.ctypes.data if koc else None)
+                          self._cnt.ctypes.data if koc else None,
+                          (self.sub if len(self.sub) else np.zeros(1, np.uint8)).ctypes.data if self.sub is not None else None)
 
     @classmethod
     def _from_c(cls, s):
@@ -825,6 +838,14 @@ class GpuCtx:
     def set_fastq_reads(self, on):
         """FASTQ text calls frame their input like dist -A (mt_shortreads2koc); what only the host does exactly is handed back"""
         _gck(gpu_lib().kssd_gpu_set_fastq_reads(self.h, int(bool(on))))
+
+    def tuple_passes(self):
+        """1, or 16 for k - drlevel = 9 (36-bit tuples: pass s keeps the tuples with low bits s, its ids are tuple >> 4)"""
+        gpu_lib().kssd_gpu_tuple_passes.restype = C.c_uint32
+        return int(gpu_lib().kssd_gpu_tuple_passes(self.h))
+
+    def set_tuple_pass(self, s):
+        _gck(gpu_lib().kssd_gpu_set_tuple_pass(self.h, int(s)))
 
     def set_scan_grid(self, max_workgroups):
         """at most this many scan workgroups (0 = one per CU): longer chunk runs per wave; results unchanged"""

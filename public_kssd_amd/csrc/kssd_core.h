@@ -35,6 +35,11 @@ struct KssdParams {
     uint32_t g_log2;   // exact table G: 2^g_log2 buckets of two slots
     uint32_t g_mul[2]; // their multiplicative hashes (chosen by kssd_build_tables)
     uint64_t dim_mask; // 4*subk ones
+    // k - drlevel = 9: the reduced tuple has 36 bits (the reference splits it over 256 component files of 28-bit ids,
+    // iseq2comem.c:63-64,527,542-543).  The device works in 2^pass_bits = 16 passes over the candidates of ONE scan: pass s
+    // keeps the tuples whose low four bits are s and calls tuple >> 4 their id -- 32 bits, like the sixteen components of
+    // k - drlevel = 8.  Component file of an id of pass s: ((id & 15) << 4) | s, stored id: id >> 4.
+    uint32_t pass_bits, pass;
 };
 
 // hash-table sizes of the reference, only used for the capacity rule (global_basic.c:74-81)
@@ -51,7 +56,9 @@ static inline int kssd_params_init(KssdParams *p, int k, int subk, int drlevel)
     int pidx = 4 * (k - drlevel) - KSSD_CTX_SPC_USE_L - 7;                        // command_dist.c:220
     if (pidx < 0 || pidx > 24) return -1;
     if (subk < 2) return -2;                       // group filter needs >= 4 bases of sub-context
-    if (4 * (k - drlevel) > 32) return -2;         // reduced tuple must fit the u32 the formats store
+    if (4 * (k - drlevel) > 36) return -2;         // (never: the table sizes above end at k - drlevel = 9)
+    p->pass_bits = 4 * (k - drlevel) > 32 ? (uint32_t)(4 * (k - drlevel) - 32) : 0u;  // ids are 32 bits: the rest names the pass
+    p->pass = 0;
     if (subk < drlevel) return -1;
     p->k = k; p->subk = subk; p->drlevel = drlevel;
     p->out = k - subk;
@@ -376,11 +383,24 @@ KSSD_HD uint64_t kssd_carry_fwd(const KssdParams &P, uint64_t payload40)
 }
 
 // reduced tuple (iseq2comem.c:250-253): outer bases packed above the rank, literally as the reference adds them
-KSSD_HD uint32_t kssd_s2_tuple(const KssdParams &P, uint64_t u, uint32_t rank)
+KSSD_HD uint64_t kssd_s2_tuple64(const KssdParams &P, uint64_t u, uint32_t rank)
 {
     const uint64_t upper = u & (((1ull << (2 * P.out)) - 1ull) << (2 * (P.k + P.subk)));
     const uint64_t lower = u & ((1ull << (2 * P.out)) - 1ull);
-    return (uint32_t)(((upper + (lower << (2 * P.nb - 4 * P.out))) >> (4 * P.drlevel)) + rank);
+    return ((upper + (lower << (2 * P.nb - 4 * P.out))) >> (4 * P.drlevel)) + rank;
+}
+// the id the sketch stores (the whole tuple up to 32 bits; tuple >> pass_bits beyond), and whether the tuple belongs to
+// the pass the parameters name
+KSSD_HD uint32_t kssd_s2_tuple(const KssdParams &P, uint64_t u, uint32_t rank, bool &mine)
+{
+    const uint64_t dr = kssd_s2_tuple64(P, u, rank);
+    mine = (dr & ((1ull << P.pass_bits) - 1ull)) == P.pass;
+    return (uint32_t)(dr >> P.pass_bits);
+}
+KSSD_HD uint32_t kssd_s2_tuple(const KssdParams &P, uint64_t u, uint32_t rank)
+{
+    bool mine;
+    return kssd_s2_tuple(P, u, rank, mine);
 }
 
 // Stage 2 in one piece: exact evaluation of the k-mer whose sub-context starts at global position s.

@@ -854,9 +854,10 @@ __global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams 
         uint32_t rank = 0;
         int hit = kssd_g_match(gb[j], dim[j], rank);
         if (hit == 2) hit = kssd_g_match(GB[kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)], dim[j], rank) == 1 ? 1 : 0;  // (1.4 % of the buckets)
-        ok[j] = ok[j] && valid[j] && hit == 1 && b0 >= (long long)glo[j] && b0 + P.nb <= (long long)ghi[j];
+        bool mine;
+        dr[j] = kssd_s2_tuple(P, u[j], rank, mine);
+        ok[j] = ok[j] && valid[j] && hit == 1 && mine && b0 >= (long long)glo[j] && b0 + P.nb <= (long long)ghi[j];
         gpos[j] = (uint32_t)(s - (long long)glo[j]);  // first-position mode: genomes are < 2^32 positions there (checked on the host)
-        dr[j] = kssd_s2_tuple(P, u[j], rank);
     }
     // Survivors go to their genome's staging region.  Candidates arrive in stream order, so a wave's survivors almost
     // always belong to ONE genome, and so do the workgroup's: then ONE returning atomic reserves room for all of them.
@@ -1420,14 +1421,15 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                     uint32_t rank = 0;
                     int hit = kssd_g_match(gb[j], dim[j], rank);
                     if (hit == 2) hit = kssd_g_match(GB[kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)], dim[j], rank) == 1 ? 1 : 0;
-                    ok[j] = ok[j] && hit == 1;
+                    bool mine;
+                    const uint32_t dr = kssd_s2_tuple(P, u[j], rank, mine);
+                    ok[j] = ok[j] && hit == 1 && mine;
                     const uint64_t bal = __ballot(ok[j]);
                     if (bal) {  // one LDS atomic per wave reserves room for its survivors
                         uint32_t at = 0;
                         if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__builtin_popcountll(bal));
                         at = __builtin_amdgcn_readfirstlane(at) + rank_in(bal);
                         if (ok[j] && at < fx.lds_keys) {
-                            const uint32_t dr = kssd_s2_tuple(P, u[j], rank);
                             const uint32_t gpos = (uint32_t)((long long)cd[j].x - glo);
                             a[at] = fx.by_pos ? KeyOps<K>::make(gpos, dr) : KeyOps<K>::make(dr, gpos);
                         }
@@ -1983,7 +1985,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
 #ifdef KSSD_DEV
     if (getenv("KSSD_DEV_NO_BUCKET_SORT")) bsort = false;  // (development A/B: the bitonic network for every genome)
 #endif
-    fx.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
+    fx.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel)) - c->P.pass_bits;
     fx.lds_keys = np;
     auto bsort_slots = [&](uint32_t key_slots) -> uint32_t {  // what fits beside the key array and the kernel's static LDS
         if (!bsort) return 0u;
@@ -2027,7 +2029,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         px.out = c->d_med_out;
         px.cnt = c->d_med_cnt;
         px.part_cap = c->med_part_cap;
-        px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
+        px.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel)) - c->P.pass_bits;
         fx.bsort_keys = bsort_slots(px.part_cap);
         const size_t plds = (size_t)px.part_cap * sizeof(K) + (size_t)fx.bsort_keys * (sizeof(K) + 4) + (fx.bsort_keys ? DEDUP_BSORT_HEAVY * 4 : 0);
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_PARTS>),
@@ -2065,7 +2067,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
             const uint32_t *cur = c->d_cursor + g;
             if (ranges) {
                 // the keys' leading field: the id, or (--byread) the position inside the genome
-                uint32_t lead_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel));
+                uint32_t lead_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel)) - c->P.pass_bits;
                 if (c->plan.flags & KSSD_SKETCH_BY_POS) {
                     const uint64_t positions = (c->h_chunk_off[g + 1] - c->h_chunk_off[g]) * KSSD_CHUNK;
                     lead_bits = 1;
@@ -2173,6 +2175,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
         flags |= KSSD_SKETCH_KEEP_ZERO | KSSD_SKETCH_NO_CAPACITY;
         min_occ = 1;
     }
+    if (c->P.pass) flags |= KSSD_SKETCH_KEEP_ZERO;  // id 0 of pass s is the tuple s, not the tuple 0 the reference never stores
     if (with_pos && !c->d_out_pos) return KSSD_ERR_PARAM;  // kssd_gpu_sketch_set_pos_output first
     const uint64_t n_chunks = h_chunk_off[n_genomes];
     auto &pl = c->plan;
@@ -2414,6 +2417,21 @@ static int phase_finish(kssd_gpu_ctx *c, hipStream_t s)
     return KSSD_OK;
 }
 
+// the per-call state a further tuple pass starts from: cursors and the status words of the stages behind the scan
+__global__ void repass_reset_kernel(uint32_t *__restrict__ cursor, uint32_t n_genomes, SketchStatus *st)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_genomes) cursor[i] = 0;
+    if (i == 0) {
+        st->total_ids = 0;
+        st->region_overflow = 0;
+        st->out_overflow = 0;
+        st->max_need_q8 = 0;
+        st->capacity_genome_p1 = 0;
+        st->ranges_skew = 0;
+    }
+}
+
 extern "C" int kssd_gpu_sketch_phase(kssd_gpu_ctx *c, int phase, void *stream)
 {
     if (!c || !c->plan.valid) return KSSD_ERR_PARAM;
@@ -2424,6 +2442,11 @@ extern "C" int kssd_gpu_sketch_phase(kssd_gpu_ctx *c, int phase, void *stream)
     case KSSD_PHASE_SCAN: return phase_scan(c, s);
     case KSSD_PHASE_EXACT: return phase_exact(c, s);
     case KSSD_PHASE_FINISH: return phase_finish(c, s);
+    case KSSD_PHASE_REPASS:
+        if (c->plan.n_genomes)
+            hipLaunchKernelGGL(repass_reset_kernel, dim3((c->plan.n_genomes + 255) / 256), dim3(256), 0, s, c->d_cursor, c->plan.n_genomes, c->d_status);
+        HIPCK(hipGetLastError());
+        return KSSD_OK;
     default: return KSSD_ERR_PARAM;
     }
 }
@@ -2448,6 +2471,15 @@ extern "C" int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *c, uint32_t max_tuples)
 {
     if (!c) return KSSD_ERR_PARAM;
     c->lds_sort_limit = max_tuples;
+    return KSSD_OK;
+}
+
+// k - drlevel = 9 (36-bit tuples): which of the 2^4 passes the following sketch calls make (kssd_core.h KssdParams::pass_bits)
+extern "C" uint32_t kssd_gpu_tuple_passes(const kssd_gpu_ctx *c) { return c ? 1u << c->P.pass_bits : 0u; }
+extern "C" int kssd_gpu_set_tuple_pass(kssd_gpu_ctx *c, uint32_t pass)
+{
+    if (!c || pass >= (1u << c->P.pass_bits)) return KSSD_ERR_PARAM;
+    c->P.pass = pass;
     return KSSD_OK;
 }
 

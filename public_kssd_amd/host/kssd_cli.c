@@ -292,6 +292,7 @@ typedef struct job {
     uint64_t *off;    /* n_files + 1 */
     uint32_t *ids;    /* slot order per genome */
     uint16_t *counts; /* -A */
+    uint8_t *sub;     /* k - drlevel = 9: the tuples' low four bits (ids = tuple >> 4) */
     struct job *next;
 } job;
 
@@ -464,6 +465,9 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     uint64_t *off = NULL;
     uint32_t *ids = NULL, *pos = NULL;
     int64_t bad = -1;
+    const uint32_t passes = kssd_gpu_tuple_passes(ctx);
+    if (passes > 1 && (o->u || o->abundance || (is_fq && (o->kmerocrs > 1 || o->kmerqlty > 127))))
+        die(ENOTSUP, "-u, -A, -n > 1 with k - drlevel = 9 (36-bit tuples, 256 components) are not built");
     if (j->streamed && !j->uploaded) { /* the text's length (a gzip'ed input: only known now) decides what follows */
         const double tu0 = now_s();
         j->tlen[0] = j->streamed == 2 ? stream_gz_in(ctx, ring, fl->path[j->first_file], j->tlen[0])
@@ -486,6 +490,10 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     if (replay_all) {
         flags &= ~KSSD_SKETCH_UNIQ;
         min_occ = 1;
+    }
+    if (passes > 1) {
+        if (!with_pos) die(ENOTSUP, "genomes of 2^32 positions and more with k - drlevel = 9 are not built");
+        gck(kssd_gpu_set_tuple_pass(ctx, 0), "kssd_gpu_set_tuple_pass");
     }
     int rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &off, &ids, with_pos ? &pos : NULL, &bad);
     if (rc == KSSD_ERR_UNSUPPORTED && (j->tx || j->streamed) && is_fq) {
@@ -523,6 +531,61 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
+    if (passes > 1) {
+        /* 36-bit tuples: the passes 1 .. 15 over the same job (pass s: the tuples with low bits s, ids = tuple >> 4), then
+         * every genome's tuples of all passes in the reference's file order (its ONE table holds the whole tuples) */
+        uint64_t *poff[16] = {off};
+        uint32_t *pids[16] = {ids}, *ppos[16] = {pos};
+        for (uint32_t sp = 1; sp < passes; sp++) {
+            gck(kssd_gpu_set_tuple_pass(ctx, sp), "kssd_gpu_set_tuple_pass");
+            rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &poff[sp], &pids[sp], &ppos[sp], &bad);
+            if (rc == KSSD_ERR_CAPACITY)
+                die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
+            gck(rc, "sketch (tuple pass)");
+        }
+        gck(kssd_gpu_set_tuple_pass(ctx, 0), "kssd_gpu_set_tuple_pass");
+        uint64_t *moff = calloc((size_t)n + 1, sizeof *moff);
+        if (!moff) die(ENOMEM, "out of memory");
+        for (uint32_t g = 0; g < n; g++) {
+            uint64_t m = 0;
+            for (uint32_t sp = 0; sp < passes; sp++) m += poff[sp][g + 1] - poff[sp][g];
+            moff[g + 1] = moff[g] + m;
+            if (!is_fq && m > (uint64_t)(hashsize * 0.6)) /* keycount > hashlimit over the whole table (iseq2comem.c:261-263; LD_FCTR) */
+                die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + g], o->k + 1);
+        }
+        uint32_t *mids = malloc((size_t)(moff[n] ? moff[n] : 1) * 4);
+        uint8_t *msub = malloc((size_t)(moff[n] ? moff[n] : 1));
+        if (!mids || !msub) die(ENOMEM, "out of memory");
+#pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 16)
+        for (uint32_t g = 0; g < n; g++) {
+            const uint64_t m = moff[g + 1] - moff[g];
+            uint64_t *t = malloc((size_t)(m ? m : 1) * 8);
+            uint32_t *p = malloc((size_t)(m ? m : 1) * 4);
+            uint64_t w = 0;
+            for (uint32_t sp = 0; sp < passes; sp++)
+                for (uint64_t i = poff[sp][g]; i < poff[sp][g + 1]; i++) {
+                    t[w] = ((uint64_t)pids[sp][i] << 4) | sp;
+                    p[w++] = ppos[sp][i];
+                }
+            kssd_slot_order_pos64(t, p, m, hashsize);
+            for (uint64_t i = 0; i < m; i++) {
+                mids[moff[g] + i] = (uint32_t)(t[i] >> 4);
+                msub[moff[g] + i] = (uint8_t)(t[i] & 15u);
+            }
+            free(t);
+            free(p);
+        }
+        for (uint32_t sp = 0; sp < passes; sp++) {
+            kssd_gpu_free(poff[sp]);
+            kssd_gpu_free(pids[sp]);
+            kssd_gpu_free(ppos[sp]);
+        }
+        *t_call += now_s() - tc0;
+        j->off = moff;
+        j->ids = mids;
+        j->sub = msub;
+        return;
+    }
     if (replay_all) {
         uint64_t *coff = NULL;
         uint32_t *cids = NULL, *ccnt = NULL;
@@ -992,7 +1055,8 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     s.off = calloc((size_t)fl->n + 1, sizeof(uint64_t));
     s.ids = malloc((size_t)(total ? total : 1) * 4);
     s.counts = o->abundance ? malloc((size_t)(total ? total : 1) * 2) : NULL;
-    if (!s.off || !s.ids || (o->abundance && !s.counts)) die(ENOMEM, "out of memory");
+    s.sub = (nj && jl[0]->sub) ? malloc((size_t)(total ? total : 1)) : NULL; /* k - drlevel = 9 */
+    if (!s.off || !s.ids || (o->abundance && !s.counts) || (nj && jl[0]->sub && !s.sub)) die(ENOMEM, "out of memory");
     uint64_t at = 0;
     for (int i = 0; i < nj; i++) {
         job *j = jl[i];
@@ -1000,10 +1064,12 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         for (int g = 0; g < j->n_files; g++) s.off[j->first_file + g + 1] = at + j->off[g + 1];
         memcpy(s.ids + at, j->ids, (size_t)m * 4);
         if (o->abundance) memcpy(s.counts + at, j->counts, (size_t)m * 2);
+        if (s.sub) memcpy(s.sub + at, j->sub, (size_t)m);
         at += m;
         kssd_gpu_free(j->off);
         kssd_gpu_free(j->ids);
         free(j->counts);
+        free(j->sub);
         free(j);
     }
     free(jl);
@@ -1027,6 +1093,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     free(s.off);
     free(s.ids);
     free(s.counts);
+    free(s.sub);
     if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
         fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
                         "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "

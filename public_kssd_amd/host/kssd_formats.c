@@ -123,6 +123,64 @@ static uint64_t slot_order_replay_keep(uint32_t *ids, const uint8_t *keep, uint6
     return m;
 }
 
+typedef struct {
+    uint32_t pos;
+    uint64_t key;
+} pos_key;
+typedef struct {
+    uint32_t slot;
+    uint64_t key;
+} slot_key;
+static int cmp_pos_key(const void *a, const void *b)
+{
+    uint32_t x = ((const pos_key *)a)->pos, y = ((const pos_key *)b)->pos;
+    return x < y ? -1 : x > y;
+}
+static int cmp_slot_key(const void *a, const void *b)
+{
+    uint32_t x = ((const slot_key *)a)->slot, y = ((const slot_key *)b)->slot;
+    return x < y ? -1 : x > y;
+}
+
+/* tuples beyond 32 bits: the same replay (insertions in sequence order into a sparse image of the reference's table) */
+void kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t n, uint32_t hashsize)
+{
+    if (n < 2) return;
+    pos_key *pk = malloc(n * sizeof *pk);
+    slot_key *sl = malloc(n * sizeof *sl);
+    uint64_t cap = 16;
+    while (cap < 4 * n) cap <<= 1;
+    uint32_t *occ = malloc(cap * sizeof(uint32_t));
+    if (!pk || !sl || !occ) { free(pk); free(sl); free(occ); return; }
+    for (uint64_t i = 0; i < n; i++) { pk[i].pos = first_pos[i]; pk[i].key = tuples[i]; }
+    qsort(pk, n, sizeof *pk, cmp_pos_key);
+    memset(occ, 0xFF, cap * sizeof(uint32_t));
+    const uint64_t S = hashsize;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t key = pk[i].key, h1 = key % S, h2 = 1 + key % (S - 1); /* global_basic.h:228-230 */
+        for (uint64_t t = 0;; t++) {
+            const uint32_t slot = (uint32_t)((h1 + t * h2) % S);
+            uint64_t p = ((uint64_t)slot * 0x9E3779B97F4A7C15ull) >> 32 & (cap - 1);
+            int taken = 0;
+            while (occ[p] != 0xFFFFFFFFu) {
+                if (occ[p] == slot) { taken = 1; break; }
+                p = (p + 1) & (cap - 1);
+            }
+            if (!taken) {
+                occ[p] = slot;
+                sl[i].slot = slot;
+                sl[i].key = key;
+                break;
+            }
+        }
+    }
+    qsort(sl, n, sizeof *sl, cmp_slot_key);
+    for (uint64_t i = 0; i < n; i++) tuples[i] = sl[i].key;
+    free(pk);
+    free(sl);
+    free(occ);
+}
+
 void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
 {
     if (n < 2) return;
@@ -253,6 +311,7 @@ static int read_stat(kssd_sketchset *s, const char *dir, int mco, uint32_t **siz
         s->kmerlen = v[0]; s->dim_rd_len = v[1]; s->comp_num = v[2]; s->n = (uint32_t)v[3];
     }
     if (!ok || s->comp_num < 1 || s->comp_num > 65536) { fclose(f); return KSSD_HOST_ERR_FORMAT; }
+    if (s->comp_num > 16) { fclose(f); return KSSD_HOST_ERR_WIDE; } /* stored id (28 bits) + component: more than the 32 bits the sets hold */
     {   /* n comes from the file: it must agree with the file's size before anything is sized by it */
         struct stat st;
         const size_t hdr = mco ? 20 : 32;
@@ -290,6 +349,7 @@ static int comp_bits_of(int comp_num)
 int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hashsize, int slot_order)
 {
     mkdir(dir, 0777);
+    if (s->sub && (slot_order || s->koc || s->comp_num != 256)) return KSSD_HOST_ERR_PARAM; /* 36-bit tuples: in file order already */
     if (slot_order)
         for (uint32_t g = 0; g < s->n; g++) {
             const uint64_t n = s->off[g + 1] - s->off[g];
@@ -330,7 +390,13 @@ int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hash
                 if (fa) fwrite(s->counts + s->off[g], 2, cnt, fa);
                 run += cnt;
             } else {
-                for (uint64_t i = s->off[g]; i < s->off[g + 1]; i++)
+                for (uint64_t i = s->off[g]; s->sub && i < s->off[g + 1]; i++) /* the tuple is ids[i] << 4 | sub[i] */
+                    if (((((s->ids[i] & 15u) << 4) | s->sub[i]) & cmask) == (uint32_t)c) {
+                        uint32_t id = s->ids[i] >> (cb - 4);
+                        fwrite(&id, 4, 1, f);
+                        run++;
+                    }
+                for (uint64_t i = s->off[g]; !s->sub && i < s->off[g + 1]; i++)
                     if ((s->ids[i] & cmask) == (uint32_t)c) { /* drtuple % component_num, iseq2comem.c:543 */
                         uint32_t id = s->ids[i] >> cb;
                         fwrite(&id, 4, 1, f);

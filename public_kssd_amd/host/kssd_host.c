@@ -31,6 +31,9 @@ const char *kssd_host_strerror(int code)
     case KSSD_HOST_ERR_EMPTY: return "eof or fread error";
     case KSSD_HOST_ERR_NOMEM: return "out of memory";
     case KSSD_HOST_ERR_FORMAT: return "malformed file";
+    case KSSD_HOST_ERR_WIDE:
+        return "sketches of 36-bit tuples (k - drlevel = 9, 256 components) can be written but not indexed or searched: the reference's own "
+               "index builder does not survive them either (tests/golden/make_golden_k12.py)";
     default: return "unknown kssd_host error";
     }
 }

@@ -21,6 +21,7 @@ extern "C" {
 #define KSSD_HOST_ERR_EMPTY (-104)  /* no input bytes, iseq2comem.c:201-202 */
 #define KSSD_HOST_ERR_NOMEM (-105)
 #define KSSD_HOST_ERR_FORMAT (-106)
+#define KSSD_HOST_ERR_WIDE (-107)   /* a sketch directory of 36-bit tuples (256 components): only written, never read back (see kssd_sketchset.sub) */
 
 #define KSSD_PATHLEN 256 /* PATHLEN, global_basic.h:40: name records in cofiles.stat */
 
@@ -114,6 +115,9 @@ typedef struct kssd_sketchset {
     uint32_t *ids;           /* FULL reduced tuples (component folded back in), genome after genome */
     char (*names)[KSSD_PATHLEN];
     uint16_t *counts;        /* koc != 0: occurrences of ids[i], saturated at 65535 (write_fqkoc2files, iseq2comem.c:435-471); else NULL */
+    uint8_t *sub;            /* k - drlevel = 9 (36-bit tuples, 256 components): the tuple's low four bits, ids[i] = tuple >> 4 (the device's
+                              * passes, include/kssd_gpu.h kssd_gpu_set_tuple_pass); NULL for every other parameter set.  Only the writer
+                              * knows it: the reference's own index builder does not survive 256 components (tests/golden/make_golden_k12.py) */
 } kssd_sketchset;
 void kssd_sketchset_release(kssd_sketchset *s);
 
@@ -127,6 +131,8 @@ void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize);
  * puts them and the file is byte-identical.  (fastq -n >= 2 and -u also let ids that are dropped later occupy
  * slots: kssd_slot_order_pos_keep below.) */
 void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
+/* the same for tuples of more than 32 bits (k - drlevel = 9) */
+void kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
 /* For the modes whose dump drops ids that nevertheless sit in the reference's table and shift later probes (fastq
  * -n >= 2: fewer than n occurrences; -u: seen more than once): ALL distinct ids of the genome with their first
  * positions, keep[i] != 0 for the ids the dump writes.  Returns how many are kept; they come back at the front of

@@ -123,3 +123,17 @@ def sample_reads(genomes, n_reads, read_len, seed, err=0.005):
         rf = r.reshape(-1)
         rf[at] = (rf[at] + rng.integers(1, 4, ne, dtype=np.uint8)) & 3
     return r
+
+
+def k12_genomes():
+    """the three small genomes of tests/golden/make_golden_k12.py (k - drlevel = 9), as FASTA texts by file name"""
+    rng = np.random.default_rng(20260312)
+    a = rng.integers(0, 4, 1_500_000, dtype=np.uint8)
+    b = a.copy()
+    hit = rng.random(len(b)) < 0.002
+    b[hit] = (b[hit] + rng.integers(1, 4, int(hit.sum()), dtype=np.uint8)) & 3
+    c = rng.integers(0, 4, 600_000, dtype=np.uint8)
+    nm = np.zeros(len(a), dtype=bool)
+    nm[rng.integers(0, len(a), 40)] = True
+    return {"a.fa": fasta_text(a, b"a random genome", n_mask=nm), "b.fa": fasta_text(b, b"a with 0.2 % substitutions"),
+            "c.fa": fasta_text(c, b"unrelated")}
