@@ -775,6 +775,9 @@ struct ExactArgs {
     void *regions;  // uint32_t[] or, in first-position mode, unsigned long long[]
     uint32_t by_pos;  // KSSD_SKETCH_BY_POS: the 64-bit key is position << 32 | tuple, so that the sort leaves sequence order
     SketchStatus *status;
+#ifdef KSSD_DEV
+    uint32_t dev_no_atomic;  // development A/B (wrong results): the workgroup's room is not reserved at the genome's cursor
+#endif
 };
 
 #define EXACT_THREADS 256  // four waves share one reservation of staging room (see below); 1 024 threads: fewer atomics, and 450 us instead of 210 -- too few chains in flight
@@ -894,6 +897,11 @@ __global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams 
         }
     }
     if (wg_same && wg_total) {  // (workgroup-uniform)
+#ifdef KSSD_DEV
+        if (x.dev_no_atomic) {
+            if (threadIdx.x == 0) s_base = (blockIdx.y * gridDim.x + blockIdx.x) * 400u;
+        } else
+#endif
         if (threadIdx.x == 0) s_base = atomicAdd(&x.cursor[wg_g], wg_total);
         __syncthreads();
     }
@@ -2391,6 +2399,9 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     x.n_slices = pl.n_slices;
     x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
     x.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
+#ifdef KSSD_DEV
+    x.dev_no_atomic = getenv("KSSD_DEV_EXACT_NO_ATOMIC") ? 1u : 0u;
+#endif
     x.status = c->d_status;
     const dim3 grid((unsigned)((pl.cand_cap + EXACT_THREADS * EXACT_PER - 1) / (EXACT_THREADS * EXACT_PER)), pl.n_slices);
     if (pl.with_pos) hipLaunchKernelGGL((sketch_exact_kernel<unsigned long long>), grid, dim3(EXACT_THREADS), 0, s, c->P, x);
