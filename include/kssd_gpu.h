@@ -181,6 +181,11 @@ int kssd_gpu_set_lds_sort_limit(kssd_gpu_ctx *ctx, uint32_t max_tuples);
  */
 uint32_t kssd_gpu_tuple_passes(const kssd_gpu_ctx *ctx);
 int kssd_gpu_set_tuple_pass(kssd_gpu_ctx *ctx, uint32_t pass);
+/* host level: the batch of the context's LAST host-level sketch call (kssd_gpu_sketch_batch[_pos], kssd_gpu_sketch_fast[aq]_text)
+ * once more, without scanning it again: the passes 1 .. 15 after kssd_gpu_set_tuple_pass.  Same flags / min_occ / out_pos
+ * as that call; results as there (kssd_gpu_free). */
+int kssd_gpu_sketch_again(kssd_gpu_ctx *ctx, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids,
+                          uint32_t **out_pos, int64_t *bad_genome);
 
 /*
  * Tuning knob of the scan: at most max_workgroups workgroups of 16 waves (0 = default, one per compute unit).  Every wave

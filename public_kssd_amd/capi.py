@@ -44,7 +44,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fasta_device", "kssd_gpu_tokenise_status", "kssd_gpu_sketch_fasta_text",
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
-    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts", "kssd_gpu_tuple_passes", "kssd_gpu_set_tuple_pass",
+    "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts", "kssd_gpu_tuple_passes", "kssd_gpu_set_tuple_pass", "kssd_gpu_sketch_again",
 ]
 
 
@@ -650,6 +650,7 @@ class GpuCtx:
         """FASTA texts tokenised ON THE DEVICE and sketched: (off, ids[, pos]); one genome per text"""
         buf, offs, lens = self._text_layout(texts)
         n = len(texts)
+        self._last_n = n
         po, pi, pp, bad = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(-1)
         lines = np.zeros(max(n, 1), dtype=np.uint64)
         if _fastq:
@@ -843,6 +844,23 @@ class GpuCtx:
         """1, or 16 for k - drlevel = 9 (36-bit tuples: pass s keeps the tuples with low bits s, its ids are tuple >> 4)"""
         gpu_lib().kssd_gpu_tuple_passes.restype = C.c_uint32
         return int(gpu_lib().kssd_gpu_tuple_passes(self.h))
+
+    def sketch_again(self, flags=SKETCH_FASTA, min_occ=1, with_pos=False):
+        """the batch of the last host-level sketch call once more without a scan (the tuple passes 1 .. 15)"""
+        n = C.c_uint32(0)
+        po, pi, pp, bad = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(-1)
+        _gck(gpu_lib().kssd_gpu_sketch_again(self.h, flags, min_occ, C.byref(po), C.byref(pi), C.byref(pp) if with_pos else None, C.byref(bad)))
+        try:
+            ng = self._last_n
+            off = np.frombuffer((C.c_char * (8 * (ng + 1))).from_address(po.value), dtype=np.uint64).copy()
+            tot = int(off[-1])
+            ids = np.frombuffer((C.c_char * (4 * tot)).from_address(pi.value), dtype=np.uint32).copy() if tot else np.zeros(0, np.uint32)
+            pos = (np.frombuffer((C.c_char * (4 * tot)).from_address(pp.value), dtype=np.uint32).copy() if tot else np.zeros(0, np.uint32)) if with_pos else None
+        finally:
+            for q in (po, pi, pp):
+                if q.value:
+                    gpu_lib().kssd_gpu_free(q)
+        return (off, ids, pos) if with_pos else (off, ids)
 
     def set_tuple_pass(self, s):
         _gck(gpu_lib().kssd_gpu_set_tuple_pass(self.h, int(s)))

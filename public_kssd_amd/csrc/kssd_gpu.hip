@@ -165,6 +165,7 @@ struct kssd_gpu_ctx {
     uint32_t *d_hdr_cnt = nullptr;
     unsigned long long *d_hdr_pre = nullptr, *d_hdr_out = nullptr;
     size_t cap_hdr_cnt = 0, cap_hdr_pre = 0, cap_hdr_out = 0;
+    bool resident_valid = false;  // the last sketch call was a host-level one: its batch is in d_in_packed / d_in_mask (kssd_gpu_sketch_again)
     bool ranges_off = false; // a batch of this context has shown keys that do not spread over id ranges: large genomes take the global-memory sort
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
     bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
@@ -2166,6 +2167,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
 {
     if (!c) return KSSD_ERR_PARAM;
     c->plan.valid = false;
+    if (d_packed != c->d_in_packed) c->resident_valid = false;
     if (c->dist_only || !h_chunk_off || !d_out_off || (!d_out_ids && out_cap)) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     c->last_launch_rc = KSSD_OK;
@@ -2562,8 +2564,9 @@ extern "C" int kssd_gpu_scan_stats(kssd_gpu_ctx *c, uint64_t *stage1, uint64_t *
 }
 
 // the batch is in the context's input buffers (d_in_packed / d_in_mask): sketch it and bring the CSR to the host
+// again = true: the batch of the last call once more (a further tuple pass): its scan's candidates are still there
 static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
-                                uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome)
+                                uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos, int64_t *bad_genome, bool again = false)
 {
     hipStream_t s = c->own_stream;
     const uint64_t n_chunks = chunk_off[n_genomes];
@@ -2580,8 +2583,14 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
             if ((rc = ensure(&c->d_b_pos, &c->cap_b_pos, (size_t)out_cap)) != KSSD_OK) break;
             c->d_out_pos = c->d_b_pos;
         }
-        rc = kssd_gpu_sketch_device(c, c->d_in_packed, c->d_in_mask, chunk_off, n_genomes, flags, min_occ, c->d_b_off, c->d_b_ids,
-                                    out_cap, s);
+        if (again && attempt == 0) {  // (a retry after an overflow scans again: its workspaces may have moved)
+            rc = kssd_gpu_sketch_plan(c, c->d_in_packed, c->d_in_mask, chunk_off, n_genomes, flags, min_occ, c->d_b_off, c->d_b_ids, out_cap);
+            for (int ph : {KSSD_PHASE_REPASS, KSSD_PHASE_EXACT, KSSD_PHASE_FINISH})
+                if (rc == KSSD_OK) rc = kssd_gpu_sketch_phase(c, ph, s);
+        } else {
+            rc = kssd_gpu_sketch_device(c, c->d_in_packed, c->d_in_mask, chunk_off, n_genomes, flags, min_occ, c->d_b_off, c->d_b_ids,
+                                        out_cap, s);
+        }
         if (rc != KSSD_OK) break;
         rc = kssd_gpu_sketch_status(c, &total, bad_genome, s);
         if (rc != KSSD_ERR_OVERFLOW) break;
@@ -2601,8 +2610,26 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
     *out_off = h_off;
     *out_ids = h_ids;
     if (out_pos) *out_pos = h_pos;
+    c->resident_valid = true;
     return KSSD_OK;
 }
+
+// The batch of the context's LAST host-level sketch call (kssd_gpu_sketch_batch[_pos], kssd_gpu_sketch_fast[aq]_text) once
+// more without scanning it again -- for the tuple passes 1 .. 15 of k - drlevel = 9 after kssd_gpu_set_tuple_pass (same flags
+// and min_occ as that call; out_pos NULL like there)
+extern "C" int kssd_gpu_sketch_again(kssd_gpu_ctx *c, uint32_t flags, uint32_t min_occ, uint64_t **out_off, uint32_t **out_ids, uint32_t **out_pos,
+                                     int64_t *bad_genome)
+{
+    if (!c || !out_off || !out_ids || c->h_chunk_off.size() != (size_t)c->last_n_genomes + 1 || !c->resident_valid) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    *out_off = nullptr;
+    *out_ids = nullptr;
+    if (out_pos) *out_pos = nullptr;
+    if (bad_genome) *bad_genome = -1;
+    const std::vector<uint64_t> co = c->h_chunk_off;  // (the plan rewrites the context's copy)
+    return sketch_resident_impl(c, co.data(), c->last_n_genomes, flags, min_occ, out_off, out_ids, out_pos, bad_genome, true);
+}
+
 
 
 // Host-level sketch call.  The device-side input and output buffers belong to the context and only ever grow, the

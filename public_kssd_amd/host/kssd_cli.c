@@ -538,7 +538,7 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
         uint32_t *pids[16] = {ids}, *ppos[16] = {pos};
         for (uint32_t sp = 1; sp < passes; sp++) {
             gck(kssd_gpu_set_tuple_pass(ctx, sp), "kssd_gpu_set_tuple_pass");
-            rc = job_sketch(ctx, j, ring, fl, flags, min_occ, &poff[sp], &pids[sp], &ppos[sp], &bad);
+            rc = kssd_gpu_sketch_again(ctx, flags, min_occ, &poff[sp], &pids[sp], &ppos[sp], &bad); /* one scan for all sixteen */
             if (rc == KSSD_ERR_CAPACITY)
                 die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
             gck(rc, "sketch (tuple pass)");

@@ -86,6 +86,21 @@ def test_sixteen_passes_give_the_references_tuples():
                 got[g].append((ids[int(off[g]):int(off[g + 1])].astype(np.uint64) << np.uint64(4)) | np.uint64(s))
         for g, nm in enumerate(names):
             assert np.array_equal(np.sort(np.concatenate(got[g])), gold[nm][1]), nm
+        # host level, one scan: kssd_gpu_sketch_again for the passes 1 .. 15 (what the command line does), with first positions
+        texts_l = [texts[nm] for nm in names]
+        ctx.set_tuple_pass(0)
+        off0, ids0, pos0 = ctx.sketch_fasta_texts(texts_l, with_pos=True)
+        again = [(off0, ids0, pos0)] + [None] * 15
+        for s in range(1, 16):
+            ctx.set_tuple_pass(s)
+            again[s] = ctx.sketch_again(with_pos=True)
+        for g, nm in enumerate(names):
+            t = np.concatenate([(i[int(o[g]):int(o[g + 1])].astype(np.uint64) << np.uint64(4)) | np.uint64(s) for s, (o, i, p) in enumerate(again)])
+            pp = np.concatenate([p[int(o[g]):int(o[g + 1])] for (o, i, p) in again])
+            assert np.array_equal(np.sort(t), gold[nm][1]), nm
+            order = K.slot_order_pos64(t, pp, 536870909)                     # the reference's file order, component by component
+            for c in range(256):
+                assert np.array_equal((order[(order & np.uint64(255)) == np.uint64(c)] >> np.uint64(8)).astype(np.uint32), gold[nm][0][c]), (nm, c)
         # one scan, sixteen passes over its candidates
         dev = torch.device("cuda", 0)
         packed = torch.from_numpy(b.packed().view(np.int32)).to(dev)
