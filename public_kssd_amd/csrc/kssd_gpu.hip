@@ -387,6 +387,19 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
     return v;
 }
 
+// the same through DPP moves (row shifts inside the rows of 16 lanes, then the two row broadcasts): no LDS crossbar traffic,
+// which a kernel that keeps the LDS pipe busy with table reads cannot afford (a ds_bpermute costs what a conflicted read costs)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // kernel 0: chunk -> genome map
 // ---------------------------------------------------------------------------------------------------
@@ -520,6 +533,66 @@ __device__ __forceinline__ uint32_t bloom_round(const ScanArgs &a, const uint32_
     return (uint32_t)__builtin_popcountll(bal);
 }
 
+#ifndef SCAN_GATHER
+#define SCAN_GATHER 1
+#endif
+// SCAN_GATHER: the candidate loop buffers nothing but the candidate's position (4 bytes); the bases are fetched when the
+// Bloom round comes, one lane per buffered candidate, from the packed stream itself -- a 12-byte gather per lane that hits
+// L2 (the wave read those lines a few chunks ago) on the vector-memory path, which the scan leaves idle (3 coalesced loads
+// per chunk), instead of being cut out of the scanning lane's registers inside a loop that runs at ~15 % lane efficiency
+// (3.4 passes per chunk for ~34 candidates, 26 VALU instructions each: more than stage 1 itself).  A round is issued (entries
+// read, gathers sent) one step before it is completed (Bloom test, survivors stored), so nothing waits for the gather.
+//   entry: [11:0] position inside its chunk   [22:12] chunk - block's first chunk   [23] all 2k bases known valid
+struct ScanRound {
+    uint32_t e, w0, w1, w2, n;  // n (wave-uniform): entries of the round, 0 = none pending
+    unsigned long long c0;      // first chunk of the block the entries belong to (wave-uniform)
+};
+__device__ __forceinline__ void scan_round_issue(const ScanArgs &a, unsigned long long blk_c0, const uint32_t *cbuf, uint32_t first, uint32_t n,
+                                                 uint32_t lane, ScanRound &r)
+{
+    r.n = n;
+    r.c0 = blk_c0;
+    r.e = 0;
+    r.w0 = r.w1 = r.w2 = 0;
+    if (lane < n) {
+        r.e = cbuf[first + lane];
+        const unsigned long long p = ((blk_c0 + ((r.e >> 12) & 2047u)) << 12) | (r.e & 4095u);  // global position of the sub-context
+        const unsigned long long i = p >> 4;                                                     // its packed word
+        const uint32_t *pp = a.packed + (i ? i - 1 : 0);  // the word in front (the 4 bases before p may lie there), the word, the next
+        r.w0 = pp[0];
+        r.w1 = pp[1];
+        r.w2 = pp[2];
+    }
+}
+template <int SUBK, int ABL>
+__device__ __forceinline__ uint32_t scan_round_complete(const ScanArgs &a, const uint32_t *bloom, unsigned long long wid,
+                                                        uint32_t stored, uint32_t lane, ScanRound &r, uint32_t &abl_acc)
+{
+    bool pass = false;
+    uint32_t top32 = 0, front = 0;
+    unsigned long long p = 0;
+    if (lane < r.n) {
+        p = ((r.c0 + ((r.e >> 12) & 2047u)) << 12) | (r.e & 4095u);
+        const bool at0 = (p >> 4) == 0;  // no word in front of the batch's first one
+        const uint32_t wm = at0 ? 0u : r.w0, wa = at0 ? r.w0 : r.w1, wb = at0 ? r.w1 : r.w2;
+        const uint32_t sh = 2u * ((uint32_t)p & 15u);
+        top32 = (uint32_t)(((((unsigned long long)wa << 32) | wb) << sh) >> 32);            // the 16 bases from p on
+        front = (uint32_t)(((((unsigned long long)wm << 32) | wa) << sh) >> 32) & 0xFFu;    // the 4 bases in front of p
+        const uint32_t h = kssd_bloom_hash(top32 >> (32 - 4 * SUBK));
+        const uint32_t bits = kssd_bloom_bits(h);
+        pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
+    }
+    const uint64_t bal = __ballot(pass);
+    if (pass) {
+        const unsigned long long at = (unsigned long long)stored + rank_in(bal);
+        if (ABL != 0) abl_acc ^= r.e;
+        else if (at < a.cand_cap)
+            a.cand[wid * a.cand_cap + at] = make_ulonglong2(p, kssd_carry_payload(top32, front) | ((unsigned long long)((r.e >> 23) & 1u) << 63));
+    }
+    r.n = 0;
+    return (uint32_t)__builtin_popcountll(bal);
+}
+
 // ABL != 0: development-only ablations for profiling (1 = loads only, 2 = + stage 1, 3 = + stage 1.5 without
 // the candidate list); never used by the product path.
 //
@@ -552,6 +625,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const uint32_t wg_first = blockIdx.x * wg_per;
     const uint32_t n_blocks = wg_first >= n_blocks_all ? 0u : (n_blocks_all - wg_first < wg_per ? n_blocks_all - wg_first : wg_per);  // of this workgroup
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
+#if SCAN_GATHER
+    uint32_t *pbuf = reinterpret_cast<uint32_t *>(cbuf);  // the same room as 4-byte position entries
+    // rounds in flight (issued, not completed): one per step; two behind a block's last step, whose survivors -- and the block's
+    // blk_info entry -- are completed by the first step of the wave's next block (or after its last one)
+    ScanRound pendA, pendB;
+    pendA.n = pendB.n = 0;
+    pendA.e = pendA.w0 = pendA.w1 = pendA.w2 = pendB.e = pendB.w0 = pendB.w1 = pendB.w2 = 0;
+    pendA.c0 = pendB.c0 = 0;
+    uint32_t defer_blk = 0xFFFFFFFFu, defer_first = 0;  // the block whose blk_info entry waits for those rounds (wave-uniform)
+    uint32_t cur_first = 0;  // where the survivors of the block being worked on begin in the slice: behind the last survivor of the block before
+    auto finish_pending = [&]() {
+        if (pendA.n) stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, pendA, abl_acc);
+        if (pendB.n) stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, pendB, abl_acc);
+        if (defer_blk != 0xFFFFFFFFu) {
+            if (ABL == 0 && lane == 0) {  // where the block's survivors are (clamped to what the slice holds: an overflow is reported below)
+                const unsigned long long cap = a.cand_cap;
+                const unsigned long long f = defer_first < cap ? defer_first : cap, e = stored < cap ? stored : cap;
+                a.blk_info[defer_blk] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
+            }
+            defer_blk = 0xFFFFFFFFu;
+            cur_first = stored;
+        }
+    };
+#endif
 #ifdef KSSD_DEV
     const unsigned long long dev_t0 = __builtin_readcyclecounter();
 #endif
@@ -636,6 +733,62 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 const uint32_t ebase = (crel << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
                 // the neighbouring lane's last packed word (v_mov_b32 wave_shr:1; lane 0 keeps the previous chunk's tail)
                 const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s_tail, (int)cur.W[3], 0x138, 0xf, 0xf, false);
+#if SCAN_GATHER
+                (void)wm1;
+                // The lanes' candidate bits become one dense list of positions: a prefix sum over the lanes' counts (DPP moves),
+                // then every lane writes its own ~0.5 positions -- a loop over its set bits with nothing but a find-first-bit, a
+                // clear and a 4-byte LDS write per pass, no ballot, no rank, no extraction.
+                // (No vector-memory instruction may sit inside such a loop: one on ANY path through it makes the compiler wait
+                // for all outstanding loads -- the prefetched chunks -- at the loop's head, every pass.)
+                unsigned long long m64 = ((unsigned long long)ch << 32) | cl;
+                const uint32_t mine = (uint32_t)__builtin_popcountll(m64);
+                const uint32_t incl = wave_incl_scan_dpp(mine);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (cn + total > 2 * CBUF) {  // dense parameter sets only: rounds completed at once make room (the rounds in flight first: blocks stay in order)
+                    finish_pending();
+                    wave_lds_sync();
+                    while (cn >= 64 && cn + total > 2 * CBUF) {
+                        ScanRound tmp;
+                        scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
+                        stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
+                        n_rounded += 64;
+                        cn -= 64;
+                    }
+                    wave_lds_sync();
+                }
+                uint32_t w = cn + incl - mine;
+                if (cn + total <= 2 * CBUF) {
+                    while (m64) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m64);
+                        m64 &= m64 - 1ull;
+                        pbuf[w++] = ebase | b;
+                    }
+                    cn += total;
+                } else {
+                    // more candidates in ONE chunk than the buffer holds (a stretch where nearly every position passes stage 1):
+                    // lane after lane, 64 positions at a time
+                    for (uint32_t l = 0; l < 64; l++) {
+                        const unsigned long long ml = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ch, (int)l) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readlane((int)cl, (int)l);
+                        if (ml == 0) continue;
+                        const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)ebase, (int)l);
+                        if ((ml >> lane) & 1ull) pbuf[cn + (uint32_t)__builtin_popcountll(ml & ((1ull << lane) - 1ull))] = eb | lane;
+                        cn += (uint32_t)__builtin_popcountll(ml);
+                        if (cn + 64 > 2 * CBUF) {
+                            wave_lds_sync();
+                            while (cn >= 64) {
+                                ScanRound tmp;
+                                scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
+                                stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
+                                n_rounded += 64;
+                                cn -= 64;
+                            }
+                            wave_lds_sync();
+                        }
+                    }
+                }
+                (void)wm1;
+#else
                 for (;;) {
                     // ONE compare per pass, in uniform control flow, feeds the ballot, the loop exit and the branch below
                     // (a `has` carried around the loop as a bool came back through v_cndmask + v_cmp, three compares per pass)
@@ -663,6 +816,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     }
                     cn += __builtin_popcountll(hbal);
                 }
+#endif
             }
             s_tail = __builtin_amdgcn_readlane(cur.W[3], 63);
             vb_prev = vb;
@@ -672,6 +826,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
             // buffer: the block's survivors then sit in one run of the wave's slice (blk_info), and an entry never waits
             // longer than a block (it names its chunk relative to the block's first one)
             kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
+#if SCAN_GATHER
+            if (ABL != 2) {
+                // the rounds issued one step ago are completed (their gathers have long arrived) -- with them, behind a block's
+                // last step, the block's blk_info entry -- and the next round is issued.  A block's last step issues everything
+                // that is left (two rounds in flight; more than 128 entries: the rest at once), so that the buffer is empty when
+                // the next block begins and a block's survivors are one run of the slice
+                finish_pending();
+                if (!last) {
+                    if (cn >= 64) {
+                        wave_lds_sync();
+                        scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, pendA);
+                        n_rounded += 64;
+                        cn -= 64;
+                    }
+                } else if (cn) {
+                    wave_lds_sync();
+                    if (cn > 128) {  // (dense parameter sets)
+                        do {
+                            ScanRound tmp;
+                            scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
+                            stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
+                            n_rounded += 64;
+                            cn -= 64;
+                        } while (cn > 128);
+                    }
+                    uint32_t n = cn < 64 ? cn : 64;
+                    scan_round_issue(a, blk_c0, pbuf, cn - n, n, lane, pendA);
+                    n_rounded += n;
+                    cn -= n;
+                    if (cn) {
+                        scan_round_issue(a, blk_c0, pbuf, 0, cn, lane, pendB);
+                        n_rounded += cn;
+                        cn = 0;
+                    }
+                }
+            }
+#else
             if (ABL != 2) {
                 while (cn >= 64 || (last && cn)) {
                     const uint32_t n = cn < 64 ? cn : 64;
@@ -683,6 +874,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     if (!last) break;
                 }
             }
+#endif
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
         }
     };
@@ -702,12 +894,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         step(r1, r2, r0, c + 1, 1u, nb, false);
         step(r2, r3, r1, c + 2, 2u, nb + 1, false);
         step(r3, r0, r2, c + 3, 3u, nb + 2, true);
+#if SCAN_GATHER
+        defer_blk = wg_first + b_cur;  // its last rounds are in flight: finish_pending() of the next step (or below) writes the entry
+        defer_first = cur_first;
+        (void)first_stored;
+        if (!more) {
+            finish_pending();
+            break;
+        }
+#else
         if (ABL == 0 && lane == 0) {  // where the block's survivors are (clamped to what the slice holds: an overflow is reported below)
             const unsigned long long cap = a.cand_cap;
             const unsigned long long f = first_stored < cap ? first_stored : cap, e = stored < cap ? stored : cap;
             a.blk_info[wg_first + b_cur] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
         }
         if (!more) break;
+#endif
         b_cur = b_nxt;
         b_nxt = b_nn;
         blk_c0 = nb;
