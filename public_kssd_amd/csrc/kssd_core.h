@@ -18,7 +18,9 @@
 
 #define KSSD_CHUNK 4096      // positions per chunk (one wave-iteration: 64 lanes x 64 positions)
 #define KSSD_T1_BYTES (1u << 17)  // stage-1 group-filter table: one byte per 17-bit index
+#ifndef KSSD_GW
 #define KSSD_GW 5                // windows per table read (KssdGrp)
+#endif
 #define KSSD_MIN_DIM_SMP 4096  // MIN_SUBCTX_DIM_SMP_SZ, command_shuffle.h:29
 #define KSSD_COMPONENT_SZ 7    // reference Makefile:4
 #define KSSD_CTX_SPC_USE_L 8   // global_basic.h:45-47
