@@ -280,43 +280,18 @@ KSSD_HD uint32_t kssd_extract_m(const uint32_t (&W)[5], uint32_t b)
     return top >> (32 - 4 * SUBK);
 }
 
-// What the scanning lane hands to the exact stage together with a candidate's position, so that stage 2 does not have
-// to read the packed stream again (one 128-byte HBM line per candidate for 5 useful bytes): the 16 bases from the
-// sub-context's first base on (top32: the word the Bloom pattern is the top of) and the 4 bases in front of it (the low
-// 8 bits of `front`; Wm1 = the packed word in front of W[0], i.e. the neighbouring lane's W[3]).  20 bases
-// [b-4, b+16) hold the whole 2k-mer whenever out = k - subk <= 4 and 2 subk + out <= 16 (kssd_carry_ok: L3K10, L2K8,
-// K9 ...); other parameter sets ignore the payload and read the stream.
-template <int SUBK>
-KSSD_HD void kssd_extract_carry(const uint32_t (&W)[5], uint32_t Wm1, uint32_t b, uint32_t &top32, uint32_t &front)
+// What goes to the exact stage together with a candidate's position, so that stage 2 does not have to read the packed
+// stream again (one 128-byte HBM line per candidate for 5 useful bytes): the 16 bases from the sub-context's first base on
+// (top32: the word the Bloom pattern is the top of) and the 4 bases in front of it (front, 8 bits).  The lane that takes a
+// buffered candidate into a Bloom round fetches three packed words around its position p -- wm = the word in front of the
+// one that holds p (0 for the batch's first word), wa = that word, wb = the next -- and cuts both out with two 64-bit shifts
+// (r = p & 15).  20 bases [p-4, p+16) hold the whole 2k-mer whenever out = k - subk <= 4 and 2 subk + out <= 16
+// (kssd_carry_ok: L3K10, L2K8, K9 ...); other parameter sets ignore the payload and read the stream.
+KSSD_HD void kssd_carry_from_words(uint32_t wm, uint32_t wa, uint32_t wb, uint32_t r, uint32_t &top32, uint32_t &front)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // two select levels on the 96-bit window instead of three 4-way selects (7 v_cndmask / v_bfi instead of 9): bit 5 of b
-    // picks four consecutive words, bit 4 three of those; then one 64-bit shift each for the 16 bases and for the 4 bases
-    // in front (a v_bfe_u32 at offset 32 - sh would be cheaper but wraps to offset 0 when sh = 0)
-    uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 4, 1), s2 = (uint32_t)__builtin_amdgcn_sbfe((int)b, 5, 1);
-    // The masks are made opaque: knowing that they are all ones or all zeros, the compiler rewrites every bitwise select
-    // below as v_cmp + v_cndmask_b32 with an SGPR-pair condition -- and on gfx950 a v_cndmask_b32 issues four to five times
-    // slower than a v_bfi_b32 (profiles/r03a_valu_probe.txt: 12 against 2.8 cycles per wave instruction and SIMD at four
-    // waves).  Eleven of them per candidate pass were a third of the scan kernel's time.
-    asm volatile("" : "+v"(s1), "+v"(s2));
-#define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
-    const uint32_t x0 = KSSD_BSEL(s2, W[1], Wm1), x1 = KSSD_BSEL(s2, W[2], W[0]), x2 = KSSD_BSEL(s2, W[3], W[1]), x3 = KSSD_BSEL(s2, W[4], W[2]);
-    const uint32_t pre = KSSD_BSEL(s1, x1, x0), hi = KSSD_BSEL(s1, x2, x1), lo = KSSD_BSEL(s1, x3, x2);
-#undef KSSD_BSEL
-    const uint32_t sh = (b & 15u) * 2u;
-    top32 = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
-    front = (uint32_t)(((((uint64_t)pre << 32) | hi) << sh) >> 32);  // low 8 bits: the 4 bases before position b
-#else
-    const uint32_t s1 = 0u - ((b >> 4) & 1u), s2 = 0u - ((b >> 5) & 1u);
-#define KSSD_BSEL(m, x, y) (((m) & (x)) | (~(m) & (y)))  /* m ? x : y, bitwise */
-    const uint32_t pre = KSSD_BSEL(s2, KSSD_BSEL(s1, W[2], W[1]), KSSD_BSEL(s1, W[0], Wm1));
-    const uint32_t hi = KSSD_BSEL(s2, KSSD_BSEL(s1, W[3], W[2]), KSSD_BSEL(s1, W[1], W[0]));
-    const uint32_t lo = KSSD_BSEL(s2, KSSD_BSEL(s1, W[4], W[3]), KSSD_BSEL(s1, W[2], W[1]));
-#undef KSSD_BSEL
-    const uint32_t sh = (b & 15u) * 2u;
-    top32 = (uint32_t)(((((uint64_t)hi << 32) | lo) << sh) >> 32);
-    front = (uint32_t)(((((uint64_t)pre << 32) | hi) << sh) >> 32);  // low 8 bits: the 4 bases before position b
-#endif
+    const uint32_t sh = 2u * r;
+    top32 = (uint32_t)(((((uint64_t)wa << 32) | wb) << sh) >> 32);
+    front = (uint32_t)(((((uint64_t)wm << 32) | wa) << sh) >> 32) & 0xFFu;
 }
 
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank
@@ -375,7 +350,7 @@ KSSD_HD bool kssd_s2_decode(const KssdParams &P, uint32_t p0, uint32_t p1, uint3
     return valid;
 }
 
-// the carried payload (kssd_extract_carry: 20 bases from 4 in front of the sub-context on) holds the whole k-mer
+// the carried payload (kssd_carry_from_words: 20 bases from 4 in front of the sub-context on) holds the whole k-mer
 KSSD_HD bool kssd_carry_ok(const KssdParams &P) { return P.out <= 4 && 2 * P.subk + P.out <= 16; }
 KSSD_HD uint64_t kssd_carry_payload(uint32_t top32, uint32_t front) { return ((uint64_t)(front & 0xFFu) << 32) | top32; }
 // the 2k bases of the k-mer out of the payload: they start 4 - out bases into its 20

@@ -58,13 +58,13 @@ extern "C" const char *kssd_gpu_strerror(int code)
 // ---------------------------------------------------------------------------------------------------
 #define SCAN_THREADS 1024
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define CBUF 128          // per-wave buffer of stage-1 candidates waiting for the Bloom test (8 B each)
+#define CBUF 256          // per-wave buffer of stage-1 candidates waiting for their Bloom round: 4-byte position entries
 #define SKETCH_TRACK_FILL 0x80000000u  // internal flag: record the fullest staging region even without an overflow
 #define DEDUP_THREADS 512
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
 #define SCAN_TAB_BYTES (KSSD_T1_BYTES + KSSD_BLOOM_WORDS * 4)  // stage-1 table + stage-1.5 Bloom filter, contiguous
-#define SCAN_LDS_BYTES (SCAN_TAB_BYTES + SCAN_WAVES * CBUF * 8)
+#define SCAN_LDS_BYTES (SCAN_TAB_BYTES + SCAN_WAVES * CBUF * 4)
 
 struct SketchStatus {
     unsigned long long total_ids;
@@ -493,56 +493,22 @@ __device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long
     const uint4 v = *reinterpret_cast<const uint4 *>(pp);
     r.W[0] = v.x; r.W[1] = v.y; r.W[2] = v.z; r.W[3] = v.w;
     r.W[4] = pp[4];
-    const uint2 m = *reinterpret_cast<const uint2 *>(a.mask + c * 128 + lane * 2);
-    r.M[0] = m.x; r.M[1] = m.y;
+    // (the validity words are read once: streamed past the L2 lines of the packed words, which the Bloom rounds come back to;
+    // -0.8 % of the kernel's time, profiles/r03w)
+    const uint32_t *mp = a.mask + c * 128 + lane * 2;
+    r.M[0] = __builtin_nontemporal_load(mp);
+    r.M[1] = __builtin_nontemporal_load(mp + 1);
 }
 
-// A buffered stage-1 candidate (8 bytes in LDS):
-//   x  [11:0] position inside its chunk (lane << 6 | b)   [22:12] chunk - c0, modulo 2048 (entries live for a few chunks)
-//      [23]   1 = all 2k bases are known to be valid (the lane's and both neighbours' 64 positions are bases)
-//      [31:24] the 4 bases in front of the sub-context
-//   y  the 16 bases from the sub-context's first base on (its top 4*SUBK bits are the Bloom pattern)
-// Stage 1.5 for up to 64 buffered stage-1 candidates (entries [first, first+n) of the wave's buffer): Bloom test
-// of the pattern the owning lane cut out of its registers, survivors go straight to the wave's slice of the
-// candidate list (plain 16-byte stores, nothing to wait for) as {global position, k-mer payload | valid << 63}.
-// crel = (the chunk being worked on) - c0.  Returns how many survived (wave-uniform).
-template <int SUBK, int ABL>
-__device__ __forceinline__ uint32_t bloom_round(const ScanArgs &a, const uint32_t *bloom, unsigned long long wid,
-                                                unsigned long long c0, uint32_t crel, const uint2 *cbuf, uint32_t first, uint32_t n,
-                                                uint32_t stored, uint32_t lane, uint32_t &abl_acc)
-{
-    bool pass = false;
-    uint2 e = make_uint2(0u, 0u);
-    if (lane < n) {
-        e = cbuf[first + lane];
-        const uint32_t h = kssd_bloom_hash(e.y >> (32 - 4 * SUBK));
-        const uint32_t bits = kssd_bloom_bits(h);
-        pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
-    }
-    const uint64_t bal = __ballot(pass);
-    if (pass) {
-        const unsigned long long at = (unsigned long long)stored + rank_in(bal);
-        if (ABL != 0) abl_acc ^= e.x;
-        else if (at < a.cand_cap) {
-            const uint32_t age = (crel - (e.x >> 12)) & 2047u;  // chunks since the entry was buffered
-            const unsigned long long chunk = c0 + crel - age;
-            a.cand[wid * a.cand_cap + at] = make_ulonglong2((chunk << 12) | (e.x & 4095u),
-                                                            kssd_carry_payload(e.y, e.x >> 24) | ((unsigned long long)((e.x >> 23) & 1u) << 63));
-        }
-    }
-    return (uint32_t)__builtin_popcountll(bal);
-}
-
-#ifndef SCAN_GATHER
-#define SCAN_GATHER 1
-#endif
-// SCAN_GATHER: the candidate loop buffers nothing but the candidate's position (4 bytes); the bases are fetched when the
-// Bloom round comes, one lane per buffered candidate, from the packed stream itself -- a 12-byte gather per lane that hits
-// L2 (the wave read those lines a few chunks ago) on the vector-memory path, which the scan leaves idle (3 coalesced loads
-// per chunk), instead of being cut out of the scanning lane's registers inside a loop that runs at ~15 % lane efficiency
-// (3.4 passes per chunk for ~34 candidates, 26 VALU instructions each: more than stage 1 itself).  A round is issued (entries
-// read, gathers sent) one step before it is completed (Bloom test, survivors stored), so nothing waits for the gather.
-//   entry: [11:0] position inside its chunk   [22:12] chunk - block's first chunk   [23] all 2k bases known valid
+// Stage-1 candidates are buffered as positions only (4 bytes in LDS); their bases are fetched when the Bloom round comes, one
+// lane per buffered candidate, from the packed stream itself -- a 12-byte gather per lane on the vector-memory path, which
+// the scan leaves idle (3 coalesced loads per chunk), mostly L2 hits (the wave read those lines a few chunks ago; FETCH_SIZE
+// says a third of them come from HBM again).  Until round 3 the scanning lane cut them out of its registers inside the
+// candidate loop: 26 VALU instructions per pass at ~15 % lane efficiency (3.4 passes per chunk for ~34 candidates), more than
+// stage 1 itself.  A round is issued (entries read, gathers sent) one step before it is completed (Bloom test, survivors
+// stored as {global position, k-mer payload | valid << 63}, plain 16-byte stores), so nothing waits for the gather.
+//   entry: [11:0] position inside its chunk (lane << 6 | b)   [22:12] chunk - block's first chunk
+//          [23] 1 = all 2k bases are known to be valid (the lane's and both neighbours' 64 positions are bases)
 struct ScanRound {
     uint32_t e, w0, w1, w2, n;  // n (wave-uniform): entries of the round, 0 = none pending
     unsigned long long c0;      // first chunk of the block the entries belong to (wave-uniform)
@@ -574,10 +540,7 @@ __device__ __forceinline__ uint32_t scan_round_complete(const ScanArgs &a, const
     if (lane < r.n) {
         p = ((r.c0 + ((r.e >> 12) & 2047u)) << 12) | (r.e & 4095u);
         const bool at0 = (p >> 4) == 0;  // no word in front of the batch's first one
-        const uint32_t wm = at0 ? 0u : r.w0, wa = at0 ? r.w0 : r.w1, wb = at0 ? r.w1 : r.w2;
-        const uint32_t sh = 2u * ((uint32_t)p & 15u);
-        top32 = (uint32_t)(((((unsigned long long)wa << 32) | wb) << sh) >> 32);            // the 16 bases from p on
-        front = (uint32_t)(((((unsigned long long)wm << 32) | wa) << sh) >> 32) & 0xFFu;    // the 4 bases in front of p
+        kssd_carry_from_words(at0 ? 0u : r.w0, at0 ? r.w0 : r.w1, at0 ? r.w1 : r.w2, (uint32_t)p & 15u, top32, front);
         const uint32_t h = kssd_bloom_hash(top32 >> (32 - 4 * SUBK));
         const uint32_t bits = kssd_bloom_bits(h);
         pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
@@ -614,7 +577,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // loop counter and every counter derived from a ballot live in VGPRs and the loops run on exec masks
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = lane_id();
-    uint2 *cbuf = reinterpret_cast<uint2 *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates, see bloom_round
+    uint32_t *pbuf = reinterpret_cast<uint32_t *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates (positions, see ScanRound)
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
     // work distribution: the workgroup's run of blocks, its waves take them in turn (see SCAN_BLOCK)
@@ -625,8 +588,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const uint32_t wg_first = blockIdx.x * wg_per;
     const uint32_t n_blocks = wg_first >= n_blocks_all ? 0u : (n_blocks_all - wg_first < wg_per ? n_blocks_all - wg_first : wg_per);  // of this workgroup
     uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
-#if SCAN_GATHER
-    uint32_t *pbuf = reinterpret_cast<uint32_t *>(cbuf);  // the same room as 4-byte position entries
     // rounds in flight (issued, not completed): one per step; two behind a block's last step, whose survivors -- and the block's
     // blk_info entry -- are completed by the first step of the wave's next block (or after its last one)
     ScanRound pendA, pendB;
@@ -648,7 +609,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
             cur_first = stored;
         }
     };
-#endif
 #ifdef KSSD_DEV
     const unsigned long long dev_t0 = __builtin_readcyclecounter();
 #endif
@@ -681,12 +641,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     const unsigned long long dev_t1 = __builtin_readcyclecounter();
 #endif
     if (b_cur >= n_blocks) return;
-    // what a lane needs from its neighbours for the hand-over to the exact stage: the packed word in front of its own
-    // (lane 0: the last word of the chunk before, carried in an SGPR from step to step) and whether the neighbours' 64
-    // positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour is not looked at, and
-    // neither is lane 0's left one in the first chunk of a block: their candidates -- ~2 % -- let the exact stage read the mask)
+    // whether a lane's neighbours' 64 positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour
+    // is not looked at, and neither is lane 0's left one in the first chunk of a block: their candidates -- ~2 % -- let the
+    // exact stage read the mask)
     unsigned long long blk_c0 = (unsigned long long)(wg_first + b_cur) * SCAN_BLOCK;  // first chunk of the block being worked on
-    uint32_t s_tail = blk_c0 ? __builtin_amdgcn_readfirstlane(a.packed[blk_c0 * 256 - 1]) : 0u;
     uint64_t vb_prev = 0;
 
     // prologue: the block's first chunk through both alignments
@@ -731,10 +689,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 // would have to wait behind the table reads of the next chunk that are in flight
                 const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);  // lane and both neighbours all bases
                 const uint32_t ebase = (crel << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
-                // the neighbouring lane's last packed word (v_mov_b32 wave_shr:1; lane 0 keeps the previous chunk's tail)
-                const uint32_t wm1 = (uint32_t)__builtin_amdgcn_update_dpp((int)s_tail, (int)cur.W[3], 0x138, 0xf, 0xf, false);
-#if SCAN_GATHER
-                (void)wm1;
                 // The lanes' candidate bits become one dense list of positions: a prefix sum over the lanes' counts (DPP moves),
                 // then every lane writes its own ~0.5 positions -- a loop over its set bits with nothing but a find-first-bit, a
                 // clear and a 4-byte LDS write per pass, no ballot, no rank, no extraction.
@@ -744,10 +698,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 const uint32_t mine = (uint32_t)__builtin_popcountll(m64);
                 const uint32_t incl = wave_incl_scan_dpp(mine);
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (cn + total > 2 * CBUF) {  // dense parameter sets only: rounds completed at once make room (the rounds in flight first: blocks stay in order)
+                if (cn + total > CBUF) {  // dense parameter sets only: rounds completed at once make room (the rounds in flight first: blocks stay in order)
                     finish_pending();
                     wave_lds_sync();
-                    while (cn >= 64 && cn + total > 2 * CBUF) {
+                    while (cn >= 64 && cn + total > CBUF) {
                         ScanRound tmp;
                         scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
                         stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
@@ -757,7 +711,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     wave_lds_sync();
                 }
                 uint32_t w = cn + incl - mine;
-                if (cn + total <= 2 * CBUF) {
+                if (cn + total <= CBUF) {
                     while (m64) {
                         const uint32_t b = (uint32_t)__builtin_ctzll(m64);
                         m64 &= m64 - 1ull;
@@ -774,7 +728,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                         const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)ebase, (int)l);
                         if ((ml >> lane) & 1ull) pbuf[cn + (uint32_t)__builtin_popcountll(ml & ((1ull << lane) - 1ull))] = eb | lane;
                         cn += (uint32_t)__builtin_popcountll(ml);
-                        if (cn + 64 > 2 * CBUF) {
+                        if (cn + 64 > CBUF) {
                             wave_lds_sync();
                             while (cn >= 64) {
                                 ScanRound tmp;
@@ -787,38 +741,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                         }
                     }
                 }
-                (void)wm1;
-#else
-                for (;;) {
-                    // ONE compare per pass, in uniform control flow, feeds the ballot, the loop exit and the branch below
-                    // (a `has` carried around the loop as a bool came back through v_cndmask + v_cmp, three compares per pass)
-                    const bool has = (cl | ch) != 0;
-                    const uint64_t hbal = __ballot(has);
-                    if (hbal == 0) break;
-                    if (cn + 64 > CBUF) {  // dense parameter sets only: make room
-                        wave_lds_sync();
-                        const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, blk_c0, crel, cbuf, cn - 64, 64, stored, lane, abl_acc);
-                        stored += m;
-                        n_rounded += 64;
-                        cn -= 64;
-                        wave_lds_sync();
-                    }
-                    if (has) {
-                        // lowest set bit of (ch:cl), taken and cleared as one 64-bit value: no select on which word holds it
-                        const unsigned long long m64 = ((unsigned long long)ch << 32) | cl;
-                        const uint32_t b = (uint32_t)__builtin_ctzll(m64);
-                        const unsigned long long rest = m64 & (m64 - 1ull);
-                        cl = (uint32_t)rest;
-                        ch = (uint32_t)(rest >> 32);
-                        uint32_t top32, front;
-                        kssd_extract_carry<SUBK>(cur.W, wm1, b, top32, front);
-                        cbuf[cn + rank_in(hbal)] = make_uint2(ebase | b | (front << 24), top32);
-                    }
-                    cn += __builtin_popcountll(hbal);
-                }
-#endif
             }
-            s_tail = __builtin_amdgcn_readlane(cur.W[3], 63);
             vb_prev = vb;
             __builtin_amdgcn_s_setprio(2);
             // the next chunk: alignment A is in; nothing is outstanding in LDS now, which is the cheap moment for a
@@ -826,7 +749,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
             // buffer: the block's survivors then sit in one run of the wave's slice (blk_info), and an entry never waits
             // longer than a block (it names its chunk relative to the block's first one)
             kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
-#if SCAN_GATHER
             if (ABL != 2) {
                 // the rounds issued one step ago are completed (their gathers have long arrived) -- with them, behind a block's
                 // last step, the block's blk_info entry -- and the next round is issued.  A block's last step issues everything
@@ -834,11 +756,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                 // the next block begins and a block's survivors are one run of the slice
                 finish_pending();
                 if (!last) {
-                    if (cn >= 64) {
+                    if (cn >= 64) {  // (a round in every step whatever it holds -- younger gathers, more L2 hits -- was slower: profiles/r03x)
+                        const uint32_t n = cn < 64 ? cn : 64;
                         wave_lds_sync();
-                        scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, pendA);
-                        n_rounded += 64;
-                        cn -= 64;
+                        scan_round_issue(a, blk_c0, pbuf, cn - n, n, lane, pendA);
+                        n_rounded += n;
+                        cn -= n;
                     }
                 } else if (cn) {
                     wave_lds_sync();
@@ -862,19 +785,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
                     }
                 }
             }
-#else
-            if (ABL != 2) {
-                while (cn >= 64 || (last && cn)) {
-                    const uint32_t n = cn < 64 ? cn : 64;
-                    wave_lds_sync();
-                    const uint32_t m = bloom_round<SUBK, ABL>(a, bloom, wid, blk_c0, crel, cbuf, cn - n, n, stored, lane, abl_acc);
-                    stored += m;
-                    n_rounded += n;
-                    cn -= n;
-                    if (!last) break;
-                }
-            }
-#endif
             kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
         }
     };
@@ -885,35 +795,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         // chunks of the block after this one (none: reads clamped to the last chunk of the batch, never looked at)
         const unsigned long long nb = more ? (unsigned long long)(wg_first + b_nxt) * SCAN_BLOCK : clast;
         const uint32_t b_nn = take(b_nxt);
-        // the word in front of the next block's first chunk, for lane 0 of its first step: the last 64 words of the chunk in
-        // front of it, one per lane (a wave-uniform address would become a scalar load, whose counter is the LDS reads' too)
-        uint32_t tail_v = 0;
-        if (more && nb) tail_v = a.packed[nb * 256 - 64 + lane];
-        const uint32_t first_stored = stored;
         step(r0, r1, r3, c, 0u, c + 3, false);
         step(r1, r2, r0, c + 1, 1u, nb, false);
         step(r2, r3, r1, c + 2, 2u, nb + 1, false);
         step(r3, r0, r2, c + 3, 3u, nb + 2, true);
-#if SCAN_GATHER
         defer_blk = wg_first + b_cur;  // its last rounds are in flight: finish_pending() of the next step (or below) writes the entry
         defer_first = cur_first;
-        (void)first_stored;
         if (!more) {
             finish_pending();
             break;
         }
-#else
-        if (ABL == 0 && lane == 0) {  // where the block's survivors are (clamped to what the slice holds: an overflow is reported below)
-            const unsigned long long cap = a.cand_cap;
-            const unsigned long long f = first_stored < cap ? first_stored : cap, e = stored < cap ? stored : cap;
-            a.blk_info[wg_first + b_cur] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
-        }
-        if (!more) break;
-#endif
         b_cur = b_nxt;
         b_nxt = b_nn;
         blk_c0 = nb;
-        s_tail = __builtin_amdgcn_readlane(tail_v, 63);
         vb_prev = 0;
     }
 #ifdef KSSD_DEV

@@ -37,11 +37,12 @@ static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mas
                 n_cand[1]++;
                 uint32_t dr;
                 if (kssd_carry_ok(P)) {
-                    // what the scanning lane hands over (the neighbouring lane's last word in front of its own) must give
-                    // the k-mer the packed stream holds
-                    const uint32_t Wm1 = (c * 256 + lane * 4) ? packed[c * 256 + lane * 4 - 1] : 0u;
+                    // what the Bloom round's lane cuts out of the three packed words around the candidate's position must give
+                    // the pattern the scanning lane saw and the k-mer the packed stream holds
+                    const uint64_t p = (uint64_t)(cbeg + lane * 64 + b), wi = p >> 4;
+                    const uint32_t *pp = packed + (wi ? wi - 1 : 0);
                     uint32_t top32, front;
-                    kssd_extract_carry<SUBK>(W, Wm1, (uint32_t)b, top32, front);
+                    kssd_carry_from_words(wi ? pp[0] : 0u, wi ? pp[1] : pp[0], wi ? pp[2] : pp[1], (uint32_t)p & 15u, top32, front);
                     if ((top32 >> (32 - 4 * SUBK)) != kssd_extract_m<SUBK>(W, (uint32_t)b)) { n_cand[0] = ~0ull; return; }
                     const int64_t b0 = cbeg + lane * 64 + b - P.out;
                     if (b0 >= 0) {
