@@ -597,3 +597,27 @@ def test_large_genomes_sorted_by_ranges_of_their_keys():
     finally:
         ctx.close()
         plain.close()
+
+
+def test_chunks_with_more_stage_one_candidates_than_the_buffer_holds(gpu_ctx, shuf_l3k10):
+    """stretches where a large share of the positions passes stage 1: accepted sub-contexts tiled back to back (every twelfth
+    position is a true member, 341 per chunk: more than the wave's 256 buffered positions -- the scan's lane-after-lane
+    path), homopolymers and short tandem repeats next to ordinary sequence, N runs inside; ids against the oracle"""
+    rng = np.random.default_rng(31)
+    acc = np.flatnonzero((shuf_l3k10.table >= 0) & (shuf_l3k10.table < 4096))         # accepted sub-contexts (12 bases = 24 bits)
+    assert len(acc) == 4096
+
+    def bases_of(x):
+        return np.array([(int(x) >> (2 * (11 - i))) & 3 for i in range(12)], dtype=np.uint8)
+    pats = [bases_of(x) for x in rng.choice(acc, 6, replace=False)]
+    tiled = [np.tile(p, 30_000) for p in pats[:3]]                                      # 360 kb each of one pattern back to back
+    mix = np.concatenate([np.tile(pats[3], 2_000), rng.integers(0, 4, 50_000, dtype=np.uint8), np.tile(pats[4], 5_000),
+                          np.zeros(40_000, np.uint8), np.tile(np.array([0, 1], np.uint8), 30_000), np.tile(pats[5], 9_000),
+                          rng.integers(0, 4, 200_000, dtype=np.uint8)])
+    nm = np.zeros(len(mix), dtype=bool)
+    nm[rng.integers(0, len(mix), 60)] = True
+    texts = [fasta_text(t, b"tiled%d" % i) for i, t in enumerate(tiled)] + [fasta_text(mix, b"mix", n_mask=nm),
+                                                                            fasta_text(rng.integers(0, 4, 300_000, dtype=np.uint8), b"plain")]
+    check(gpu_ctx, shuf_l3k10, texts, flags=K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+    st1, bl = gpu_ctx.scan_stats()
+    assert st1 > 0.05 * sum(len(t) for t in tiled)                                     # the dense path really ran
