@@ -246,11 +246,11 @@ KSSD_HD void kssd_stage1g(const uint32_t (&Wd)[5], T1PTR T1, uint32_t &cand_lo, 
 
 // ---------------------------------------------------------------------------------------------------
 // Stage 1.5: exact-pattern Bloom test of the few candidates stage 1 lets through.  Stage 1 only proves that
-// each alignment agrees with SOME pattern of S; 94 % of its candidates are not in S at all.  The lane that owns
-// the candidate still holds the bases in registers, so the 2*subk-base pattern m is cut out of them (no memory
-// access) and looked up in a blocked Bloom filter of S in LDS: one 32-bit word per lookup, 3 bits per pattern,
-// 16 bits of filter per pattern -> ~1.6 % false positives.  What survives (~0.06 % of the positions, half of
-// them true samples) is all that ever reaches the exact stage 2 and its global-memory reads.
+// each alignment agrees with SOME pattern of S; 94 % of its candidates are not in S at all.  Candidates are buffered as
+// positions; the lane that takes one into a dense round of 64 fetches the packed words around it (kssd_carry_from_words),
+// and the 2*subk-base pattern m on top of them is looked up in a blocked Bloom filter of S in LDS: one 32-bit word per
+// lookup, 3 bits per pattern, 16 bits of filter per pattern -> ~1.6 % false positives.  What survives (~0.06 % of the
+// positions, half of them true samples) is all that ever reaches the exact stage 2 and its global-memory reads.
 // ---------------------------------------------------------------------------------------------------
 #define KSSD_BLOOM_WORDS 4096u
 KSSD_HD uint32_t kssd_bloom_hash(uint32_t m) { return m * 0x9E3779B1u; }
