@@ -833,8 +833,8 @@ def self_launch(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--genomes", type=int, default=None, help="genomes per GPU (allpairs: 1000; mammal: as many 3 Gb records as asked, default 8)")
     ap.add_argument("--length", type=int, default=None, help="bases per genome (allpairs: 5 000 000; mammal: 3 000 000 000)")
     ap.add_argument("--clades", type=int, default=50)
