@@ -895,8 +895,8 @@ __global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams 
     const uint32_t n = want < x.cand_cap ? want : (uint32_t)x.cand_cap;
     const uint32_t i0 = blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) + threadIdx.x;
     if (blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) >= n) return;  // whole block past the end of the slice
-    // Same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases out of the scanning
-    // lane's registers (kssd_extract_carry) and whether all of them are known to be bases, so this stage is a streaming
+    // Same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases (the scan's Bloom rounds cut
+    // them out of the packed words: kssd_carry_from_words) and whether all of them are known to be bases, so this stage is a streaming
     // read of 16-byte records plus two probes of the L2-resident cuckoo table; the packed stream is read again only for
     // parameter sets whose k-mer is longer than the 20 carried bases, the mask only for the ~2 % of the candidates near an
     // invalid position.  Out-of-genome k-mers are rejected at the end; their reads stay inside the batch (position clamped
