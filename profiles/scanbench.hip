@@ -230,9 +230,21 @@ int main(int argc, char **argv)
     if (getenv("KSSD_DEV_DEDUPTIME")) {
         std::vector<unsigned long long> t((size_t)G * 4);
         if (kssd_gpu_dev_deduptimes(t.data(), G) == 0) {
+            // (s_memrealtime: 10 ns ticks on one base for the whole chip)
             double a = 0, b = 0, c = 0;
-            for (uint32_t g = 0; g < G; g++) { a += (double)(t[4 * g + 1] - t[4 * g]); b += (double)(t[4 * g + 2] - t[4 * g + 1]); c += (double)(t[4 * g + 3] - t[4 * g + 2]); }
-            printf("per-genome kernel, mean ticks per workgroup: candidates -> keys in LDS %.0f, sort %.0f, runs + keep rules + write %.0f\n", a / G, b / G, c / G);
+            unsigned long long first = ~0ull, last = 0;
+            for (uint32_t g = 0; g < G; g++) {
+                a += (double)(t[4 * g + 1] - t[4 * g]); b += (double)(t[4 * g + 2] - t[4 * g + 1]); c += (double)(t[4 * g + 3] - t[4 * g + 2]);
+                first = std::min(first, t[4 * g]);
+                last = std::max(last, t[4 * g + 3]);
+            }
+            printf("per-genome kernel, mean us per workgroup: candidates -> keys in LDS %.2f, sort %.2f, runs + keep rules + write %.2f\n", a / G / 100, b / G / 100, c / G / 100);
+            std::vector<double> st(G), en(G);
+            for (uint32_t g = 0; g < G; g++) { st[g] = (double)(t[4 * g] - first) / 100; en[g] = (double)(t[4 * g + 3] - first) / 100; }
+            std::sort(st.begin(), st.end());
+            std::sort(en.begin(), en.end());
+            printf("  workgroup starts after the first one (us): median %.2f  p90 %.2f  max %.2f;  ends: median %.2f  p90 %.2f  last %.2f\n", st[G / 2], st[G * 9 / 10],
+                   st[G - 1], en[G / 2], en[G * 9 / 10], (double)(last - first) / 100);
         }
     }
     kssd_gpu_destroy(ctx);

@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
 {
     constexpr bool FUSED = MODE == DEDUP_FUSED;
 #ifdef KSSD_DEV
-    const unsigned long long dev_t0 = __builtin_readcyclecounter();
+    const unsigned long long dev_t0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one base for the whole chip: start skew is visible)
     unsigned long long dev_t1 = 0, dev_t2 = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1549,16 +1549,19 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         n = cursor[g];
     }
 #ifdef KSSD_DEV
-    dev_t1 = __builtin_readcyclecounter();
+    dev_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
     const K *src = MODE != DEDUP_STAGED ? a : regions + r0;
     K *outp = regions + r0;  // where the kept keys go
     if (MODE == DEDUP_PARTS) outp = reinterpret_cast<K *>(px.out) + (((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) + part) * px.part_cap;
     if (MODE == DEDUP_RANGES) outp = reinterpret_cast<K *>(const_cast<void *>(px.parted)) + rng_s0;
-    if (MODE != DEDUP_PARTS && MODE != DEDUP_RANGES && n > cap) {
+    if (MODE != DEDUP_PARTS && MODE != DEDUP_RANGES && (n > cap || n > fx.lds_keys)) {
         if (tid == 0) {
             atomicOr(&st->region_overflow, 1u);
-            unsigned long long need = ((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1);
+            // what the regions must grow by: the key array is 5/8 of the largest region (finish_sketch), and it is the array
+            // that this genome may have outgrown
+            const unsigned long long room = ((unsigned long long)cap * 5ull) / 8ull;
+            unsigned long long need = ((unsigned long long)n * 256ull + room - 1) / (room ? room : 1);
             atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
             kept[g] = 0;
         }
@@ -1602,7 +1605,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     }
     }
 #ifdef KSSD_DEV
-    dev_t2 = __builtin_readcyclecounter();
+    dev_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
     // runs of equal tuples; only the first n entries are real (in first-position mode the first entry of a run is
     // the tuple's first occurrence)
@@ -1650,7 +1653,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         fx.dev_times[blockIdx.x * 4] = dev_t0;
         fx.dev_times[blockIdx.x * 4 + 1] = dev_t1;
         fx.dev_times[blockIdx.x * 4 + 2] = dev_t2;
-        fx.dev_times[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+        fx.dev_times[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     if (tid == 0) {
@@ -2106,8 +2109,14 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
 {
     int rc;
     K *regions = reinterpret_cast<K *>(c->d_regions);
-    uint32_t np = 1;
-    while (np < max_cap) np <<= 1;
+    // The LDS key array of the per-genome workgroups: 5/8 of the largest staging region, rounded up to a power of two -- the
+    // regions are sized at twice the expected emission (region_factor), the array at 1.25 x.  A genome that emits more than the
+    // array holds is reported like one that overflows its region (the call is repeated with larger regions, hence a larger
+    // array).  Sized by the regions themselves the array took 4 096 keys for bacterial genomes that emit 1 220: 56 KB of LDS
+    // per workgroup, TWO workgroups per CU, and a batch of 1 000 genomes ran in two generations (the second started 35 us
+    // late: profiles/r03G_per_genome_occupancy.txt).
+    uint32_t np = 64;
+    while (np < (uint32_t)((max_cap * 5 + 7) / 8)) np <<= 1;
     FuseArgs fx;
     memset(&fx, 0, sizeof fx);
     PartArgs px;
