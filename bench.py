@@ -922,6 +922,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    spinup_done = [0]   # untimed spin-up steps the last measurement made (reported in the line)
+
     def measure(partition):
         """the whole measurement (sizing passes, spin-up, warm-up, the timed steps, the size-independent checks of the result)
         in one partition of the matrix; returns the numbers and rank 0's tensors for the line"""
@@ -1025,8 +1027,27 @@ def main():
             sync()
         # setup, untimed like the sizing passes above: the clocks of an idle GPU need some tens of milliseconds of work to
         # settle (measured: the scan launch takes 0.54 ms in the first dozen steps after a pause and 0.52 ms from then on)
-        run_steps(a.spinup)
-        sync()
+        # ... and a GPU that has just come out of other work (the test suite, a cold box) can sit in a slower state for seconds: the
+        # spin-up goes on in groups of a.spinup steps until two groups in a row take the same time within 0.5 %, for at most ~2.5 s.
+        # All ranks do the same number of groups (the decision is rank 0's time, broadcast by the all-reduce of `sync`-style state).
+        spun = 0
+        if a.spinup > 0:
+            prev = None
+            t_spin = time.perf_counter()
+            while True:
+                tg = time.perf_counter()
+                run_steps(a.spinup)
+                sync()
+                tg = time.perf_counter() - tg
+                spun += a.spinup
+                stable = prev is not None and abs(tg - prev) <= 0.005 * prev
+                stop = torch.tensor([1 if (stable or time.perf_counter() - t_spin > 2.5) else 0], dtype=torch.int32, device=dev)
+                if world > 1:
+                    dist.broadcast(stop, 0)
+                if int(stop.item()):
+                    break
+                prev = tg
+        spinup_done[0] = spun
         run_steps(a.warmup)
         sync()
         for sl in slots:
@@ -1174,7 +1195,7 @@ def main():
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
                        "pairs_per_step": world * pairs, "batches_in_flight": NF,
                        "parallelism": par},
-            "spinup": a.spinup,
+            "spinup": spinup_done[0],
             "pairs_per_s": world * pairs * a.steps / dt,
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
