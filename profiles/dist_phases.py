@@ -53,20 +53,10 @@ for i, nm in enumerate(("start -> ids probed (first pass)", "postings counted (+
     print("  %-40s min %7d  median %7d  mean %9.0f  p90 %7d  max %7d ticks" % (nm, v[0], v[len(v) // 2], v.mean(), v[len(v) * 9 // 10], v[-1]))
 v = np.sort(tot)
 print("  %-40s min %7d  median %7d  mean %9.0f  p90 %7d  max %7d ticks" % ("whole workgroup", v[0], v[len(v) // 2], v.mean(), v[len(v) * 9 // 10], v[-1]))
-print("  (ticks: shader clock)")
-# start skew and span per XCD (time stamps of different XCDs do not share a base: workgroups are grouped by their start
-# stamps, a gap of more than 200 000 ticks separates two XCDs)
-order = np.argsort(t[:, 0])
-groups, cur = [], [order[0]]
-for i in order[1:]:
-    if t[i, 0] - t[cur[-1], 0] > 200_000:
-        groups.append(cur)
-        cur = []
-    cur.append(i)
-groups.append(cur)
-for gi, grp in enumerate(groups):
-    tt = t[grp]
-    base = tt[:, 0].min()
-    st = np.sort(tt[:, 0] - base)
-    print("  clock domain %d (%4d workgroups): starts after the first one: median %6d  p90 %6d  max %6d; last workgroup done at %6d ticks"
-          % (gi, len(grp), st[len(st) // 2], st[len(st) * 9 // 10], st[-1], tt[:, 3].max() - base))
+print("  (ticks: 10 ns)")
+# start skew and span (s_memrealtime: 10 ns ticks on one base for the whole chip)
+base = t[:, 0].min()
+st = np.sort(t[:, 0] - base) / 100.0
+en = np.sort(t[:, 3] - base) / 100.0
+print("  workgroup starts after the first one (us): median %.2f  p90 %.2f  max %.2f;  ends: median %.2f  p90 %.2f  last %.2f"
+      % (st[len(st) // 2], st[len(st) * 9 // 10], st[-1], en[len(en) // 2], en[len(en) * 9 // 10], en[-1]))
