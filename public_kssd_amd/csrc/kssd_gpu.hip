@@ -1472,6 +1472,12 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
             const uint32_t before = block_excl_scan(cw, wsum, total);
             s_pref[tid] = before;
             s_first[tid] = first;
+            // which block a flattened record index belongs to: a table of owners in the LDS room the sort uses later (2 bytes per
+            // record; the nine-step search of the prefix array per record otherwise: 36 dependent LDS reads per thread and round)
+            uint16_t *owner = reinterpret_cast<uint16_t *>(a + fx.lds_keys);
+            const bool owned = total <= fx.bsort_keys * (uint32_t)(sizeof(K) / 2);
+            if (owned)
+                for (uint32_t j = 0; j < cw; j++) owner[before + j] = (uint16_t)tid;
             __syncthreads();
             for (uint32_t f0 = 0; f0 < total; f0 += DEDUP_THREADS * FUSE_PER) {
                 bool ok[FUSE_PER];
@@ -1484,11 +1490,16 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                     ok[j] = f < total;
                     cd[j] = make_ulonglong2(0ull, 0ull);
                     if (ok[j]) {
-                        uint32_t lo = 0, hi = DEDUP_THREADS - 1;  // last block s with s_pref[s] <= f
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi + 1) >> 1;
-                            if (s_pref[mid] <= f) lo = mid;
-                            else hi = mid - 1;
+                        uint32_t lo = 0;
+                        if (owned) {
+                            lo = owner[f];
+                        } else {
+                            uint32_t hi = DEDUP_THREADS - 1;  // last block s with s_pref[s] <= f
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi + 1) >> 1;
+                                if (s_pref[mid] <= f) lo = mid;
+                                else hi = mid - 1;
+                            }
                         }
                         cd[j] = fx.cand[s_first[lo] + (f - s_pref[lo])];
                     }
