@@ -621,3 +621,43 @@ def test_chunks_with_more_stage_one_candidates_than_the_buffer_holds(gpu_ctx, sh
     check(gpu_ctx, shuf_l3k10, texts, flags=K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
     st1, bl = gpu_ctx.scan_stats()
     assert st1 > 0.05 * sum(len(t) for t in tiled)                                     # the dense path really ran
+
+
+@pytest.mark.parametrize("params", [(10, 6, 3), (11, 6, 3), (10, 7, 5), (8, 4, 1)])
+def test_lengths_around_chunk_and_block_borders(params):
+    """batches of genomes whose lengths sit on and around the scan's borders (a packed word, the k-mer, a chunk of 4 096, a
+    block of four chunks), with tandem repeats, scattered Ns and long N runs, tiny and empty genomes -- whole tuples against
+    the oracle (profiles/fuzz_sketch.py is the long version of this)"""
+    k, s, l = params
+    shuf = K.Shuf.generate(k, s, l, seed=77 + k)
+    sk = ko.Sketcher(shuf.table, k, s, l)
+    cb = 4 * max(k - l - 7, 0)
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        for seed in range(4):
+            rng = np.random.default_rng(100 * k + seed)
+            texts = []
+            for g in range(10):
+                n = int(rng.choice([0, 1, 15, 16, 17, 2 * k - 1, 2 * k, 4095, 4096, 4097, 16383, 16384, 16385, 65536, int(rng.integers(100, 300_000))]))
+                codes = rng.integers(0, 4, n, dtype=np.uint8)
+                kind = int(rng.integers(0, 4))
+                if kind == 1 and n > 100:
+                    codes = np.tile(codes[: int(rng.integers(1, 50))], n)[:n]
+                nm = np.zeros(n, dtype=bool)
+                if kind == 2 and n:
+                    nm[rng.integers(0, n, max(1, n // 500))] = True
+                if kind == 3 and n > 50:
+                    a = int(rng.integers(0, n - 10))
+                    nm[a:a + int(rng.integers(1, 9000))] = True
+                texts.append(fasta_text(codes, b"g%d" % g, n_mask=nm if nm.any() else None))
+            b = K.Batch()
+            for t in texts:
+                b.add_fasta(t)
+            off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+            for g, t in enumerate(texts):
+                wi, wc = sk.fasta(t, with_comps=True)
+                want = np.sort((wi.astype(np.uint64) << np.uint64(cb) | wc.astype(np.uint64)).astype(np.uint32))
+                assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want), (params, seed, g, len(t))
+            b.close()
+    finally:
+        ctx.close()
