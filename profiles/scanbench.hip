@@ -238,7 +238,10 @@ int main(int argc, char **argv)
                 first = std::min(first, t[4 * g]);
                 last = std::max(last, t[4 * g + 3]);
             }
-            printf("per-genome kernel, mean us per workgroup: candidates -> keys in LDS %.2f, sort %.2f, runs + keep rules + write %.2f\n", a / G / 100, b / G / 100, c / G / 100);
+            if (getenv("KSSD_DEV_GATHERSPLIT"))
+                printf("per-genome kernel, mean us per workgroup: block table + owners %.2f, first round of records %.2f, further rounds %.2f\n", a / G / 100, b / G / 100, c / G / 100);
+            else
+                printf("per-genome kernel, mean us per workgroup: candidates -> keys in LDS %.2f, sort %.2f, runs + keep rules + write %.2f\n", a / G / 100, b / G / 100, c / G / 100);
             std::vector<double> st(G), en(G);
             for (uint32_t g = 0; g < G; g++) { st[g] = (double)(t[4 * g] - first) / 100; en[g] = (double)(t[4 * g + 3] - first) / 100; }
             std::sort(st.begin(), st.end());

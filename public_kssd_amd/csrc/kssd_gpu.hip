@@ -1286,7 +1286,8 @@ struct FuseArgs {
     uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
     uint32_t id_bits, bsort_keys;      // ids are below 2^id_bits (roughly); bsort_keys: key slots of the bucket sort's LDS arrays (0: none)
 #ifdef KSSD_DEV
-    unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memtime)
+    unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memrealtime)
+    uint32_t dev_split;
 #endif
 };
 #define FUSE_PER 4  // candidates a thread evaluates at a time (six spill at 64 VGPRs)
@@ -1330,7 +1331,8 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     constexpr bool FUSED = MODE == DEDUP_FUSED;
 #ifdef KSSD_DEV
     const unsigned long long dev_t0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one base for the whole chip: start skew is visible)
-    unsigned long long dev_t1 = 0, dev_t2 = 0;
+    unsigned long long dev_t1 = 0, dev_t2 = 0, dev_tA = 0, dev_tB = 0;
+    const bool dev_split = fx.dev_split != 0;  // KSSD_DEV_GATHERSPLIT: the four stamps are start, block table in, first round done, keys in LDS
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K *a = reinterpret_cast<K *>(smem);
@@ -1479,6 +1481,9 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
             if (owned)
                 for (uint32_t j = 0; j < cw; j++) owner[before + j] = (uint16_t)tid;
             __syncthreads();
+#ifdef KSSD_DEV
+            if (!dev_tA) dev_tA = __builtin_amdgcn_s_memrealtime();
+#endif
             for (uint32_t f0 = 0; f0 < total; f0 += DEDUP_THREADS * FUSE_PER) {
                 bool ok[FUSE_PER];
                 ulonglong2 cd[FUSE_PER];
@@ -1551,6 +1556,9 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                         }
                     }
                 }
+#ifdef KSSD_DEV
+                if (!dev_tB) dev_tB = __builtin_amdgcn_s_memrealtime();
+#endif
             }
             __syncthreads();  // s_pref is rewritten by the next round of slices
         }
@@ -1662,9 +1670,9 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
 #ifdef KSSD_DEV
     if ((FUSED || MODE == DEDUP_RANGES) && fx.dev_times && tid == 0 && blockIdx.x < 65536) {
         fx.dev_times[blockIdx.x * 4] = dev_t0;
-        fx.dev_times[blockIdx.x * 4 + 1] = dev_t1;
-        fx.dev_times[blockIdx.x * 4 + 2] = dev_t2;
-        fx.dev_times[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        fx.dev_times[blockIdx.x * 4 + 1] = dev_split ? dev_tA : dev_t1;
+        fx.dev_times[blockIdx.x * 4 + 2] = dev_split ? dev_tB : dev_t2;
+        fx.dev_times[blockIdx.x * 4 + 3] = dev_split ? dev_t1 : __builtin_amdgcn_s_memrealtime();
     }
 #endif
     if (tid == 0) {
@@ -2161,6 +2169,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         fx.lds_keys = np;
 #ifdef KSSD_DEV
         fx.dev_times = n_genomes <= 65536 ? dev_dedup_times() : nullptr;
+        fx.dev_split = getenv("KSSD_DEV_GATHERSPLIT") ? 1u : 0u;
 #endif
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
