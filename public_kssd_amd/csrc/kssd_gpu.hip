@@ -400,6 +400,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
     return v;
 }
 
+__global__ void status_reset_kernel(uint32_t *__restrict__ status_words)
+{
+    if (threadIdx.x < sizeof(SketchStatus) / 4) status_words[threadIdx.x] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // kernel 0: chunk -> genome map
 // ---------------------------------------------------------------------------------------------------
@@ -2470,6 +2475,13 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
             c->dev_med = c->h_med;  // (the copy reads dev_med: it stays as it is until the next plan that differs)
             HIPCK(hipMemcpyAsync(c->d_med, c->dev_med.data(), c->dev_med.size() * sizeof(uint2), hipMemcpyHostToDevice, s));
         }
+    }
+    if (c->h_big.empty() && c->h_med.empty()) {
+        // every genome goes through the fused per-genome kernel: nobody reads the chunk -> genome map, the cursors or the slices'
+        // counts (the scan writes every one of them) -- only the status words have to start at zero
+        hipLaunchKernelGGL(status_reset_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t *>(c->d_status));
+        HIPCK(hipGetLastError());
+        return KSSD_OK;
     }
     uint64_t init_n = pl.n_chunks > pl.n_genomes ? pl.n_chunks : pl.n_genomes;
     if (init_n < pl.n_slices) init_n = pl.n_slices;
