@@ -75,6 +75,11 @@ def test_sixteen_passes_give_the_references_tuples():
     ctx = K.GpuCtx(shuf, 0)
     try:
         assert ctx.tuple_passes() == 16
+        ctx._last_n = 0
+        with pytest.raises(K.KssdError):          # nothing sketched yet: there is no batch to go over again
+            ctx.sketch_again()
+        with pytest.raises(K.KssdError):
+            ctx.set_tuple_pass(16)
         b = K.Batch()
         for nm in names:
             b.add_fasta(texts[nm])
