@@ -1324,6 +1324,8 @@ enum { DEDUP_STAGED = 0, DEDUP_FUSED = 1, DEDUP_PARTS = 2, DEDUP_RANGES = 3 };
 #define RNG_T 1024u             // span of the partitioned array an item begins in
 #define RNG_BIN_MEAN 512u      // keys per bin aimed at
 #define RNG_MAX_LOG2_BINS 14u
+#define RNG_BSORT_KEYS 2048u    // bucket-sort arrays of an item (items of up to 2 048 keys, nearly all of them): 33 KB of LDS per workgroup,
+                                // four per CU, instead of 49 KB and three (configs[3] step -0.7 %); larger items take the bitonic sort
 #define RNG_PART_CAP 4096u      // keys an item may hold (its LDS array): RNG_T + the largest bin, i.e. a bin six times the mean
 
 template <typename K, int MODE>
@@ -2274,6 +2276,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
                 rf.id_bits = lead_bits;
                 rf.lds_keys = RNG_PART_CAP;
                 rf.bsort_keys = bsort_slots(RNG_PART_CAP);
+                if (rf.bsort_keys > RNG_BSORT_KEYS) rf.bsort_keys = RNG_BSORT_KEYS;
 #ifdef KSSD_DEV
                 rf.dev_times = dev_dedup_times();  // (per item here)
 #endif
