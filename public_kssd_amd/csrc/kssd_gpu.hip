@@ -166,6 +166,7 @@ struct kssd_gpu_ctx {
     unsigned long long *d_hdr_pre = nullptr, *d_hdr_out = nullptr;
     size_t cap_hdr_cnt = 0, cap_hdr_pre = 0, cap_hdr_out = 0;
     bool resident_valid = false;  // the last sketch call was a host-level one: its batch is in d_in_packed / d_in_mask (kssd_gpu_sketch_again)
+    uint32_t ranges_off_calls = 0;  // successful calls the switch below still lasts for
     bool ranges_off = false; // a batch of this context has shown keys that do not spread over id ranges: large genomes take the global-memory sort
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
     bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
@@ -2703,6 +2704,7 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
     }
     if (st.ranges_skew && !st.region_overflow) {
         c->ranges_off = true;
+        c->ranges_off_calls = 4;  // the repeated call and the further passes callers make over the same batch (occurrences, abundances)
         return KSSD_ERR_OVERFLOW;
     }
     if (st.region_overflow) {
@@ -2717,6 +2719,7 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
         const double f = c->region_factor * ((double)st.max_need_q8 / 256.0) * 2.0;
         c->region_factor = f > 2.0 ? f : 2.0;
     }
+    if (c->ranges_off && c->ranges_off_calls && --c->ranges_off_calls == 0) c->ranges_off = false;  // later batches try the ranges again
     if (st.capacity_genome_p1) {
         if (bad_genome) *bad_genome = (int64_t)(0xFFFFFFFFu - st.capacity_genome_p1);
         return KSSD_ERR_CAPACITY;
