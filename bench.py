@@ -1003,11 +1003,12 @@ def main():
                 index_build(sl)
                 rows(sl)
                 rc, total, bad = sl.ctx.sketch_status(sl.stream)
-                if rc == 0:
+                irc = sl.ctx.index_status(sl.stream)        # (a capped index build that overflowed: the next one counts first)
+                if rc == 0 and irc == 0:
                     sl.idx_bound = min(cap, int(total) + 1024)
                     break
-                if rc != K.capi.ERR_OVERFLOW:
-                    raise SystemExit("sketch failed: rc=%d" % rc)
+                if rc not in (0, K.capi.ERR_OVERFLOW) or irc not in (0, K.capi.ERR_OVERFLOW):
+                    raise SystemExit("sketch / index failed: rc=%d, %d" % (rc, irc))
             else:
                 raise SystemExit("sketch kept overflowing")
         sync()
@@ -1071,6 +1072,32 @@ def main():
             dist_n += n
         scan_ms = scan_ms / scan_n if scan_n else 0.0       # average launch duration over every timed launch
         dist_ms = dist_ms / dist_n if dist_n else 0.0
+        for sl in slots:
+            if sl.ctx.index_status(sl.stream) != 0:
+                raise SystemExit("index status after the timed loop: the build overflowed")
+
+        # The distance half alone, timed the same way (same warm-up, same number of steps, barrier + synchronize on both sides,
+        # max over ranks): index build + the rank's rows on the sketches that are resident from the steps above -- what
+        # `kssd dist -r` does once stage I is through (command_dist.c:763-790).  N > 1: the exchange is part of it.
+        def run_dist(n):
+            sl = slots[0]
+            for _ in range(n):
+                index_build(sl)
+                rows(sl)
+        run_dist(a.warmup)
+        sync()
+        slots[0].ctx.kernel_time(1, reset=True)
+        t0 = time.perf_counter()
+        run_dist(a.steps)
+        sync()
+        dt_dist = time.perf_counter() - t0
+        dist_only_ms, dist_only_n = slots[0].ctx.kernel_time(1)
+        if slots[0].ctx.index_status(slots[0].stream) != 0:
+            raise SystemExit("index status after the distance loop: the build overflowed")
+        tmax = torch.tensor([dt_dist], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_dist = float(tmax.item())
         ctx, stream = slots[0].ctx, slots[0].stream
         off_l, ids_l, shared = slots[0].off_l, slots[0].ids_l, slots[0].shared
         n_stage1, n_bloom = ctx.scan_stats(stream)
@@ -1145,7 +1172,8 @@ def main():
             own = sh[rank * G:(rank + 1) * G, :]
         assert torch.equal(own.diagonal(), szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
         assert torch.equal(own, own.t()), "all-pairs shared-count matrix must be symmetric"
-        res = dict(dt=dt, scan_ms=scan_ms, dist_ms=dist_ms, scan_n=scan_n, dist_n=dist_n, total=int(total), n_stage1=n_stage1,
+        res = dict(dt=dt, dt_dist=dt_dist, dist_only_ms=dist_only_ms, dist_only_n=dist_only_n,
+                   scan_ms=scan_ms, dist_ms=dist_ms, scan_n=scan_n, dist_n=dist_n, total=int(total), n_stage1=n_stage1,
                    n_bloom=n_bloom, exchange_us=exchange_us, unit=unit, scan_alone_ms=scan_alone_ms, checksum=checksum,
                    off=off_l.cpu().numpy(), ids=ids_l.cpu().numpy().view(np.uint32))
         for sl in slots:
@@ -1197,6 +1225,8 @@ def main():
                        "parallelism": par},
             "spinup": spinup_done[0],
             "pairs_per_s": world * pairs * a.steps / dt,
+            "pairs_per_s_dist": world * pairs * a.steps / m["dt_dist"],
+            "dist_ms_per_step": m["dt_dist"] / a.steps * 1e3,
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
             "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [m["scan_n"], m["dist_n"]],
@@ -1206,6 +1236,16 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_launch": scan_bytes},
+            # the distance half as its own quantity (BASELINE's metric names two rates): `pairs_per_s_dist` above is its
+            # whole-job rate (index build + rows, `steps` timed passes), this is its dominant kernel against the same roofline:
+            # 36 B per pair written (4 B shared count + four f64 metrics) + 4 B per query and reference id read
+            "roofline_dist": {"bound": "hbm", "kernel": "dist_rows_kernel",
+                              "achieved": dist_bytes / (m["dist_only_ms"] * 1e-3) / 1e9 if m["dist_only_ms"] > 0 else 0.0,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": dist_bytes / (m["dist_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if m["dist_only_ms"] > 0 else 0.0,
+                              "traffic": None, "traffic_source": None,
+                              "algorithmic_bytes_per_launch": dist_bytes, "launch_ms": m["dist_only_ms"],
+                              "launches_timed": m["dist_only_n"]},
         }
         if world > 1:
             res["backend"] = backend
@@ -1238,12 +1278,22 @@ def main():
             if "reference_gz" in cb:
                 res["cpu_baseline_gz"] = cb["reference_gz"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and G == 1000 and L == 5_000_000:  # the PMC passes were collected on the default workload
+        if os.path.exists(pmc) and G == 1000 and L == 5_000_000 and world == 1:  # the PMC passes were collected on the default workload
+            # counters cannot be collected inside a timed run: the figures are RECORDED by profiles/pmc_refresh.py, which stamps
+            # them with a hash of the kernel sources they were measured on -- sources that have changed since: no figure
             try:
                 pj = json.load(open(pmc))
-                res["roofline"]["traffic"] = pj.get("sketch_scan_bytes_per_launch")
-                res["roofline"]["traffic_source"] = ("RECORDED, not measured by this run: profiles/pmc_traffic.json (rocprofv3 --pmc "
-                                                     "FETCH_SIZE pass of %s, kernel source %s)" % (pj.get("tag", "?"), pj.get("source_commit", "?")))
+                if pj.get("source_sha") == K.capi.kernel_source_sha():
+                    src = ("RECORDED, not measured by this run: profiles/pmc_traffic.json (rocprofv3 --pmc passes of %s, "
+                           "(FETCH_SIZE x 2 + WRITE_SIZE) x 1024 per launch, kernel sources %s)" % (pj.get("tag", "?"), pj["source_sha"][:12]))
+                    res["roofline"]["traffic"] = pj.get("sketch_scan_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = src
+                    res["roofline_dist"]["traffic"] = pj.get("dist_rows_bytes_per_launch")
+                    res["roofline_dist"]["traffic_source"] = src
+                else:
+                    res["roofline"]["traffic_source"] = res["roofline_dist"]["traffic_source"] = (
+                        "none: profiles/pmc_traffic.json was recorded on other kernel sources (%s, now %s): run profiles/pmc_refresh.py"
+                        % (str(pj.get("source_sha"))[:12], K.capi.kernel_source_sha()[:12]))
             except Exception:
                 pass
         if a.cpu_sample and world == 1 and NF == 1 and not os.environ.get("KSSD_BENCH_NO_PIPELINED"):

@@ -303,6 +303,17 @@ void kssd_gpu_host_free(void *p);
  */
 int kssd_gpu_index_build_device(kssd_gpu_ctx *ctx, const uint64_t *d_roff, const uint32_t *d_rids,
                                 uint32_t n_ref, uint64_t max_ref_ids, void *stream);
+/*
+ * Synchronises `stream` and reports on the last kssd_gpu_index_build_device -- the counterpart of kssd_gpu_sketch_status.
+ * The ordinary build gives every bucket of the hash the same room (no counting pass: two launches, and the search finds a
+ * bucket's slots from its number alone); ids that do not spread over the buckets -- crafted ones, a database of hundreds of
+ * near-identical genomes -- overflow a bucket: KSSD_ERR_OVERFLOW, the index in place is not whole (kssd_gpu_dist_device
+ * computes nothing on it), and every later build of this context counts first (the exact build: four launches, one
+ * descriptor per bucket).  Call kssd_gpu_index_build_device again.  The host-level searches do all of this themselves.
+ * kssd_gpu_index_set_exact(ctx, 1) asks for the exact build up front (a tuning / test knob: results do not depend on it).
+ */
+int kssd_gpu_index_status(kssd_gpu_ctx *ctx, void *stream);
+int kssd_gpu_index_set_exact(kssd_gpu_ctx *ctx, int exact);
 
 /*
  * Tuning knob for searches whose query rows mostly MISS the index (the foreign rows of the multi-GPU all-pairs

@@ -45,6 +45,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_tokenise_fastq_device", "kssd_gpu_tokenise_fastq_status", "kssd_gpu_sketch_fastq_text",
     "kssd_gpu_text_reserve", "kssd_gpu_text_put", "kssd_gpu_text_wait", "kssd_gpu_concat_units_device",
     "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts", "kssd_gpu_tuple_passes", "kssd_gpu_set_tuple_pass", "kssd_gpu_sketch_again",
+    "kssd_gpu_index_status", "kssd_gpu_index_set_exact",
 ]
 
 
@@ -91,6 +92,19 @@ _host = None
 DEFAULT_LDS_SORT_LIMIT = 0  # tests: kssd_gpu_set_lds_sort_limit for every new GpuCtx (0 = the library's default)
 
 
+def kernel_source_sha():
+    """sha256 over the device sources (csrc/*, sorted by name): what recorded counter figures are stamped with
+    (profiles/pmc_refresh.py writes it, bench.py compares) -- the GPU box has no git history to ask"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(HERE, "csrc")
+    for nm in sorted(os.listdir(d)):
+        if nm.endswith((".hip", ".inc", ".h")):
+            h.update(nm.encode())
+            h.update(open(os.path.join(d, nm), "rb").read())
+    return h.hexdigest()
+
+
 def gpu_lib():
     """libkssd_gpu.so; raises if it has not been built (no fallback exists)."""
     global _gpu
@@ -123,6 +137,8 @@ def gpu_lib():
         L.kssd_gpu_free.argtypes = [vp]
         L.kssd_gpu_free.restype = None
         L.kssd_gpu_index_build_device.argtypes = [vp, vp, vp, u32, u64, vp]
+        L.kssd_gpu_index_status.argtypes = [vp, vp]
+        L.kssd_gpu_index_set_exact.argtypes = [vp, i32]
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
@@ -201,11 +217,11 @@ def host_lib():
         L.kssd_sketchset_release.argtypes = [C.POINTER(_SketchSet)]
         L.kssd_sketchset_release.restype = None
         L.kssd_slot_order_pos64.argtypes = [vp, vp, u64, u32]
-        L.kssd_slot_order_pos64.restype = None
+        L.kssd_slot_order_pos64.restype = C.c_int
         L.kssd_slot_order.argtypes = [vp, u64, u32]
-        L.kssd_slot_order.restype = None
+        L.kssd_slot_order.restype = C.c_int
         L.kssd_slot_order_pos.argtypes = [vp, vp, u64, u32]
-        L.kssd_slot_order_pos.restype = None
+        L.kssd_slot_order_pos.restype = C.c_int
         L.kssd_sketchset_write.argtypes = [C.POINTER(_SketchSet), C.c_char_p, u32, i32]
         L.kssd_sketchset_read.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
         L.kssd_index_write.argtypes = [C.POINTER(_SketchSet), C.c_char_p]
@@ -286,7 +302,7 @@ def slot_order_pos64(tuples, first_pos, hashsize):
     """tuples of more than 32 bits (k - drlevel = 9) in the reference's file order (kssd_slot_order_pos64)"""
     t = np.ascontiguousarray(tuples, dtype=np.uint64).copy()
     p = np.ascontiguousarray(first_pos, dtype=np.uint32)
-    host_lib().kssd_slot_order_pos64(t.ctypes.data, p.ctypes.data, len(t), hashsize)
+    _hck(host_lib().kssd_slot_order_pos64(t.ctypes.data, p.ctypes.data, len(t), hashsize))
     return t
 
 
@@ -384,13 +400,13 @@ def slot_order_pos(ids, first_pos, hashsize):
     """ids of one genome in the reference's file order, insertions replayed in sequence order"""
     a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
     p = np.ascontiguousarray(first_pos, dtype=np.uint32)
-    host_lib().kssd_slot_order_pos(a.ctypes.data, p.ctypes.data, len(a), hashsize)
+    _hck(host_lib().kssd_slot_order_pos(a.ctypes.data, p.ctypes.data, len(a), hashsize))
     return a
 
 
 def slot_order(ids, hashsize):
     a = np.ascontiguousarray(ids, dtype=np.uint32).copy()
-    host_lib().kssd_slot_order(a.ctypes.data, len(a), hashsize)
+    _hck(host_lib().kssd_slot_order(a.ctypes.data, len(a), hashsize))
     return a
 
 
@@ -758,6 +774,13 @@ class GpuCtx:
 
     def index_build_device(self, d_roff, d_rids, n_ref, max_ref_ids, stream=None):
         _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
+
+    def index_status(self, stream=None):
+        """synchronises the stream; 0, or ERR_OVERFLOW when the (capped) build in place met a bucket fuller than its run: build again"""
+        return gpu_lib().kssd_gpu_index_status(self.h, stream)
+
+    def index_set_exact(self, exact=True):
+        _gck(gpu_lib().kssd_gpu_index_set_exact(self.h, 1 if exact else 0))
 
     def dist_device(self, d_qoff, d_qids, n_qry, q_begin, q_end, d_shared, d_j=None, d_m=None, d_c=None, d_a=None,
                     stream=None, max_row_ids=0):

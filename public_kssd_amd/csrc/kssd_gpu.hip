@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -135,6 +136,15 @@ struct kssd_gpu_ctx {
     } plan;
     std::vector<uint64_t> h_chunk_off;      // the planned batch's chunk offsets
     std::vector<uint64_t> dev_chunk_off, dev_reg_off;  // what d_chunk_off / d_reg_off hold (copies are skipped when unchanged)
+    struct {  // the last scan: candidate list and staging layout a further tuple pass has to find as they were
+        bool valid = false, fused = false;
+        const void *cand = nullptr, *blk_info = nullptr;
+        uint64_t cand_cap = 0, n_chunks = 0;
+        uint32_t n_slices = 0;
+        std::vector<uint64_t> reg_off;
+        std::vector<uint2> med;
+        std::vector<uint32_t> big;
+    } scanned;
     // device-side buffers of the host-level sketch call (kssd_gpu_sketch_batch): grow-only
     uint32_t *d_in_packed, *d_in_mask, *d_b_ids, *d_b_pos;
     uint64_t *d_b_off;
@@ -149,6 +159,10 @@ struct kssd_gpu_ctx {
     uint32_t *d_ref_sz;     // n_ref sketch sizes
     uint32_t *d_hkeys;      // the bucketed table: 16-byte slots (IdxSlot)
     uint32_t h_log2;        // log2 of the number of buckets
+    uint32_t idx_lg_cap = 0;      // capped build in place: log2 of every bucket's slots (0: exact build, descriptors)
+    uint32_t idx_serial = 0;      // number of the build in place
+    uint32_t *d_idx_flag = nullptr;  // serial of the last capped build that met a bucket fuller than its run
+    bool idx_exact = false;       // builds of this context count first (a capped build of it has overflowed, or the caller asked)
     uint32_t *d_bkt;        // per bucket: counters | starts | cursors | descriptors (kssd_dist.inc)
     size_t cap_bkt;
     // device tokeniser (kssd_tok.inc)
@@ -198,7 +212,7 @@ static int ctx_upload_tables(kssd_gpu_ctx *c, const std::vector<uint32_t> &accep
     std::vector<uint8_t> T1;
     std::vector<uint32_t> bloom;
     std::vector<KssdG> G;
-    kssd_build_tables(P, accepted, KSSD_GW, T1, bloom, G);
+    if (!kssd_build_tables(P, accepted, KSSD_GW, T1, bloom, G)) return KSSD_ERR_PARAM;
     const size_t gn = G.size();
     HIPCK(hipMalloc(&c->d_T1, SCAN_TAB_BYTES));
     HIPCK(hipMalloc(&c->d_G, gn * sizeof(KssdG)));
@@ -216,6 +230,13 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
     if (prc == -1) return KSSD_ERR_PARAM;
     if (prc == -2) return KSSD_ERR_UNSUPPORTED;
     if (accepted.size() != P.dim_end) return KSSD_ERR_PARAM;
+    {   // accepted[] is a set of sub-contexts: every value below 16^subk, none twice (a compact form from a damaged cache file)
+        std::vector<uint32_t> sorted(accepted);
+        std::sort(sorted.begin(), sorted.end());
+        if ((uint64_t)sorted.back() >= (1ull << (4 * P.subk))) return KSSD_ERR_PARAM;
+        for (size_t i = 1; i < sorted.size(); i++)
+            if (sorted[i] == sorted[i - 1]) return KSSD_ERR_PARAM;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KSSD_ERR_NO_DEVICE;
     HIPCK(hipSetDevice(device));
@@ -296,7 +317,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag};
     for (void *p : ptrs)
         if (p) hipFree(p);
     free(c->tok_args_saved);
@@ -401,11 +422,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
     return v;
 }
 
-__global__ void status_reset_kernel(uint32_t *__restrict__ status_words)
-{
-    if (threadIdx.x < sizeof(SketchStatus) / 4) status_words[threadIdx.x] = 0;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // kernel 0: chunk -> genome map
 // ---------------------------------------------------------------------------------------------------
@@ -463,7 +479,8 @@ struct ScanArgs {
     const uint8_t *tab;             // stage-1 table followed by the Bloom filter (SCAN_TAB_BYTES)
     ulonglong2 *cand;               // (waves of the grid) * cand_cap records {global position, carried k-mer bits}
     unsigned long long cand_cap;    // per wave
-    uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported)
+    uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported by the stage behind the scan)
+    uint32_t *stage1_count;         // per wave: positions that passed stage 1 (telemetry)
     unsigned long long *blk_info;   // per block of SCAN_BLOCK chunks: where its candidates sit in the list (scan_blk_pack)
     SketchStatus *status;
 #ifdef KSSD_DEV
@@ -583,6 +600,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     // loop counter and every counter derived from a ballot live in VGPRs and the loops run on exec masks
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = lane_id();
+    // the call's status words start at zero: every kernel that reports into them runs behind this one on the stream, and the
+    // scan itself reports per wave (cand_count / stage1_count, added up by the stage that follows) -- no reset launch in front
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(SketchStatus) / 4) reinterpret_cast<uint32_t *>(a.status)[threadIdx.x] = 0;
     uint32_t *pbuf = reinterpret_cast<uint32_t *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates (positions, see ScanRound)
     uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
 
@@ -646,7 +666,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
 #ifdef KSSD_DEV
     const unsigned long long dev_t1 = __builtin_readcyclecounter();
 #endif
-    if (b_cur >= n_blocks) return;
+    if (b_cur >= n_blocks) {  // a wave without a block (a batch smaller than the grid): nothing listed
+        if (lane == 0) { a.cand_count[wid] = 0; a.stage1_count[wid] = 0; }
+        return;
+    }
     // whether a lane's neighbours' 64 positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour
     // is not looked at, and neither is lane 0's left one in the first chunk of a block: their candidates -- ~2 % -- let the
     // exact stage read the mask)
@@ -824,13 +847,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
     }
 #endif
     if (lane == 0) {
-        a.cand_count[wid] = stored;
-        if (stored > a.cand_cap) {  // the wave wanted to list more than its slice holds: the call is repeated larger
-            atomicOr(&a.status->cand_overflow, 1u);
-            atomicMax(&a.status->cand_need, stored);
-        }
-        atomicAdd(&a.status->n_stage1, (unsigned long long)n_rounded);
-        atomicAdd(&a.status->n_bloom, (unsigned long long)stored);  // every survivor of a round was counted into `stored`
+        a.cand_count[wid] = stored;  // (more than cand_cap: the slice was too small -- scan_totals reports it, the call is repeated larger)
+        a.stage1_count[wid] = n_rounded;
     }
     if (ABL != 0) {
         for (int i = 0; i < Gp::NMAX; i++) abl_acc ^= raw[i];
@@ -848,6 +866,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
 // (KSSD_SKETCH_FIRST_POS): key = tuple << 32 | position inside the genome, so that the first entry of a run of equal
 // tuples carries the tuple's first occurrence -- what the host needs to replay the reference's hash insertions in
 // sequence order and leave combco.* byte-identical even where two ids of a genome probe the same slot.
+// what the waves of the scan left per slice, added up into the call's status by ONE workgroup of the stage behind the scan
+// (plain stores: no other kernel writes these four words)
+__device__ __forceinline__ void scan_totals(const uint32_t *__restrict__ cand_count, uint32_t n_slices, unsigned long long cand_cap,
+                                            SketchStatus *st, unsigned long long *s_acc /* LDS: 3 words */)
+{
+    const uint32_t *stage1_count = cand_count + n_slices;
+    if (threadIdx.x == 0) s_acc[0] = s_acc[1] = s_acc[2] = 0;
+    __syncthreads();
+    unsigned long long bloom = 0, stage1 = 0, need = 0;
+    for (uint32_t w = threadIdx.x; w < n_slices; w += blockDim.x) {
+        const uint32_t n = cand_count[w];
+        bloom += n;
+        stage1 += stage1_count[w];
+        need = n > need ? n : need;
+    }
+    atomicAdd(&s_acc[0], bloom);
+    atomicAdd(&s_acc[1], stage1);
+    atomicMax(&s_acc[2], need);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->n_bloom = s_acc[0];
+        st->n_stage1 = s_acc[1];
+        if (s_acc[2] > cand_cap) {
+            st->cand_overflow = 1u;
+            st->cand_need = (uint32_t)s_acc[2];
+        }
+    }
+}
+
 template <typename K> struct KeyOps;
 template <> struct KeyOps<uint32_t> {
     static __device__ __forceinline__ uint32_t id(uint32_t k) { return k; }
@@ -894,9 +941,9 @@ __global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams 
     const uint32_t lane = lane_id();
     const uint32_t w = blockIdx.y;
     const uint32_t want = x.cand_count[w];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && want > x.cand_cap) {
-        atomicOr(&x.status->cand_overflow, 1u);
-        atomicMax(&x.status->cand_need, want);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {  // (workgroup-uniform)
+        __shared__ unsigned long long s_acc[3];
+        scan_totals(x.cand_count, x.n_slices, x.cand_cap, x.status, s_acc);
     }
     const uint32_t n = want < x.cand_cap ? want : (uint32_t)x.cand_cap;
     const uint32_t i0 = blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) + threadIdx.x;
@@ -1290,6 +1337,9 @@ struct FuseArgs {
     const uint32_t *packed, *mask;
     const KssdG *G;
     uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
+    const uint32_t *cand_count;        // FUSED: the scan's per-slice counts (workgroup 0 adds them up into the status: scan_totals)
+    uint32_t n_slices;
+    unsigned long long cand_cap;
     uint32_t id_bits, bsort_keys;      // ids are below 2^id_bits (roughly); bsort_keys: key slots of the bucket sort's LDS arrays (0: none)
 #ifdef KSSD_DEV
     unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memrealtime)
@@ -1462,6 +1512,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         __shared__ uint32_t s_n, s_pref[DEDUP_THREADS];
         __shared__ unsigned long long s_first[DEDUP_THREADS];
         const uint32_t lane = lane_id();
+        if (blockIdx.x == 0 && fx.n_slices) scan_totals(fx.cand_count, fx.n_slices, fx.cand_cap, st, s_first);  // (s_first: not in use yet)
         if (tid == 0) s_n = 0;
         const unsigned long long cb = fx.chunk_off[g], ce = fx.chunk_off[g + 1];
         const long long glo = (long long)(cb * KSSD_CHUNK), ghi = (long long)(ce * KSSD_CHUNK);
@@ -2175,6 +2226,9 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         fx.carry = kssd_carry_ok(c->P) ? 1u : 0u;
         fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
         fx.lds_keys = np;
+        fx.cand_count = c->d_cand_count;
+        fx.n_slices = pl.n_chunks ? pl.n_slices : 0u;  // (no chunk, no scan: nothing to add up)
+        fx.cand_cap = pl.cand_cap;
 #ifdef KSSD_DEV
         fx.dev_times = n_genomes <= 65536 ? dev_dedup_times() : nullptr;
         fx.dev_split = getenv("KSSD_DEV_GATHERSPLIT") ? 1u : 0u;
@@ -2445,7 +2499,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
     uint64_t cand_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * (2.0 * rate + 0.0005) * c->cand_factor / n_slices) + 256;
     if (cand_cap < c->cand_floor) cand_cap = c->cand_floor;  // what the fullest slice of an overflowed attempt wanted
     if ((rc = ensure(&c->d_cand, &c->cap_cand, (size_t)cand_cap * n_slices * 2)) != KSSD_OK) return rc;  // 16-byte records
-    if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, (size_t)n_slices)) != KSSD_OK) return rc;
+    if ((rc = ensure(&c->d_cand_count, &c->cap_cand_count, 2 * (size_t)n_slices)) != KSSD_OK) return rc;  // per slice: candidates listed | positions past stage 1
     if ((rc = ensure(&c->d_blk_info, &c->cap_blk_info, (size_t)((n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK) + 1)) != KSSD_OK) return rc;
     c->last_cand_cap = cand_cap;
     pl.big_min = big_min; pl.max_cap = max_cap; pl.max_big = max_big; pl.cand_cap = cand_cap; pl.n_slices = n_slices; pl.grid = grid;
@@ -2481,10 +2535,10 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
         }
     }
     if (c->h_big.empty() && c->h_med.empty()) {
-        // every genome goes through the fused per-genome kernel: nobody reads the chunk -> genome map, the cursors or the slices'
-        // counts (the scan writes every one of them) -- only the status words have to start at zero
-        hipLaunchKernelGGL(status_reset_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t *>(c->d_status));
-        HIPCK(hipGetLastError());
+        // every genome goes through the fused per-genome kernel: nobody reads the chunk -> genome map or the cursors, the scan
+        // writes every slice's counts and zeroes the status words itself -- nothing to launch (a batch without a chunk has no
+        // scan: the status is cleared here)
+        if (pl.n_chunks == 0) HIPCK(hipMemsetAsync(c->d_status, 0, sizeof(SketchStatus), s));
         return KSSD_OK;
     }
     uint64_t init_n = pl.n_chunks > pl.n_genomes ? pl.n_chunks : pl.n_genomes;
@@ -2527,6 +2581,7 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     ScanArgs a;
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
+    a.stage1_count = c->d_cand_count + pl.n_slices;
     a.blk_info = c->d_blk_info;
     a.status = c->d_status;
 #ifdef KSSD_DEV
@@ -2560,7 +2615,31 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     }
     if (rc != KSSD_OK) return rc;
     c->ev_n[0]++;
+    c->scanned.valid = true;  // what a further tuple pass (KSSD_PHASE_REPASS) must find unchanged
+    c->scanned.cand = c->d_cand;
+    c->scanned.blk_info = c->d_blk_info;
+    c->scanned.cand_cap = pl.cand_cap;
+    c->scanned.n_slices = pl.n_slices;
+    c->scanned.n_chunks = pl.n_chunks;
+    c->scanned.fused = c->h_big.empty() && c->h_med.empty();
+    c->scanned.reg_off = c->h_reg_off;
+    c->scanned.med = c->h_med;
+    c->scanned.big = c->h_big;
     return KSSD_OK;
+}
+
+// does the plan in place describe the batch, the candidate list and the staging layout the last scan ran with?
+static bool repass_matches_scan(const kssd_gpu_ctx *c)
+{
+    const auto &pl = c->plan;
+    const auto &sc = c->scanned;
+    if (!pl.valid || !sc.valid || sc.cand != c->d_cand || sc.blk_info != c->d_blk_info || sc.cand_cap != pl.cand_cap ||
+        sc.n_slices != pl.n_slices || sc.n_chunks != pl.n_chunks || sc.reg_off != c->h_reg_off || sc.big != c->h_big ||
+        sc.med.size() != c->h_med.size())
+        return false;
+    for (size_t i = 0; i < sc.med.size(); i++)
+        if (sc.med[i].x != c->h_med[i].x || sc.med[i].y != c->h_med[i].y) return false;
+    return true;
 }
 
 static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
@@ -2610,14 +2689,7 @@ __global__ void repass_reset_kernel(uint32_t *__restrict__ cursor, uint32_t n_ge
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_genomes) cursor[i] = 0;
-    if (i == 0) {
-        st->total_ids = 0;
-        st->region_overflow = 0;
-        st->out_overflow = 0;
-        st->max_need_q8 = 0;
-        st->capacity_genome_p1 = 0;
-        st->ranges_skew = 0;
-    }
+    if (i < sizeof(SketchStatus) / 4) reinterpret_cast<uint32_t *>(st)[i] = 0;  // (the scan's totals are added up again by the stage that follows)
 }
 
 extern "C" int kssd_gpu_sketch_phase(kssd_gpu_ctx *c, int phase, void *stream)
@@ -2631,6 +2703,7 @@ extern "C" int kssd_gpu_sketch_phase(kssd_gpu_ctx *c, int phase, void *stream)
     case KSSD_PHASE_EXACT: return phase_exact(c, s);
     case KSSD_PHASE_FINISH: return phase_finish(c, s);
     case KSSD_PHASE_REPASS:
+        if (!repass_matches_scan(c)) return KSSD_ERR_PARAM;  // the plan is not the scanned batch's any more: PREP + SCAN instead
         if (c->plan.n_genomes)
             hipLaunchKernelGGL(repass_reset_kernel, dim3((c->plan.n_genomes + 255) / 256), dim3(256), 0, s, c->d_cursor, c->plan.n_genomes, c->d_status);
         HIPCK(hipGetLastError());
@@ -2713,13 +2786,15 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
         return KSSD_ERR_OVERFLOW;
     }
     if (st.out_overflow) return KSSD_ERR_OVERFLOW;
-    if (c->region_factor > 2.0 && st.max_need_q8 < 64) {
+    // (36-bit tuples: a pass stages a sixteenth of what the regions are sized for, and the passes 1 .. 15 of a batch run on the
+    // layout tables of its scan -- nothing about the layout may move between them: no shrinking, and only pass 0 counts a call)
+    if (c->region_factor > 2.0 && st.max_need_q8 < 64 && c->P.pass_bits == 0) {
         // the regions were grown for a batch that emitted far more than the sampling rate predicts; this batch filled
         // its fullest region to less than a quarter: shrink towards the default again
         const double f = c->region_factor * ((double)st.max_need_q8 / 256.0) * 2.0;
         c->region_factor = f > 2.0 ? f : 2.0;
     }
-    if (c->ranges_off && c->ranges_off_calls && --c->ranges_off_calls == 0) c->ranges_off = false;  // later batches try the ranges again
+    if (c->ranges_off && c->ranges_off_calls && c->P.pass == 0 && --c->ranges_off_calls == 0) c->ranges_off = false;  // later batches try the ranges again
     if (st.capacity_genome_p1) {
         if (bad_genome) *bad_genome = (int64_t)(0xFFFFFFFFu - st.capacity_genome_p1);
         return KSSD_ERR_CAPACITY;
@@ -2762,8 +2837,11 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
         }
         if (again && attempt == 0) {  // (a retry after an overflow scans again: its workspaces may have moved)
             rc = kssd_gpu_sketch_plan(c, c->d_in_packed, c->d_in_mask, chunk_off, n_genomes, flags, min_occ, c->d_b_off, c->d_b_ids, out_cap);
-            for (int ph : {KSSD_PHASE_REPASS, KSSD_PHASE_EXACT, KSSD_PHASE_FINISH})
-                if (rc == KSSD_OK) rc = kssd_gpu_sketch_phase(c, ph, s);
+            // the pass runs on the candidate list and the layout tables of the batch's scan: a plan that differs from that
+            // scan's (the staging layout has moved since) scans again
+            const bool same = rc == KSSD_OK && repass_matches_scan(c);
+            for (int ph : {same ? KSSD_PHASE_REPASS : KSSD_PHASE_PREP, same ? -1 : KSSD_PHASE_SCAN, KSSD_PHASE_EXACT, KSSD_PHASE_FINISH})
+                if (rc == KSSD_OK && ph >= 0) rc = kssd_gpu_sketch_phase(c, ph, s);
         } else {
             rc = kssd_gpu_sketch_device(c, c->d_in_packed, c->d_in_mask, chunk_off, n_genomes, flags, min_occ, c->d_b_off, c->d_b_ids,
                                         out_cap, s);

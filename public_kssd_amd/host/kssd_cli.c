@@ -450,7 +450,7 @@ static int job_sketch(kssd_gpu_ctx *ctx, job *j, stream_ring *ring, const fileli
                                  min_occ, off, ids, bad);
 }
 
-static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, double *t_call)
+static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, uint32_t hashlimit, double *t_call)
 {
     const double tc0 = now_s();
     const int is_fq = j->is_fq;
@@ -550,7 +550,11 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
             uint64_t m = 0;
             for (uint32_t sp = 0; sp < passes; sp++) m += poff[sp][g + 1] - poff[sp][g];
             moff[g + 1] = moff[g] + m;
-            if (!is_fq && m > (uint64_t)(hashsize * 0.6)) /* keycount > hashlimit over the whole table (iseq2comem.c:261-263; LD_FCTR) */
+            /* keycount > hashlimit over the ONE table of whole tuples (iseq2comem.c:261-263).  The device applies the rule per pass
+             * (a sixteenth of the keys against the whole limit: it never fires first); here the passes' distinct tuples are added
+             * up.  What is not added: the occurrences of the tuple 0 itself, which the reference counts one by one (:255-263) --
+             * they decide only for a genome within a handful of k-mers of 322 million distinct ones. */
+            if (!is_fq && m > (uint64_t)hashlimit)
                 die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + g], o->k + 1);
         }
         uint32_t *mids = malloc((size_t)(moff[n] ? moff[n] : 1) * 4);
@@ -561,13 +565,14 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
             const uint64_t m = moff[g + 1] - moff[g];
             uint64_t *t = malloc((size_t)(m ? m : 1) * 8);
             uint32_t *p = malloc((size_t)(m ? m : 1) * 4);
+            if (!t || !p) die(ENOMEM, "out of memory");
             uint64_t w = 0;
             for (uint32_t sp = 0; sp < passes; sp++)
                 for (uint64_t i = poff[sp][g]; i < poff[sp][g + 1]; i++) {
                     t[w] = ((uint64_t)pids[sp][i] << 4) | sp;
                     p[w++] = ppos[sp][i];
                 }
-            kssd_slot_order_pos64(t, p, m, hashsize);
+            if (kssd_slot_order_pos64(t, p, m, hashsize)) die(ENOMEM, "out of memory");
             for (uint64_t i = 0; i < m; i++) {
                 mids[moff[g] + i] = (uint32_t)(t[i] >> 4);
                 msub[moff[g] + i] = (uint8_t)(t[i] & 15u);
@@ -597,9 +602,11 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
         for (uint32_t g = 0; g < n; g++) {
             const uint64_t m = off[g + 1] - off[g];
             uint8_t *keep = malloc(m ? m : 1);
+            if (!keep) die(ENOMEM, "out of memory");
             for (uint64_t i = 0; i < m; i++) /* both passes list a genome's distinct ids ascending */
                 keep[i] = is_fq ? ccnt[coff[g] + i] >= keep_rule_occ : ccnt[coff[g] + i] == 1;
             koff[g + 1] = kssd_slot_order_pos_keep(ids + off[g], pos + off[g], keep, m, hashsize); /* kept ids to the front, file order */
+            if (koff[g + 1] == UINT64_MAX) die(ENOMEM, "out of memory");
             free(keep);
         }
         uint64_t at = 0;
@@ -630,8 +637,10 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
      * a genome of 2^32 positions and more, in ascending id order: exact unless two of its ids probe the same slot) */
 #pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 16)
     for (uint32_t g = 0; g < n; g++) {
-        if (with_pos > 0) kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], hashsize);
-        else if (with_pos == 0) kssd_slot_order(ids + off[g], off[g + 1] - off[g], hashsize);
+        int orc = 0;
+        if (with_pos > 0) orc = kssd_slot_order_pos(ids + off[g], pos + off[g], off[g + 1] - off[g], hashsize);
+        else if (with_pos == 0) orc = kssd_slot_order(ids + off[g], off[g + 1] - off[g], hashsize);
+        if (orc) die(ENOMEM, "out of memory");
     }
     if (o->abundance) {
         uint16_t *counts = malloc((size_t)(off[n] ? off[n] : 1) * 2);
@@ -670,7 +679,7 @@ typedef struct {
     int n_pool, n_tpool, closed;
     const dist_opt *o;
     filelist *fl;
-    uint32_t hashsize;
+    uint32_t hashsize, hashlimit;
     kssd_shuf_hdr hdr;
     const uint32_t *accepted; /* the .shuf's accepted sub-contexts (load_shuf) */
     uint32_t n_accepted;
@@ -711,7 +720,7 @@ static void *worker_main(void *arg)
         if (!j) break;
         const double t0 = now_s();
         double tcall = 0;
-        process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, &tcall);
+        process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, pl->hashlimit, &tcall);
         const double dt = now_s() - t0;
         if (j->b) kssd_batch_clear(j->b);
         if (j->own_b) kssd_batch_destroy(j->own_b);
@@ -861,6 +870,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pl.o = o;
     pl.fl = fl;
     pl.hashsize = d.hashsize;
+    pl.hashlimit = d.hashlimit;
     pl.hdr = hdr;
     pl.accepted = sc.accepted;
     pl.n_accepted = sc.n_accepted;

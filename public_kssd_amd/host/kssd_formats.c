@@ -81,16 +81,20 @@ static int cmp_pos(const void *a, const void *b)
 /* replay the reference's insertions, in the order given, into a sparse image of its table; ids come back in
  * ascending slot order */
 static uint64_t slot_order_replay_keep(uint32_t *ids, const uint8_t *keep, uint64_t n, uint32_t hashsize);
-static void slot_order_replay(uint32_t *ids, uint64_t n, uint32_t hashsize) { slot_order_replay_keep(ids, NULL, n, hashsize); }
+static int slot_order_replay(uint32_t *ids, uint64_t n, uint32_t hashsize)
+{
+    return slot_order_replay_keep(ids, NULL, n, hashsize) == UINT64_MAX ? KSSD_HOST_ERR_NOMEM : 0;
+}
 
-/* keep != NULL: every id takes its slot, only the ids with keep[i] != 0 come back (their number is returned) */
+/* keep != NULL: every id takes its slot, only the ids with keep[i] != 0 come back (their number is returned; UINT64_MAX:
+ * out of memory, ids untouched) */
 static uint64_t slot_order_replay_keep(uint32_t *ids, const uint8_t *keep, uint64_t n, uint32_t hashsize)
 {
     uint64_t cap = 16;
     while (cap < 4 * n) cap <<= 1;
     uint32_t *occ = malloc(cap * sizeof(uint32_t)); /* open-addressing set of occupied slots, 0xFFFFFFFF = free */
     slot_id *sl = malloc((n ? n : 1) * sizeof(slot_id));
-    if (!occ || !sl) { free(occ); free(sl); return n; }
+    if (!occ || !sl) { free(occ); free(sl); return UINT64_MAX; }
     uint64_t m = 0;
     memset(occ, 0xFF, cap * sizeof(uint32_t));
     const uint64_t S = hashsize;
@@ -143,15 +147,15 @@ static int cmp_slot_key(const void *a, const void *b)
 }
 
 /* tuples beyond 32 bits: the same replay (insertions in sequence order into a sparse image of the reference's table) */
-void kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t n, uint32_t hashsize)
+int kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t n, uint32_t hashsize)
 {
-    if (n < 2) return;
+    if (n < 2) return 0;
     pos_key *pk = malloc(n * sizeof *pk);
     slot_key *sl = malloc(n * sizeof *sl);
     uint64_t cap = 16;
     while (cap < 4 * n) cap <<= 1;
     uint32_t *occ = malloc(cap * sizeof(uint32_t));
-    if (!pk || !sl || !occ) { free(pk); free(sl); free(occ); return; }
+    if (!pk || !sl || !occ) { free(pk); free(sl); free(occ); return KSSD_HOST_ERR_NOMEM; }
     for (uint64_t i = 0; i < n; i++) { pk[i].pos = first_pos[i]; pk[i].key = tuples[i]; }
     qsort(pk, n, sizeof *pk, cmp_pos_key);
     memset(occ, 0xFF, cap * sizeof(uint32_t));
@@ -179,24 +183,25 @@ void kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t
     free(pk);
     free(sl);
     free(occ);
+    return 0;
 }
 
-void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
+int kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
 {
-    if (n < 2) return;
-    slot_order_replay(ids, n, hashsize); /* insertions in ascending id order */
+    if (n < 2) return 0;
+    return slot_order_replay(ids, n, hashsize); /* insertions in ascending id order */
 }
 
-void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize)
+int kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize)
 {
-    if (n < 2) return;
+    if (n < 2) return 0;
     pos_id *pi = malloc(n * sizeof(pos_id));
-    if (!pi) return;
+    if (!pi) return KSSD_HOST_ERR_NOMEM;
     for (uint64_t i = 0; i < n; i++) { pi[i].pos = first_pos[i]; pi[i].id = ids[i]; }
     qsort(pi, n, sizeof(pos_id), cmp_pos); /* first positions are distinct: one k-mer per position */
     for (uint64_t i = 0; i < n; i++) ids[i] = pi[i].id;
     free(pi);
-    slot_order_replay(ids, n, hashsize); /* insertions in sequence order, as fasta2co makes them */
+    return slot_order_replay(ids, n, hashsize); /* insertions in sequence order, as fasta2co makes them */
 }
 
 /* all distinct ids of a genome with their first positions, and which of them the dump keeps: the dropped ones (fastq
@@ -207,12 +212,12 @@ uint64_t kssd_slot_order_pos_keep(uint32_t *ids, const uint32_t *first_pos, cons
     if (n == 0) return 0;
     pos_id *pi = malloc(n * sizeof(pos_id));
     uint8_t *kk = malloc(n);
-    if (!pi || !kk) { free(pi); free(kk); return 0; }
+    if (!pi || !kk) { free(pi); free(kk); return UINT64_MAX; }
     /* sort (position, index) so that the flags follow the ids */
     for (uint64_t i = 0; i < n; i++) { pi[i].pos = first_pos[i]; pi[i].id = (uint32_t)i; }
     qsort(pi, n, sizeof(pos_id), cmp_pos);
     uint32_t *tmp = malloc(n * sizeof(uint32_t));
-    if (!tmp) { free(pi); free(kk); return 0; }
+    if (!tmp) { free(pi); free(kk); return UINT64_MAX; }
     for (uint64_t i = 0; i < n; i++) { tmp[i] = ids[pi[i].id]; kk[i] = keep[pi[i].id]; }
     memcpy(ids, tmp, n * sizeof(uint32_t));
     free(tmp);
@@ -362,7 +367,7 @@ int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hash
                 memcpy(before, s->ids + s->off[g], n * 4);
                 memcpy(cb4, s->counts + s->off[g], n * 2);
             }
-            kssd_slot_order(s->ids + s->off[g], n, hashsize);
+            if (kssd_slot_order(s->ids + s->off[g], n, hashsize)) { free(before); free(cb4); return KSSD_HOST_ERR_NOMEM; }
             if (before) kssd_counts_follow(before, cb4, s->ids + s->off[g], s->counts + s->off[g], n);
             free(before);
             free(cb4);

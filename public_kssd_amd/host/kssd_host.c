@@ -158,8 +158,42 @@ typedef struct {
     int32_t id, k, subk, drlevel;
     uint64_t shuf_size;
     int64_t shuf_mtime_ns;
-    uint32_t n, pad;
+    uint32_t n, sum; /* sum: FNV-1a over accepted[] */
 } shuf_core_hdr;
+
+static uint32_t core_sum(const uint32_t *acc, uint32_t n)
+{
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < 4; b++) h = (h ^ ((acc[i] >> (8 * b)) & 0xFFu)) * 16777619u;
+    return h;
+}
+
+static int cmp_u32(const void *a, const void *b)
+{
+    const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* a cached core is believed only if it can be a core of THIS table: every value a sub-context, no value twice, and a sample
+ * of 64 ranks read back from the .shuf itself (a table rewritten inside one mtime tick at the same size is caught by the
+ * sample with all but negligible probability: two permutations agree on a given rank with probability dim_end / 16^subk) */
+static int core_plausible(int shuf_fd, const uint32_t *acc, uint32_t n, size_t n_tab)
+{
+    uint32_t *sorted = malloc((size_t)n * 4);
+    if (!sorted) return 0;
+    memcpy(sorted, acc, (size_t)n * 4);
+    qsort(sorted, n, 4, cmp_u32);
+    int ok = sorted[n - 1] < n_tab;
+    for (uint32_t i = 1; ok && i < n; i++) ok = sorted[i] != sorted[i - 1];
+    free(sorted);
+    for (uint32_t j = 0; ok && j < 64; j++) {
+        const uint32_t r = (uint32_t)(((uint64_t)j * n) / 64);
+        int32_t v;
+        ok = pread(shuf_fd, &v, 4, (off_t)(16 + (uint64_t)acc[r] * 4)) == 4 && v == (int32_t)r;
+    }
+    return ok;
+}
 
 int kssd_shuf_read_core(const char *path, kssd_shuf *hdr_out, uint32_t **accepted_out, uint32_t *n_out, int *from_cache)
 {
@@ -193,9 +227,10 @@ int kssd_shuf_read_core(const char *path, kssd_shuf *hdr_out, uint32_t **accepte
         int cfd = open(cpath, O_RDONLY);
         if (cfd >= 0) {
             shuf_core_hdr ch;
-            if (read(cfd, &ch, sizeof ch) == (ssize_t)sizeof ch && ch.magic == SHUF_CORE_MAGIC && ch.version == 1 && ch.id == hdr[0] && ch.k == hdr[1] &&
+            if (read(cfd, &ch, sizeof ch) == (ssize_t)sizeof ch && ch.magic == SHUF_CORE_MAGIC && ch.version == 2 && ch.id == hdr[0] && ch.k == hdr[1] &&
                 ch.subk == hdr[2] && ch.drlevel == hdr[3] && ch.shuf_size == (uint64_t)st.st_size && ch.shuf_mtime_ns == mtime_ns &&
-                ch.n == dim_end && read(cfd, acc, (size_t)dim_end * 4) == (ssize_t)((size_t)dim_end * 4)) {
+                ch.n == dim_end && read(cfd, acc, (size_t)dim_end * 4) == (ssize_t)((size_t)dim_end * 4) && ch.sum == core_sum(acc, dim_end) &&
+                core_plausible(fd, acc, dim_end, n_tab)) {
                 close(cfd);
                 close(fd);
                 *accepted_out = acc;
@@ -203,7 +238,7 @@ int kssd_shuf_read_core(const char *path, kssd_shuf *hdr_out, uint32_t **accepte
                 if (from_cache) *from_cache = 1;
                 return KSSD_HOST_OK;
             }
-            close(cfd);
+            close(cfd); /* anything off: the table itself is scanned (and the core rewritten) */
         }
     }
     const int32_t *tab = mmap(NULL, 16 + n_tab * 4, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -229,7 +264,7 @@ int kssd_shuf_read_core(const char *path, kssd_shuf *hdr_out, uint32_t **accepte
         snprintf(tmp, sizeof tmp, "%s.tmp%ld", cpath, (long)getpid());
         int wfd = open(tmp, O_WRONLY | O_CREAT | O_EXCL, 0644);
         if (wfd >= 0) {
-            shuf_core_hdr ch = {SHUF_CORE_MAGIC, 1, hdr[0], hdr[1], hdr[2], hdr[3], (uint64_t)st.st_size, mtime_ns, dim_end, 0};
+            shuf_core_hdr ch = {SHUF_CORE_MAGIC, 2, hdr[0], hdr[1], hdr[2], hdr[3], (uint64_t)st.st_size, mtime_ns, dim_end, core_sum(acc, dim_end)};
             const int ok = write(wfd, &ch, sizeof ch) == (ssize_t)sizeof ch && write(wfd, acc, (size_t)dim_end * 4) == (ssize_t)((size_t)dim_end * 4);
             close(wfd);
             if (!ok || rename(tmp, cpath) != 0) unlink(tmp);

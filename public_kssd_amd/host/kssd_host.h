@@ -125,18 +125,18 @@ void kssd_sketchset_release(kssd_sketchset *s);
  * double-hashing table (global_basic.h:228-230, iseq2comem.c:538-546).  Ties between ids that probe
  * the same slot depend on which the reference met first in the sequence; here the smaller id wins, so
  * the result is byte-identical to the reference's file unless two ids of the genome collide. */
-void kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize);
+int kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize); /* 0, or KSSD_HOST_ERR_NOMEM with the ids untouched (all three) */
 /* The same with every id's first position in the genome (kssd_gpu_sketch_batch_pos): the insertions are replayed
  * in sequence order like fasta2co makes them (iseq2comem.c:254-268), so colliding ids land where the reference
  * puts them and the file is byte-identical.  (fastq -n >= 2 and -u also let ids that are dropped later occupy
  * slots: kssd_slot_order_pos_keep below.) */
-void kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
+int kssd_slot_order_pos(uint32_t *ids, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
 /* the same for tuples of more than 32 bits (k - drlevel = 9) */
-void kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
+int kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t n, uint32_t hashsize);
 /* For the modes whose dump drops ids that nevertheless sit in the reference's table and shift later probes (fastq
  * -n >= 2: fewer than n occurrences; -u: seen more than once): ALL distinct ids of the genome with their first
  * positions, keep[i] != 0 for the ids the dump writes.  Returns how many are kept; they come back at the front of
- * ids, in the reference's file order. */
+ * ids, in the reference's file order.  UINT64_MAX: out of memory. */
 uint64_t kssd_slot_order_pos_keep(uint32_t *ids, const uint32_t *first_pos, const uint8_t *keep, uint64_t n, uint32_t hashsize);
 
 /* abundances follow a reordering of one genome's (distinct) ids: counts_after[i] = the count ids_after[i] had in

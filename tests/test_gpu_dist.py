@@ -194,6 +194,96 @@ def test_index_buckets_too_large_for_lds(gpu_ctx):
     q = np.unique(q)
     got = gpu_ctx.dist(roff1, big, np.array([0, len(q)], np.uint64), q, planes=False)
     assert int(got[0, 0]) == len(np.intersect1d(q, big))
+    gpu_ctx.index_set_exact(False)    # (the crafted bucket has sent the session's context to the counting build: back to the ordinary one)
+
+
+def test_capped_and_exact_index_builds_agree(shuf_l3k10):
+    """the ordinary index build gives every bucket the same room (no counting pass; the rows kernel needs no bucket
+    descriptor); kssd_gpu_index_set_exact asks for the counting build of rounds 1 - 3.  Same counts and planes from both, on
+    one bucket (few ids), 128 buckets and with empty sketches in between."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        for n_ref, lo, hi, clades in ((5, 0, 40, 2), (200, 900, 1300, 8), (40, 0, 3, 3)):
+            roff, rids = random_sketches(rng, n_ref, lo, hi, 1 << 28, clades=clades)
+            qoff, qids = random_sketches(rng, 31, 0, hi, 1 << 28, clades=clades)
+            if len(rids) and len(qids):
+                qids[: len(qids) // 2] = rng.choice(rids, size=len(qids) // 2)
+                for i in range(len(qoff) - 1):
+                    s_, e_ = int(qoff[i]), int(qoff[i + 1])
+                    u = np.unique(qids[s_:e_])
+                    fill = rng.choice(1 << 28, size=(e_ - s_) - len(u), replace=False).astype(np.uint32)
+                    qids[s_:e_] = np.sort(np.concatenate([u, fill]))
+            want = ko.shared_counts(roff, rids, qoff, qids, threads=4)
+            d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
+            outs = []
+            for exact in (False, True):
+                ctx.index_set_exact(exact)
+                ctx.index_build_device(d[0], d[1], n_ref, len(rids))
+                assert ctx.index_status() == 0
+                shared = torch.full((31 * n_ref,), -1, dtype=torch.int32, device=dev)
+                planes = [torch.zeros(31 * n_ref, dtype=torch.float64, device=dev) for _ in range(4)]
+                ctx.dist_device(d[2], d[3], 31, 0, 31, shared, *planes)
+                torch.cuda.synchronize()
+                assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(31, n_ref), want), (n_ref, exact)
+                outs.append([p.cpu().numpy().view(np.int64) for p in planes])
+            for x, y in zip(*outs):
+                assert np.array_equal(x, y)
+    finally:
+        ctx.close()
+
+
+def test_index_overflow_is_reported_and_the_exact_build_takes_over(shuf_l3k10):
+    """ids crafted into ONE bucket of the hash: the capped build meets a bucket fuller than its run, kssd_gpu_index_status
+    says KSSD_ERR_OVERFLOW (kssd_gpu_dist_device computes nothing on that index), the next build of the context counts first
+    and its status is clean -- counts equal the oracle's.  A database of one sketch held by hundreds of genomes (every id with
+    hundreds of holders: bucket sizes come in blocks) takes the same way."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    pool = rng.choice(1 << 28, size=400_000, replace=False).astype(np.uint64)
+    mix = (pool * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    crowd = pool[(mix >> np.uint64(29)) == 0].astype(np.uint32)
+    R = 12
+    off, ids = [0], []
+    for g in range(R):
+        own = np.sort(rng.choice(crowd[:900], size=500, replace=False))
+        ids.append(own)
+        off.append(off[-1] + len(own))
+    roff, rids = np.array(off, np.uint64), np.concatenate(ids)
+    qoff = np.array([0, 700, 700, 1500], np.uint64)
+    qids = np.concatenate([np.sort(rng.choice(crowd[:1200], 700, replace=False)), np.sort(rng.choice(crowd, 800, replace=False))]).astype(np.uint32)
+    want = ko.shared_counts(roff, rids, qoff, qids)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
+        ctx.index_build_device(d[0], d[1], R, len(rids))
+        assert ctx.index_status() == K.capi.ERR_OVERFLOW          # 6 000 entries in one bucket of four, whose run holds 4 095
+        shared = torch.full((3 * R,), -1, dtype=torch.int32, device=dev)
+        ctx.dist_device(d[2], d[3], 3, 0, 3, shared)              # nothing is computed on an index that is not whole
+        torch.cuda.synchronize()
+        assert int((shared == -1).sum().item()) == 3 * R
+        ctx.index_build_device(d[0], d[1], R, len(rids))          # the context counts first from now on
+        assert ctx.index_status() == 0
+        ctx.dist_device(d[2], d[3], 3, 0, 3, shared)
+        torch.cuda.synchronize()
+        assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(3, R), want)
+        ctx.index_set_exact(False)
+        # host level: the retry is inside
+        assert np.array_equal(ctx.dist(roff, rids, qoff, qids, planes=False), want)
+        ctx.index_set_exact(False)
+        # 600 copies of one sketch of 1 200 ids: 720 000 entries in 512 buckets of up to 4 096, ~2.3 ids x 600 holders each
+        one = np.sort(rng.choice(1 << 28, size=1200, replace=False)).astype(np.uint32)
+        roff2 = (np.arange(601, dtype=np.uint64) * 1200)
+        rids2 = np.tile(one, 600)
+        q2 = np.sort(np.concatenate([one[::2], rng.choice(1 << 28, 300).astype(np.uint32)]))
+        q2 = np.unique(q2)
+        got = ctx.dist(roff2, rids2, np.array([0, len(q2)], np.uint64), q2, planes=False)
+        assert np.array_equal(got, ko.shared_counts(roff2, rids2, np.array([0, len(q2)], np.uint64), q2, threads=4))
+    finally:
+        ctx.close()
 
 
 def _sketchset(names, off, ids, kmerlen=20, dim_rd_len=6):
