@@ -492,7 +492,9 @@ KSSD_HD double kssd_log_over_k(double x, double k)
 //       at the GW window offsets a group can see it in; entry bit j <=> window j of the group
 //   bloom  stage-1.5 blocked Bloom filter of the same pattern set
 //   G   stage-2 exact map sub-context -> rank (two-choice cuckoo, see KssdG)
-// returns false when no placement of the keys is found in 64 attempts (never for distinct sub-contexts: callers check that)
+// returns false when no placement of the keys is found in 2^16 attempts (an attempt places 4 096 distinct keys greedily with
+// probability ~1 / 400: hundreds of attempts are ordinary, microseconds each; more than four EQUAL keys can never be placed --
+// callers check that the sub-contexts are distinct)
 static inline bool kssd_build_tables(KssdParams &P, const std::vector<uint32_t> &accepted, int GW,
                                      std::vector<uint8_t> &T1, std::vector<uint32_t> &bloom, std::vector<KssdG> &G)
 {
@@ -527,7 +529,7 @@ static inline bool kssd_build_tables(KssdParams &P, const std::vector<uint32_t> 
     const size_t nb = (size_t)1 << P.g_log2;
     uint64_t seed = 0x243F6A8885A308D3ull;
     for (int attempt = 0;; attempt++) {
-        if (attempt == 64) return false;
+        if (attempt == (1 << 16)) return false;
         G.assign(2 * nb, KssdG{KSSD_EMPTY_KEY, 0});
         bool ok = true;
         for (size_t r = 0; r < accepted.size() && ok; r++) {

@@ -133,6 +133,50 @@ def test_sixteen_passes_give_the_references_tuples():
 
 
 @pytest.mark.gpu
+def test_passes_after_a_region_overflow_keep_the_scanned_layout():
+    """A batch whose staging regions overflow at pass 0 (2 Mb of a period-4 repeat whose 12-mer is an accepted sub-context:
+    every fourth position is sampled, 500 x the rate the regions are sized for) is repeated with larger regions; the passes
+    1 .. 15 then run on the candidate list and the layout tables of THAT scan -- the layout may not move between them (the
+    regions used to shrink back after the first pass that filled them to under a quarter, which every pass of a sixteenth
+    does).  All sixteen passes against the oracle, twice over the same context, ordinary genomes beside the repeat."""
+    from synth import fasta_text
+    shuf0 = K.Shuf.generate(*K12, seed=SEED)
+    tab = shuf0.table.copy()
+    code = 0
+    for ch in b"ACGT" * 3:
+        code = (code << 2) | b"ACGT".index(ch)
+    y = int(np.nonzero(tab == 7)[0][0])          # the repeat's sub-context gets rank 7: still a permutation
+    tab[y], tab[code] = tab[code], 7
+    shuf = K.Shuf((shuf0.id,) + K12, tab)
+    rng = np.random.default_rng(99)
+    texts = [fasta_text(rng.integers(0, 4, 700_000, dtype=np.uint8)), b">str\n" + b"ACGT" * 500_000 + b"\n",
+             fasta_text(rng.integers(0, 4, 300_000, dtype=np.uint8)), b">polyA\n" + b"A" * 300_000 + b"\n"]
+    sk = ko.Sketcher(shuf.table, *K12)
+    want = []
+    for t in texts:
+        ids, comps = sk.fasta(t, with_comps=True)
+        want.append(np.sort((ids.astype(np.uint64) << np.uint64(8)) | comps.astype(np.uint64)))
+    assert len(want[1]) >= 1
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        for rep in range(2):
+            ctx.set_tuple_pass(0)
+            passes = [ctx.sketch_fasta_texts(texts, with_pos=True)]
+            if rep == 0:
+                assert ctx.scan_stats()[1] > 400_000          # the flood happened
+            for s in range(1, 16):
+                ctx.set_tuple_pass(s)
+                passes.append(ctx.sketch_again(with_pos=True))
+            for g in range(len(texts)):
+                t = np.concatenate([(i[int(o[g]):int(o[g + 1])].astype(np.uint64) << np.uint64(4)) | np.uint64(s)
+                                    for s, (o, i, p) in enumerate(passes)])
+                assert np.array_equal(np.sort(t), want[g]), (rep, g)
+        ctx.set_tuple_pass(0)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_command_line_writes_the_references_256_component_files(tmp_path):
     d = str(tmp_path)
     B = np.load(os.path.join(G, "k12.npz"))
