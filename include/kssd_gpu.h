@@ -401,6 +401,36 @@ int kssd_gpu_concat_units_device(kssd_gpu_ctx *ctx, const uint64_t *d_off_all, c
 int kssd_gpu_allgather_sketches(kssd_gpu_ctx *const *ctxs, int n, const uint64_t *const *d_off_l, const uint32_t *const *d_ids_l,
                                 uint32_t n_per_rank, uint64_t unit_ids, uint64_t *const *d_roff, uint32_t *const *d_rids,
                                 void *const *streams);
+/*
+ * Stage I, the exchange and the search as ONE flow in which the sketches never leave the devices that made them: what the
+ * reference's `dist` does when it runs stage I, stage II and the search back to back (dist_dispatch, command_dist.c:64-99;
+ * mco_cbdco_nobin_dist :670-808, one owner thread per output row :774-785) -- there through files every thread can map,
+ * here with devices as the owners of rows.
+ *   kssd_gpu_resident_create    one object per device: `n_slots` genome slots.  Touches no device.
+ *   kssd_gpu_resident_put       slots [first_slot, first_slot + n) := the n genomes of ctx's LAST host-level sketch call
+ *                               (kssd_gpu_sketch_batch[_pos], kssd_gpu_sketch_fast[aq]_text, kssd_gpu_sketch_again; not a
+ *                               KSSD_SKETCH_BY_POS stream): their ids as that call left them on the device, copied device
+ *                               to device.  ctx lives on the object's device; several threads (the sketch workers of one
+ *                               device) may put into one object, each slot once.
+ *   kssd_gpu_resident_put_host  the same from host arrays (the modes whose keep rule the host replays: -u, fastq -n > 1)
+ *   kssd_gpu_resident_sizes     sizes[n_slots]: the sketch size of every slot (0xFFFFFFFF: never put)
+ *   kssd_gpu_resident_allpairs  all-pairs among the genomes of `sets` (global numbering: set 0's slots, then set 1's, ...;
+ *                               every set but the last holds the same number of slots -- kssd_shard_plan of the host
+ *                               library deals the inputs out that way): ONE RCCL all-gather of every device's packed
+ *                               sketches (kssd_gpu_allgather_sketches; one device: a one-rank communicator), the full index
+ *                               on every device, every device's own genomes as its block of query rows, written into the
+ *                               caller's HOST matrices (N x N row-major; `shared` may be a mapped sharedk_ct.dat, the f64
+ *                               planes may be NULL).  One host thread per device.  KSSD_ERR_PARAM when a device is named
+ *                               twice (RCCL: one rank per device) or a slot was never put.
+ */
+typedef struct kssd_gpu_resident kssd_gpu_resident;
+int kssd_gpu_resident_create(kssd_gpu_resident **out, int device, uint32_t n_slots);
+void kssd_gpu_resident_destroy(kssd_gpu_resident *r);
+int kssd_gpu_resident_put(kssd_gpu_resident *r, kssd_gpu_ctx *ctx, uint32_t first_slot, uint32_t n);
+int kssd_gpu_resident_put_host(kssd_gpu_resident *r, uint32_t first_slot, uint32_t n, const uint64_t *off, const uint32_t *ids);
+int kssd_gpu_resident_sizes(const kssd_gpu_resident *r, uint32_t *sizes);
+int kssd_gpu_resident_allpairs(kssd_gpu_resident *const *sets, int n_sets, int kmerlen, uint32_t *shared, double *jaccard,
+                               double *mashd, double *contain, double *aafd);
 /* how many gfx950 devices this process sees (0 without any; never an error) */
 int kssd_gpu_device_count(void);
 

@@ -3077,3 +3077,4 @@ extern "C" int kssd_gpu_text_wait(kssd_gpu_ctx *c, int64_t ticket)
 // ---------------------------------------------------------------------------------------------------
 #include "kssd_set.inc"
 #include "kssd_xchg.inc"
+#include "kssd_resident.inc"

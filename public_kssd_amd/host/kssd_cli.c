@@ -212,6 +212,8 @@ typedef struct {
     int nargs;
     char **args;
     int device, gpus; /* first device, number of devices (--gpus / KSSD_GPUS) */
+    int allpairs;     /* --allpairs: stage I, then all-pairs among the inputs in the same run, sketches resident on the devices */
+    int devs[64], n_devs; /* the device list: device .. device + gpus - 1, or KSSD_DEVICE_LIST=a,b,c */
     unsigned long long seed;
 } dist_opt;
 
@@ -289,6 +291,7 @@ typedef struct job {
     int uploaded;
     uint64_t *toff, *tlen, *lines;
     int is_fq, first_file, n_files;
+    int q;            /* the queue (device of the list) that takes it: 0 unless the inputs are dealt out to devices (--allpairs) */
     uint64_t *off;    /* n_files + 1 */
     uint32_t *ids;    /* slot order per genome */
     uint16_t *counts; /* -A */
@@ -450,8 +453,9 @@ static int job_sketch(kssd_gpu_ctx *ctx, job *j, stream_ring *ring, const fileli
                                  min_occ, off, ids, bad);
 }
 
-static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, uint32_t hashlimit, double *t_call)
-{
+static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist_opt *o, filelist *fl, uint32_t hashsize, uint32_t hashlimit, double *t_call,
+                        kssd_gpu_resident *res, uint32_t res_first)
+{   /* res != NULL: the job's sketches also stay on the device, as slots first_file - res_first .. of res (--allpairs) */
     const double tc0 = now_s();
     const int is_fq = j->is_fq;
     const uint32_t first_file = (uint32_t)j->first_file;
@@ -468,6 +472,7 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     const uint32_t passes = kssd_gpu_tuple_passes(ctx);
     if (passes > 1 && (o->u || o->abundance || (is_fq && (o->kmerocrs > 1 || o->kmerqlty > 127))))
         die(ENOTSUP, "-u, -A, -n > 1 with k - drlevel = 9 (36-bit tuples, 256 components) are not built");
+    if (passes > 1 && res) die(ENOTSUP, "--allpairs with k - drlevel = 9: a directory of 256 components is not searched (the reference's own stage II does not survive it)");
     if (j->streamed && !j->uploaded) { /* the text's length (a gzip'ed input: only known now) decides what follows */
         const double tu0 = now_s();
         j->tlen[0] = j->streamed == 2 ? stream_gz_in(ctx, ring, fl->path[j->first_file], j->tlen[0])
@@ -531,6 +536,9 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     if (rc == KSSD_ERR_CAPACITY)
         die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
     gck(rc, "sketch");
+    /* the ids this call left on the device (ascending per genome) are the job's sketches unless a keep rule is replayed on the
+     * host below (-u, fastq -n > 1: the call was made without the rule) */
+    if (res && !replay_all) gck(kssd_gpu_resident_put(res, ctx, first_file - res_first, n), "kssd_gpu_resident_put");
     if (passes > 1) {
         /* 36-bit tuples: the passes 1 .. 15 over the same job (pass s: the tuples with low bits s, ids = tuple >> 4), then
          * every genome's tuples of all passes in the reference's file order (its ONE table holds the whole tuples) */
@@ -622,6 +630,7 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
         kssd_gpu_free(cids);
         kssd_gpu_free(ccnt);
         with_pos = -1; /* already in file order */
+        if (res) gck(kssd_gpu_resident_put_host(res, first_file - res_first, n, off, ids), "kssd_gpu_resident_put_host");
     }
     *t_call += now_s() - tc0;
     /* -A: a second pass over the same batch returns the occurrences of every id (ids ascending inside a genome,
@@ -672,7 +681,10 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
 typedef struct {
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    job *todo_head, *todo_tail; /* tokenised, waiting for a device */
+    job *todo_head[64], *todo_tail[64]; /* tokenised, waiting for a device: one queue, or one per device of the list (--allpairs) */
+    int n_q;
+    kssd_gpu_resident **res;    /* --allpairs: per device, what it has sketched */
+    const uint32_t *first;      /* ... and the first input of every device (kssd_shard_plan) */
     job *done;                  /* sketched */
     kssd_batch **pool;          /* free batches */
     textbuf **tpool;            /* free text buffers */
@@ -691,7 +703,7 @@ typedef struct {
 
 typedef struct {
     pipeline *pl;
-    int device;
+    int device, q; /* the device, and the queue it takes jobs from */
     pthread_t th;
 } worker;
 
@@ -710,17 +722,17 @@ static void *worker_main(void *arg)
     stream_ring ring = {{0}};
     for (;;) {
         pthread_mutex_lock(&pl->mu);
-        while (!pl->todo_head && !pl->closed) pthread_cond_wait(&pl->cv, &pl->mu);
-        job *j = pl->todo_head;
+        while (!pl->todo_head[w->q] && !pl->closed) pthread_cond_wait(&pl->cv, &pl->mu);
+        job *j = pl->todo_head[w->q];
         if (j) {
-            pl->todo_head = j->next;
-            if (!pl->todo_head) pl->todo_tail = NULL;
+            pl->todo_head[w->q] = j->next;
+            if (!pl->todo_head[w->q]) pl->todo_tail[w->q] = NULL;
         }
         pthread_mutex_unlock(&pl->mu);
         if (!j) break;
         const double t0 = now_s();
         double tcall = 0;
-        process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, pl->hashlimit, &tcall);
+        process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, pl->hashlimit, &tcall, pl->res ? pl->res[w->q] : NULL, pl->res ? pl->first[w->q] : 0u);
         const double dt = now_s() - t0;
         if (j->b) kssd_batch_clear(j->b);
         if (j->own_b) kssd_batch_destroy(j->own_b);
@@ -842,8 +854,18 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     o = &oa;
     if (abundance) printf("running mt_shortreads2koc()\n");
     const double t_start = now_s();
+    /* --allpairs: the inputs are dealt out to the devices of the list in contiguous runs (kssd_shard_plan) -- a device sketches
+     * its run, keeps the sketches, and owns their rows of the matrix later.  Decided here, before anything touches a GPU: a list
+     * that names a device twice is refused with the reason (RCCL admits one rank per device). */
+    const int n_dev = o->n_devs;
+    uint32_t first[65] = {0};
+    if (o->allpairs) {
+        if (abundance) die(ENOTSUP, "--allpairs with -A: abundance sketches are not searched (mco_cbdco_nobin_dist reads plain sketches)");
+        if (kssd_shard_plan(o->devs, n_dev, (uint32_t)fl->n, first))
+            die(EINVAL, "--allpairs: the device list names a device twice (or none): one rank per device");
+    }
     pthread_t warm;
-    int warm_dev = o->device;
+    int warm_dev = o->devs[0];
     const int warming = pthread_create(&warm, NULL, warm_device, &warm_dev) == 0; /* under the .shuf read */
     shuf_core sc;
     load_shuf(o, &sc);
@@ -855,11 +877,11 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
     const double t_shuf = now_s() - t_start;
     if (warming) pthread_join(warm, NULL);
-    int n_dev = o->gpus > 0 ? o->gpus : 1;
     {
         const int have = kssd_gpu_device_count();
         if (have <= 0) die(ENODEV, "kssd_gpu_create: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
-        if (o->device + n_dev > have) die(ENODEV, "--gpus %d from device %d: only %d device(s) visible", n_dev, o->device, have);
+        for (int i = 0; i < n_dev; i++)
+            if (o->devs[i] >= have) die(ENODEV, "device %d of the list: only %d device(s) visible", o->devs[i], have);
     }
     const int n_workers = 2 * n_dev;
     const int threads = o->p > 0 ? o->p : 1;
@@ -874,6 +896,13 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pl.hdr = hdr;
     pl.accepted = sc.accepted;
     pl.n_accepted = sc.n_accepted;
+    pl.n_q = o->allpairs ? n_dev : 1;
+    kssd_gpu_resident *res[64] = {0};
+    if (o->allpairs) {
+        for (int d = 0; d < n_dev; d++) gck(kssd_gpu_resident_create(&res[d], o->devs[d], first[d + 1] - first[d]), "kssd_gpu_resident_create");
+        pl.res = res;
+        pl.first = first;
+    }
     const int n_batches = n_workers + 1; /* one being filled, one per worker */
     pl.pool = calloc((size_t)n_batches, sizeof *pl.pool);
     for (int i = 0; i < n_batches; i++) {
@@ -887,7 +916,8 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     worker *ws = calloc((size_t)n_workers, sizeof *ws);
     for (int i = 0; i < n_workers; i++) {
         ws[i].pl = &pl;
-        ws[i].device = o->device + i % n_dev;
+        ws[i].device = o->devs[i % n_dev];
+        ws[i].q = o->allpairs ? i % n_dev : 0; /* (one queue for all workers unless the inputs belong to devices) */
         if (pthread_create(&ws[i].th, NULL, worker_main, &ws[i])) die(EAGAIN, "pthread_create");
     }
 
@@ -943,8 +973,12 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             int r1 = r0;
             /* a long file is a job of its own */
             const int stream0 = direct[r0] == 2 ? 2 : (direct[r0] == 1 && len[r0] >= STREAM_MIN);
+            int q0 = 0; /* the device (queue) that owns input i0 + r0 */
+            if (o->allpairs)
+                while ((uint32_t)(i0 + r0) >= first[q0 + 1]) q0++;
             while (r1 < nw && has_fmt(fl->path[i0 + r1], fq_fmt) == fq) {
                 const uint64_t c = (len[r1] + KSSD_CHUNK_BASES - 1) / KSSD_CHUNK_BASES;
+                if (o->allpairs && (uint32_t)(i0 + r1) >= first[q0 + 1]) break; /* a job stays inside one device's run */
                 if (r1 > r0 && (stream0 || direct[r1] == 2 || (direct[r1] == 1 && len[r1] >= STREAM_MIN))) break;
                 if (r1 > r0 && chunks + c > max_chunks) break;
                 chunks += c;
@@ -954,6 +988,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             j->is_fq = fq;
             j->first_file = i0 + r0;
             j->n_files = r1 - r0;
+            j->q = q0;
             if (!fq || fq_dev) {
                 /* FASTA, FASTQ with -Q 0: the raw bytes go to the device, which tokenises them (csrc/kssd_tok.inc) */
                 if (fq) j->lines = calloc((size_t)(r1 - r0) + 1, sizeof(uint64_t));
@@ -1028,9 +1063,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             }
         queue_job:
             pthread_mutex_lock(&pl.mu);
-            if (pl.todo_tail) pl.todo_tail->next = j;
-            else pl.todo_head = j;
-            pl.todo_tail = j;
+            if (pl.todo_tail[j->q]) pl.todo_tail[j->q]->next = j;
+            else pl.todo_head[j->q] = j;
+            pl.todo_tail[j->q] = j;
             pthread_cond_broadcast(&pl.cv);
             pthread_mutex_unlock(&pl.mu);
             n_jobs++;
@@ -1100,6 +1135,56 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     s.koc = o->abundance;
     int rc = kssd_sketchset_write(&s, outdir, d.hashsize, 0); /* already in slot order */
     if (rc) die(EIO, "%s: %s", outdir, kssd_host_strerror(rc));
+    const double t_written = now_s();
+    double t_allpairs = 0, t_report = 0;
+    if (o->allpairs) {
+        /* what `kssd dist -r <outdir> -o <outdir> <outdir>` would do from the files just written (mco_cbdco_nobin_dist +
+         * dist_print_nobin, command_dist.c:670-808,1161-1250), on the sketches the devices still hold: one all-gather, every
+         * device's index, every device's own rows straight into the count matrix */
+        if (d.comp_num != 1) die(ENOTSUP, "--allpairs: %d components", (int)d.comp_num);
+        char skf[KSSD_PATHLEN + 32], distf[KSSD_PATHLEN + 32];
+        snprintf(skf, sizeof skf, "%s/sharedk_ct.dat", outdir);
+        snprintf(distf, sizeof distf, "%s/distance.out", outdir);
+        const size_t cells = (size_t)s.n * s.n;
+        uint32_t *shared = NULL;
+        int skfd = -1;
+        if (access(skf, F_OK) == 0) die(EEXIST, " mco_cbdco_nobin_dist():%s", skf); /* the reference refuses to overwrite */
+        printf("disf_sz=%zu\trefnum=%u\tqrynum=%u\n", cells * 4, s.n, s.n);
+        if (o->keep_skf) {
+            skfd = open(skf, O_RDWR | O_CREAT | O_EXCL, 0600);
+            if (skfd < 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+            snprintf(g_unlink_on_die, sizeof g_unlink_on_die, "%s", skf);
+            if (ftruncate(skfd, (off_t)(cells * 4)) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+            if (cells) shared = mmap(NULL, cells * 4, PROT_READ | PROT_WRITE, MAP_SHARED, skfd, 0);
+        } else if (cells) {
+            shared = mmap(NULL, cells * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        }
+        if (cells && shared == MAP_FAILED) die(errno, "mco_cbdco_nobin_dist(): %zu bytes of shared k-mer counts", cells * 4);
+        {   /* the devices' sketch sizes are the files': the two were made by the same calls, one stayed behind */
+            uint32_t *sz = malloc(((size_t)s.n + 1) * 4);
+            for (int dv = 0; dv < n_dev; dv++) {
+                gck(kssd_gpu_resident_sizes(res[dv], sz + first[dv]), "kssd_gpu_resident_sizes");
+                for (uint32_t g = first[dv]; g < first[dv + 1]; g++)
+                    if (sz[g] != (uint32_t)(s.off[g + 1] - s.off[g])) die(EIO, "--allpairs: genome %u: %u ids on the device, %llu in the file", g, sz[g], (unsigned long long)(s.off[g + 1] - s.off[g]));
+            }
+            free(sz);
+        }
+        gck(kssd_gpu_resident_allpairs(res, n_dev, d.kmerlen, shared, NULL, NULL, NULL, NULL), "all-pairs on the resident sketches");
+        if (o->keep_skf && cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
+        t_allpairs = now_s() - t_written;
+        kssd_print_opt po = {o->metric, o->outfields, o->correction, o->mut_dist_max, o->num_neigb, o->p};
+        rc = kssd_distance_print(distf, shared, &s, &s, &po);
+        if (rc != 0)
+            die(rc == KSSD_HOST_ERR_PARAM ? EINVAL : EIO, "dist_print_nobin():%s: neighborN_max %d should smaller than NREF 1024 and ref_num %u", distf, o->num_neigb, s.n);
+        g_unlink_on_die[0] = 0;
+        if (cells && shared) munmap(shared, cells * 4);
+        if (skfd >= 0) close(skfd);
+        t_report = now_s() - t_written - t_allpairs;
+        for (int dv = 0; dv < n_dev; dv++) kssd_gpu_resident_destroy(res[dv]);
+        if (getenv("KSSD_TIMING"))
+            fprintf(stderr, "{\"kssd_timing\": \"allpairs\", \"genomes\": %u, \"gpus\": %d, \"s_exchange_index_rows\": %.6f, \"s_report\": %.6f}\n", s.n, n_dev,
+                    t_allpairs, t_report);
+    }
     free(s.off);
     free(s.ids);
     free(s.counts);
@@ -1109,7 +1194,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                         "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
                         "\"s_workers_summed\": %.6f, \"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
                 fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_shuf, sc.from_cache, t_read, t_tok,
-                pl.t_gpu, pl.t_call, now_s() - t_sketched);
+                pl.t_gpu, pl.t_call, t_written - t_sketched);
 }
 
 /* stage II (run_stageII, command_dist.c:381-417): the index FILES are for the reference binary; our own search
@@ -1179,10 +1264,11 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
             if (shared == MAP_FAILED) die(errno, "mco_cbdco_nobin_dist(): %zu bytes of shared k-mer counts", cells * 4);
         }
         if (warming) pthread_join(warm, NULL);
-        int n_dev = o->gpus > 0 ? o->gpus : 1;
+        const int n_dev = o->n_devs;
         const int have = kssd_gpu_device_count();
         if (have <= 0) die(ENODEV, "kssd_gpu_create_for_dist: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
-        if (o->device + n_dev > have) die(ENODEV, "--gpus %d from device %d: only %d device(s) visible", n_dev, o->device, have);
+        for (int i = 0; i < n_dev; i++)
+            if (o->devs[i] >= have) die(ENODEV, "device %d of the list: only %d device(s) visible", o->devs[i], have);
         const double t0 = now_s();
         if (selecting) {
             /* -N / -D leave few lines: let the device pick the pairs that can be printed (output_ctrl's rules with a
@@ -1196,11 +1282,8 @@ static void search(const dist_opt *o, const char *refdir, const char *qrydir)
             kssd_gpu_destroy(g_ctx);
             g_ctx = NULL;
         } else {
-            int *devs = malloc((size_t)n_dev * sizeof *devs);
-            for (int i = 0; i < n_dev; i++) devs[i] = o->device + i;
             /* query rows in contiguous blocks, one per device; every device indexes all references (command_dist.c:774-785) */
-            gck(kssd_gpu_dist_multi(devs, n_dev, qry.kmerlen, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
-            free(devs);
+            gck(kssd_gpu_dist_multi(o->devs, n_dev, qry.kmerlen, ref.off, ref.ids, ref.n, qry.off, qry.ids, qry.n, shared, NULL, NULL, NULL, NULL), "dist");
         }
         t_dist = now_s() - t0;
         if (o->keep_skf && cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
@@ -1289,7 +1372,8 @@ static int cmd_dist(int argc, char **argv)
         {"outdir", 1, 0, 'o'},         {"neighborN_max", 1, 0, 'N'}, {"mutDist_max", 1, 0, 'D'}, {"metric", 1, 0, 'M'},
         {"outfields", 1, 0, 'O'},      {"correction", 1, 0, 333},   {"abundance", 0, 0, 'A'},  {"dedup", 0, 0, 'u'},
         {"keepcofile", 0, 0, 888},     {"pipecmd", 1, 0, 'P'},      {"keepskf", 0, 0, 777},    {"skf", 1, 0, 'f'},
-        {"byread", 0, 0, 555},         {"seed", 1, 0, 998},         {"gpus", 1, 0, 997},       {0, 0, 0, 0}};
+        {"byread", 0, 0, 555},         {"seed", 1, 0, 998},         {"gpus", 1, 0, 997},       {"allpairs", 0, 0, 996},
+        {0, 0, 0, 0}};
     if (argc < 2) die(EINVAL, "usage: kssd dist [-L <.shuf|level>] [-k K] [-r <reference>] [-o <outdir>] [<query> ...]");
     int c;
     while ((c = getopt_long(argc, argv, "k:p:l:L:m:n:Q:r:o:N:D:M:O:AuP:f:", lo, NULL)) != -1) {
@@ -1326,10 +1410,25 @@ static int cmd_dist(int argc, char **argv)
         case 555: o.byread = 1; break;
         case 998: o.seed = strtoull(optarg, NULL, 10); break;
         case 997: o.gpus = atoi(optarg); break;
+        case 996: o.allpairs = 1; break; /* extension: stage I + all-pairs in one run, sketches resident on the devices */
         default: die(EINVAL, "dist: unknown option");
         }
     }
-    if (o.gpus < 1) die(EINVAL, "--gpus: at least one device");
+    if (o.gpus < 1 || o.gpus > 64) die(EINVAL, "--gpus: between 1 and 64 devices");
+    o.n_devs = o.gpus;
+    for (int i = 0; i < o.gpus; i++) o.devs[i] = o.device + i;
+    if (getenv("KSSD_DEVICE_LIST")) { /* an explicit list, e.g. 2,3,6 (development: 0,0 must be refused by --allpairs) */
+        o.n_devs = 0;
+        for (const char *p = getenv("KSSD_DEVICE_LIST"); *p && o.n_devs < 64;) {
+            o.devs[o.n_devs++] = atoi(p);
+            p += strcspn(p, ",");
+            if (*p == ',') p++;
+        }
+        if (o.n_devs < 1) die(EINVAL, "KSSD_DEVICE_LIST: no device");
+        o.gpus = o.n_devs;
+        o.device = o.devs[0];
+    }
+    if (o.allpairs && (o.byread || o.pipecmd[0])) die(ENOTSUP, "--allpairs with --byread / --pipecmd");
     if (o.p == 0) o.p = default_threads();
     o.nargs = argc - optind;
     o.args = argv + optind;

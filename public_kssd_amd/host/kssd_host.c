@@ -275,6 +275,22 @@ int kssd_shuf_read_core(const char *path, kssd_shuf *hdr_out, uint32_t **accepte
     return KSSD_HOST_OK;
 }
 
+int kssd_shard_plan(const int *devices, int n_devices, uint32_t n_files, uint32_t *first)
+{
+    if (!devices || !first || n_devices < 1) return KSSD_HOST_ERR_PARAM;
+    for (int d = 0; d < n_devices; d++) {
+        if (devices[d] < 0) return KSSD_HOST_ERR_PARAM;
+        for (int e = 0; e < d; e++)
+            if (devices[e] == devices[d]) return KSSD_HOST_ERR_PARAM;
+    }
+    const uint64_t per = ((uint64_t)n_files + (uint64_t)n_devices - 1) / (uint64_t)n_devices;
+    for (int d = 0; d <= n_devices; d++) {
+        const uint64_t at = per * (uint64_t)d;
+        first[d] = (uint32_t)(at < n_files ? at : n_files);
+    }
+    return KSSD_HOST_OK;
+}
+
 void kssd_shuf_release(kssd_shuf *s)
 {
     if (s) {

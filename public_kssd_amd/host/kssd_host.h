@@ -166,6 +166,14 @@ int kssd_index_read(kssd_sketchset *s, const char *dir);
 /* 1 if dir holds cofiles.stat, 2 if mcofiles.stat, 3 both, 0 none (dist_dispatch probing, command_dist.c:62-63) */
 int kssd_probe_dir(const char *dir);
 
+/* Stage I and the all-pairs search sharded over a device list (no counterpart in the reference: its threads take files from
+ * one OpenMP loop, command_dist.c:277, and rows from another, :774): device d of the list sketches -- and later owns the
+ * query rows of -- the inputs [first[d], first[d + 1]) of the (sorted) input list, runs of ceil(n_files / n_devices) files,
+ * the last ones shorter or empty.  That is the layout an all-gather of fixed-size units leaves, so a genome's number on every
+ * device is its input's index.  first: n_devices + 1 entries.  KSSD_HOST_ERR_PARAM: no device, a negative device, or one
+ * named twice (one rank per device). */
+int kssd_shard_plan(const int *devices, int n_devices, uint32_t n_files, uint32_t *first);
+
 /* kssd reverse (command_reverse.c:219-321): the canonical 2k-mer behind a sketch id.  accepted[r] = the sub-context
  * whose permutation rank is r (r < 4096, the inverse of the .shuf table on its first 4096 ranks, :223-231);
  * full_id = the reduced tuple with the component folded back in.  Returns the 2k-mer, 2 bits per base, first base in
