@@ -431,6 +431,9 @@ int kssd_gpu_resident_put_host(kssd_gpu_resident *r, uint32_t first_slot, uint32
 int kssd_gpu_resident_sizes(const kssd_gpu_resident *r, uint32_t *sizes);
 int kssd_gpu_resident_allpairs(kssd_gpu_resident *const *sets, int n_sets, int kmerlen, uint32_t *shared, double *jaccard,
                                double *mashd, double *contain, double *aafd);
+/* which == 0: the file of the HIP runtime this library is bound to; 1: the RCCL the first exchange loaded ("" before it).
+ * For the line a multi-GPU run prints about itself; the string is the calling thread's until its next call. */
+const char *kssd_gpu_runtime_path(int which);
 /* how many gfx950 devices this process sees (0 without any; never an error) */
 int kssd_gpu_device_count(void);
 

@@ -47,7 +47,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts", "kssd_gpu_tuple_passes", "kssd_gpu_set_tuple_pass", "kssd_gpu_sketch_again",
     "kssd_gpu_index_status", "kssd_gpu_index_set_exact",
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
-    "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs",
+    "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path",
 ]
 
 
@@ -107,6 +107,38 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
+def runtime_paths():
+    """which HIP runtime / RCCL / HSA files this process has mapped: {"hip": [...], "rccl": [...], "hsa": [...]}"""
+    out = {"hip": set(), "rccl": set(), "hsa": set()}
+    try:
+        for ln in open("/proc/self/maps"):
+            path = ln.split()[-1] if "/" in ln else ""
+            base = os.path.basename(path)
+            if base.startswith("libamdhip64.so"):
+                out["hip"].add(path)
+            elif base.startswith("librccl.so"):
+                out["rccl"].add(path)
+            elif base.startswith("libhsa-runtime64.so"):
+                out["hsa"].add(path)
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in out.items()}
+
+
+def assert_single_runtime():
+    """One process, one HIP runtime: raw hipStream_t handles, device pointers and RCCL communicators cross between torch and
+    libkssd_gpu.so in the harness (bench.py, the tests), which only means something inside ONE runtime.  torch's libraries ask
+    for "libamdhip64.so" by that name, so a runtime that came in earlier under its soname (libamdhip64.so.7, what
+    libkssd_gpu.so asks for) does not satisfy them and a second one gets mapped; the other way round the loader hands
+    libkssd_gpu.so the copy torch has brought.  Hence gpu_lib() imports torch first where it exists."""
+    rp = runtime_paths()
+    for k in ("hip", "rccl"):
+        if len(rp[k]) > 1:
+            raise RuntimeError("two %s libraries are mapped into this process: %s -- import torch before public_kssd_amd loads "
+                               "libkssd_gpu.so (gpu_lib() does that by itself unless something loaded a runtime earlier)" % (k, rp[k]))
+    return rp
+
+
 def gpu_lib():
     """libkssd_gpu.so; raises if it has not been built (no fallback exists)."""
     global _gpu
@@ -114,7 +146,13 @@ def gpu_lib():
         if not os.path.exists(GPU_LIB):
             raise ImportError("public_kssd_amd: %s is missing -- build it with `make -C public_kssd_amd` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % GPU_LIB)
+        if "torch" not in sys.modules and not os.environ.get("KSSD_NO_TORCH"):
+            try:    # the harness uses torch next to this library: its runtime first (assert_single_runtime)
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(GPU_LIB)
+        assert_single_runtime()
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
         L.kssd_gpu_strerror.restype = C.c_char_p
         L.kssd_gpu_strerror.argtypes = [i32]
@@ -140,6 +178,8 @@ def gpu_lib():
         L.kssd_gpu_free.restype = None
         L.kssd_gpu_index_build_device.argtypes = [vp, vp, vp, u32, u64, vp]
         L.kssd_gpu_index_status.argtypes = [vp, vp]
+        L.kssd_gpu_runtime_path.restype = C.c_char_p
+        L.kssd_gpu_runtime_path.argtypes = [i32]
         L.kssd_gpu_index_set_exact.argtypes = [vp, i32]
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]

@@ -28,8 +28,8 @@ def _native_built():
     if not _have("oracle/libkssd_oracle.so"):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"),
                                os.path.join(ROOT, "oracle", "libkssd_oracle.so")])
-    # torch brings its own HIP runtime; where tests use both it and libkssd_gpu.so (the system's runtime) in one
-    # process, torch has to see the device first -- initialised after the other runtime it reports "No HIP GPUs"
+    # One HIP runtime per process: torch brings its own and asks for it as "libamdhip64.so"; imported BEFORE libkssd_gpu.so is
+    # loaded, the loader hands that library the same copy (public_kssd_amd.capi.assert_single_runtime checks it on every load)
     try:
         import torch
         if torch.cuda.is_available():

@@ -22,3 +22,29 @@ def test_bench_starts_its_own_ranks():
     assert "starting -m torch.distributed.run" in err and "--nproc-per-node 2" in err
     assert err.count("bench.py needs a GPU") >= 2, err[-2000:]  # both ranks got as far as the bench's own check
     assert r.stdout.decode().strip() == ""                      # no line without a measurement
+
+
+def test_exchange_c_refuses_more_devices_than_there_are():
+    """--exchange c drives the N devices from ONE process (no launcher, no torch.distributed): asked for more devices than the
+    machine has it says so"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--exchange", "c", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and "--exchange c --gpus 64" in r.stderr.decode(errors="replace")
+    assert r.stdout.decode().strip() == ""
+
+
+@pytest.mark.gpu
+def test_exchange_c_on_one_device_goes_through_rccl_and_holds_one_runtime():
+    """bench.py --gpus 1 --exchange c: the whole step with kssd_gpu_allgather_sketches in it (a one-rank RCCL communicator on a
+    one-GPU box), the line names the files the exchange ran on -- ONE HIP runtime and ONE RCCL mapped into the process"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--exchange", "c", "--steps", "3", "--warmup", "1", "--spinup", "0",
+                        "--genomes", "60", "--length", "400000", "--clades", "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert j["n_gpus"] == 1 and j["exchange"]["kind"] == "c" and j["exchange"]["us"] > 0
+    assert len(j["runtime"]["mapped"]["hip"]) == 1 and len(j["runtime"]["mapped"]["rccl"]) == 1
+    assert os.path.dirname(j["runtime"]["rccl"]) == os.path.dirname(j["runtime"]["hip"])      # the RCCL next to the runtime in use
+    assert j["matrix_checksum"] > 0 and j["value"] > 0
