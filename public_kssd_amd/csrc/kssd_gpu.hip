@@ -19,6 +19,7 @@
 
 #include "../../include/kssd_gpu.h"
 #include "kssd_core.h"
+#include "kssd_dev.h"
 
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
@@ -483,9 +484,7 @@ struct ScanArgs {
     uint32_t *stage1_count;         // per wave: positions that passed stage 1 (telemetry)
     unsigned long long *blk_info;   // per block of SCAN_BLOCK chunks: where its candidates sit in the list (scan_blk_pack)
     SketchStatus *status;
-#ifdef KSSD_DEV
-    unsigned long long *dev_times;  // development build: per wave {first instruction, tables in LDS, last chunk done} (s_memtime)
-#endif
+    KSSD_DEV_FIELD(unsigned long long *dev_times)  // per wave {first instruction, tables in LDS, last chunk done} (shader cycles)
 };
 
 // The scan's unit of work: a block of SCAN_BLOCK consecutive chunks.  A workgroup owns one contiguous run of the batch's
@@ -635,9 +634,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
             cur_first = stored;
         }
     };
-#ifdef KSSD_DEV
-    const unsigned long long dev_t0 = __builtin_readcyclecounter();
-#endif
+    KSSD_DEV_STAMP_CYC(dev_t0);
     auto take = [&](uint32_t prev) -> uint32_t { return prev >= n_blocks ? prev : prev + SCAN_WAVES; };  // the wave's next block of the run
     auto chunk_at = [&](unsigned long long c) -> unsigned long long { return c < clast ? c : clast; };
     uint32_t b_cur = wave, b_nxt = take(b_cur);  // indices into the workgroup's run
@@ -663,9 +660,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         for (int r = 0; r < TAB_ROUNDS; r++) *reinterpret_cast<uint4 *>(smem + (size_t)(r * SCAN_THREADS + threadIdx.x) * 16) = t[r];
     }
     __syncthreads();
-#ifdef KSSD_DEV
-    const unsigned long long dev_t1 = __builtin_readcyclecounter();
-#endif
+    KSSD_DEV_STAMP_CYC(dev_t1);
     if (b_cur >= n_blocks) {  // a wave without a block (a batch smaller than the grid): nothing listed
         if (lane == 0) { a.cand_count[wid] = 0; a.stage1_count[wid] = 0; }
         return;
@@ -713,9 +708,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
             if (ABL == 2) {
                 abl_acc ^= cl ^ ch;
             } else {
-                // every pass takes one candidate of every lane that still has one: cut its pattern out of the lane's
-                // registers and buffer (position, pattern) by ballot compaction.  No LDS read in this loop: a read
-                // would have to wait behind the table reads of the next chunk that are in flight
                 const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);  // lane and both neighbours all bases
                 const uint32_t ebase = (crel << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
                 // The lanes' candidate bits become one dense list of positions: a prefix sum over the lanes' counts (DPP moves),
@@ -839,13 +831,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
         blk_c0 = nb;
         vb_prev = 0;
     }
-#ifdef KSSD_DEV
-    if (a.dev_times && lane == 0) {
+    KSSD_DEV_DO(if (a.dev_times && lane == 0) {
         a.dev_times[wid * 3] = dev_t0;
         a.dev_times[wid * 3 + 1] = dev_t1;
         a.dev_times[wid * 3 + 2] = __builtin_readcyclecounter();
-    }
-#endif
+    })
     if (lane == 0) {
         a.cand_count[wid] = stored;  // (more than cand_cap: the slice was too small -- scan_totals reports it, the call is repeated larger)
         a.stage1_count[wid] = n_rounded;
@@ -925,9 +915,7 @@ struct ExactArgs {
     void *regions;  // uint32_t[] or, in first-position mode, unsigned long long[]
     uint32_t by_pos;  // KSSD_SKETCH_BY_POS: the 64-bit key is position << 32 | tuple, so that the sort leaves sequence order
     SketchStatus *status;
-#ifdef KSSD_DEV
-    uint32_t dev_no_atomic;  // development A/B (wrong results): the workgroup's room is not reserved at the genome's cursor
-#endif
+    KSSD_DEV_FIELD(uint32_t dev_no_atomic)  // A/B (wrong results): the workgroup's room is not reserved at the genome's cursor
 };
 
 #define EXACT_THREADS 256  // four waves share one reservation of staging room (see below); 1 024 threads: fewer atomics, and 450 us instead of 210 -- too few chains in flight
@@ -1047,11 +1035,7 @@ __global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams 
         }
     }
     if (wg_same && wg_total) {  // (workgroup-uniform)
-#ifdef KSSD_DEV
-        if (x.dev_no_atomic) {
-            if (threadIdx.x == 0) s_base = (blockIdx.y * gridDim.x + blockIdx.x) * 400u;
-        } else
-#endif
+        KSSD_DEV_DO(if (x.dev_no_atomic) { if (threadIdx.x == 0) s_base = (blockIdx.y * gridDim.x + blockIdx.x) * 400u; } else)
         if (threadIdx.x == 0) s_base = atomicAdd(&x.cursor[wg_g], wg_total);
         __syncthreads();
     }
@@ -1341,10 +1325,8 @@ struct FuseArgs {
     uint32_t n_slices;
     unsigned long long cand_cap;
     uint32_t id_bits, bsort_keys;      // ids are below 2^id_bits (roughly); bsort_keys: key slots of the bucket sort's LDS arrays (0: none)
-#ifdef KSSD_DEV
-    unsigned long long *dev_times;     // development build: per workgroup {start, keys in LDS, sorted, done} (s_memrealtime)
-    uint32_t dev_split;
-#endif
+    KSSD_DEV_FIELD(unsigned long long *dev_times)  // per workgroup {start, keys in LDS, sorted, done}
+    KSSD_DEV_FIELD(uint32_t dev_split)             // KSSD_DEV_GATHERSPLIT: the four stamps are start, block table in, first round done, keys in LDS
 };
 #define FUSE_PER 4  // candidates a thread evaluates at a time (six spill at 64 VGPRs)
 
@@ -1387,11 +1369,11 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                                                                       SketchStatus *st, FuseArgs fx, PartArgs px)
 {
     constexpr bool FUSED = MODE == DEDUP_FUSED;
-#ifdef KSSD_DEV
-    const unsigned long long dev_t0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz, one base for the whole chip: start skew is visible)
-    unsigned long long dev_t1 = 0, dev_t2 = 0, dev_tA = 0, dev_tB = 0;
-    const bool dev_split = fx.dev_split != 0;  // KSSD_DEV_GATHERSPLIT: the four stamps are start, block table in, first round done, keys in LDS
-#endif
+    KSSD_DEV_STAMP(dev_t0);
+    KSSD_DEV_VAR(dev_t1);
+    KSSD_DEV_VAR(dev_t2);
+    KSSD_DEV_VAR(dev_tA);
+    KSSD_DEV_VAR(dev_tB);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     K *a = reinterpret_cast<K *>(smem);
     uint32_t g = blockIdx.x, part = 0, lg_parts = 0;
@@ -1540,9 +1522,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
             if (owned)
                 for (uint32_t j = 0; j < cw; j++) owner[before + j] = (uint16_t)tid;
             __syncthreads();
-#ifdef KSSD_DEV
-            if (!dev_tA) dev_tA = __builtin_amdgcn_s_memrealtime();
-#endif
+            KSSD_DEV_MARK_ONCE(dev_tA);
             for (uint32_t f0 = 0; f0 < total; f0 += DEDUP_THREADS * FUSE_PER) {
                 bool ok[FUSE_PER];
                 ulonglong2 cd[FUSE_PER];
@@ -1615,9 +1595,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
                         }
                     }
                 }
-#ifdef KSSD_DEV
-                if (!dev_tB) dev_tB = __builtin_amdgcn_s_memrealtime();
-#endif
+                KSSD_DEV_MARK_ONCE(dev_tB);
             }
             __syncthreads();  // s_pref is rewritten by the next round of slices
         }
@@ -1626,9 +1604,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
     } else {
         n = cursor[g];
     }
-#ifdef KSSD_DEV
-    dev_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
+    KSSD_DEV_MARK(dev_t1);
     const K *src = MODE != DEDUP_STAGED ? a : regions + r0;
     K *outp = regions + r0;  // where the kept keys go
     if (MODE == DEDUP_PARTS) outp = reinterpret_cast<K *>(px.out) + (((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) + part) * px.part_cap;
@@ -1682,9 +1658,7 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         }
     }
     }
-#ifdef KSSD_DEV
-    dev_t2 = __builtin_amdgcn_s_memrealtime();
-#endif
+    KSSD_DEV_MARK(dev_t2);
     // runs of equal tuples; only the first n entries are real (in first-position mode the first entry of a run is
     // the tuple's first occurrence)
     uint32_t out_base = 0;
@@ -1726,14 +1700,12 @@ __global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdPara
         out_base += tot;
     }
     __syncthreads();
-#ifdef KSSD_DEV
-    if ((FUSED || MODE == DEDUP_RANGES) && fx.dev_times && tid == 0 && blockIdx.x < 65536) {
+    KSSD_DEV_DO(if ((FUSED || MODE == DEDUP_RANGES) && fx.dev_times && tid == 0 && blockIdx.x < 65536) {
         fx.dev_times[blockIdx.x * 4] = dev_t0;
-        fx.dev_times[blockIdx.x * 4 + 1] = dev_split ? dev_tA : dev_t1;
-        fx.dev_times[blockIdx.x * 4 + 2] = dev_split ? dev_tB : dev_t2;
-        fx.dev_times[blockIdx.x * 4 + 3] = dev_split ? dev_t1 : __builtin_amdgcn_s_memrealtime();
-    }
-#endif
+        fx.dev_times[blockIdx.x * 4 + 1] = fx.dev_split ? dev_tA : dev_t1;
+        fx.dev_times[blockIdx.x * 4 + 2] = fx.dev_split ? dev_tB : dev_t2;
+        fx.dev_times[blockIdx.x * 4 + 3] = fx.dev_split ? dev_t1 : __builtin_amdgcn_s_memrealtime();
+    })
     if (tid == 0) {
         if (MODE == DEDUP_RANGES) {  // the genome's totals and its capacity rule: big_scan_kernel
             px.item_cnt[blockIdx.x] = out_base;

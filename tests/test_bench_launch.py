@@ -43,7 +43,7 @@ def test_exchange_c_on_one_device_goes_through_rccl_and_holds_one_runtime():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--exchange", "c", "--steps", "3", "--warmup", "1", "--spinup", "0",
                         "--genomes", "60", "--length", "400000", "--clades", "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
-    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    j = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])   # (RCCL prints its version banner to stdout too)
     assert j["n_gpus"] == 1 and j["exchange"]["kind"] == "c" and j["exchange"]["us"] > 0
     assert len(j["runtime"]["mapped"]["hip"]) == 1 and len(j["runtime"]["mapped"]["rccl"]) == 1
     assert os.path.dirname(j["runtime"]["rccl"]) == os.path.dirname(j["runtime"]["hip"])      # the RCCL next to the runtime in use
