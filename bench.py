@@ -126,11 +126,9 @@ def _run_ours(args, cwd, env_extra=None, timeout=900):
     dt = time.time() - t0
     if r.returncode != 0:
         raise RuntimeError("kssd %s -> %d\n%s" % (args, r.returncode, r.stderr.decode(errors="replace")[-2000:]))
-    timing = None
-    for line in r.stderr.decode(errors="replace").splitlines():
-        if line.startswith('{"kssd_timing"'):
-            timing = json.loads(line)
-    return dt, timing
+    timing = [json.loads(line) for line in r.stderr.decode(errors="replace").splitlines() if line.startswith('{"kssd_timing"')]
+    # (one stage line per command; the one-command all-pairs flow prints two: keyed by their names then)
+    return dt, (None if not timing else timing[0] if len(timing) == 1 else {t["kssd_timing"]: t for t in timing})
 
 
 def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_search=1024):
@@ -219,6 +217,7 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
                            "combco.* written -- wall time of the command, the better of two runs (HIP start-up varies by ~0.1 s from "
                            "process to process)", "sample": fa_desc, "stages": tm, "seconds_runs": runs}
             sk_s = "our_sk"
+            dt_s = dt
             if sub:
                 _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_sk_s", "fa_s"], d)
                 sk_s = "our_sk_s"
@@ -232,6 +231,21 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
                                      "sketches, the device search and the distance.out text (%d MB) on %d host threads -- the same command "
                                      "line the reference is timed with below; wall time of the command, the better of two runs"
                                      % (ns, ns, os.path.getsize(os.path.join(d, "our_dist", "distance.out")) >> 20, cores)}
+            # the one-command flow: stage I, ONE exchange (a one-rank RCCL communicator here), index and rows on the sketches the
+            # device still holds, distance.out -- against the two commands above (sketch, then search) on the same files
+            fa_ap = "fa_s" if sub else "fa"
+            dta0, _ = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_ap0", "--allpairs", fa_ap], d)
+            dta, tma = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_ap", "--allpairs", "--keepskf", fa_ap], d, {"KSSD_TIMING": "1"})
+            _run_ours(["dist", "-p", cores, "-r", sk_s, "-o", "our_dist_k", "--keepskf", sk_s], d)
+            for fn in ("sharedk_ct.dat", "distance.out"):
+                assert open(os.path.join(d, "our_ap", fn), "rb").read() == open(os.path.join(d, "our_dist_k", fn), "rb").read(), \
+                    "kssd dist --allpairs: %s differs from the two-command flow's" % fn
+            e2e["allpairs"] = {"value": ns / min(dta, dta0), "unit": "genomes/s", "pairs_per_s": ns * ns / min(dta, dta0), "seconds_runs": [dta0, dta],
+                               "stages": tma,
+                               "what": "`kssd dist -L L3K10.shuf -o <dir> --allpairs <fasta dir>` on %d files: sketch + all-pairs + distance.out in ONE "
+                                       "command, the sketches never leave the device (kssd_gpu_resident_*, one RCCL all-gather); sharedk_ct.dat and "
+                                       "distance.out byte-identical to the two-command flow's; wall time, the better of two runs" % ns,
+                               "two_commands_seconds": dt_s + dt2 if not sub else None}
             if ngz:
                 dtg0, _ = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_gz0", "gz"], d)
                 dtg, tmg = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_gz", "gz"], d, {"KSSD_TIMING": "1"})

@@ -462,1577 +462,10 @@ __global__ void chunk_gid_by_genome_kernel(const uint64_t *__restrict__ chunk_of
         chunk_gid[c] = g;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// kernel 1: the scan.  One wave per 4096-position chunk iteration, one lane per 64 positions.
-//   HBM -> registers: 16 B of packed bases + 4 B halo + 8 B of mask per lane, coalesced, two chunks ahead
-//   stage 1    27 LDS byte reads per lane decide 64 positions (group-filter table, 128 KiB of LDS, kssd_core.h)
-//   stage 1.5  the ~0.8 % surviving positions: pattern cut out of the lane's registers, Bloom test in LDS
-//   output     the ~0.06 % that pass (global position, u64) are compacted by ballot into a per-wave LDS buffer
-//              and appended to a candidate list in HBM: 8 B per candidate, ~1 % on top of the streamed bytes
-// The exact evaluation (stage 2) is kernel 1b: it needs scattered reads and 64-bit arithmetic that would
-// cost this kernel registers, SGPRs and issue slots in its hot loop for work done on 1 position in 1 700.
-// ---------------------------------------------------------------------------------------------------
-
-struct ScanArgs {
-    const uint32_t *packed;
-    const uint32_t *mask;
-    unsigned long long n_chunks;
-    const uint8_t *tab;             // stage-1 table followed by the Bloom filter (SCAN_TAB_BYTES)
-    ulonglong2 *cand;               // (waves of the grid) * cand_cap records {global position, carried k-mer bits}
-    unsigned long long cand_cap;    // per wave
-    uint32_t *cand_count;           // per wave: candidates it wanted to store (> cand_cap: overflow, reported by the stage behind the scan)
-    uint32_t *stage1_count;         // per wave: positions that passed stage 1 (telemetry)
-    unsigned long long *blk_info;   // per block of SCAN_BLOCK chunks: where its candidates sit in the list (scan_blk_pack)
-    SketchStatus *status;
-    KSSD_DEV_FIELD(unsigned long long *dev_times)  // per wave {first instruction, tables in LDS, last chunk done} (shader cycles)
-};
-
-// The scan's unit of work: a block of SCAN_BLOCK consecutive chunks.  A workgroup owns one contiguous run of the batch's
-// blocks, its 16 waves take them in turn (wave w: blocks w, w + 16, ... of the run).  A wave lists the survivors of a block
-// contiguously in its own slice of the candidate list and leaves, per block, where (the per-genome kernel that evaluates
-// them reads exactly the blocks its genome's chunks lie in):
-//   bits 0-23 the number of records, bits 24-63 the index of the first one in the whole list
-// The buffer of stage-1 candidates is emptied at the end of every block, so an entry names its chunk relative to the block.
-// Measured and not kept (profiles/r03d_*, r03e_*): the same blocks handed out by a queue.  With equal shares the fastest wave of
-// EVERY workgroup is through at 70 % of the time its slowest one takes -- the waves of a CU do not get equal shares of its
-// LDS and issue slots -- while the workgroups' means agree to 2 %.  But a CU's throughput does not depend on which of its
-// waves get it: with a queue head per workgroup all waves finish together and the launch takes as long as before (0.621
-// against 0.598 ms); one head for the whole grid saturates (305 000 atomics on one address: 3.6 ms).
-#define SCAN_BLOCK 4
-__host__ __device__ __forceinline__ unsigned long long scan_blk_pack(unsigned long long first, uint32_t n) { return (first << 24) | n; }
-__host__ __device__ __forceinline__ uint32_t scan_blk_count(unsigned long long v) { return (uint32_t)(v & 0xFFFFFFull); }
-__host__ __device__ __forceinline__ unsigned long long scan_blk_first(unsigned long long v) { return v >> 24; }
-
-// one chunk of the lane's share of the stream: 64 positions + halo, and their validity bits
-struct ChunkRegs {
-    uint32_t W[5];
-    uint32_t M[2];
-};
-
-__device__ __forceinline__ void load_chunk(const ScanArgs &a, unsigned long long c, uint32_t lane, ChunkRegs &r)
-{
-    const uint32_t *pp = a.packed + c * 256 + lane * 4;
-    const uint4 v = *reinterpret_cast<const uint4 *>(pp);
-    r.W[0] = v.x; r.W[1] = v.y; r.W[2] = v.z; r.W[3] = v.w;
-    r.W[4] = pp[4];
-    // (the validity words are read once: streamed past the L2 lines of the packed words, which the Bloom rounds come back to;
-    // -0.8 % of the kernel's time, profiles/r03w)
-    const uint32_t *mp = a.mask + c * 128 + lane * 2;
-    r.M[0] = __builtin_nontemporal_load(mp);
-    r.M[1] = __builtin_nontemporal_load(mp + 1);
-}
-
-// Stage-1 candidates are buffered as positions only (4 bytes in LDS); their bases are fetched when the Bloom round comes, one
-// lane per buffered candidate, from the packed stream itself -- a 12-byte gather per lane on the vector-memory path, which
-// the scan leaves idle (3 coalesced loads per chunk), mostly L2 hits (the wave read those lines a few chunks ago; FETCH_SIZE
-// says a third of them come from HBM again).  Until round 3 the scanning lane cut them out of its registers inside the
-// candidate loop: 26 VALU instructions per pass at ~15 % lane efficiency (3.4 passes per chunk for ~34 candidates), more than
-// stage 1 itself.  A round is issued (entries read, gathers sent) one step before it is completed (Bloom test, survivors
-// stored as {global position, k-mer payload | valid << 63}, plain 16-byte stores), so nothing waits for the gather.
-//   entry: [11:0] position inside its chunk (lane << 6 | b)   [22:12] chunk - block's first chunk
-//          [23] 1 = all 2k bases are known to be valid (the lane's and both neighbours' 64 positions are bases)
-struct ScanRound {
-    uint32_t e, w0, w1, w2, n;  // n (wave-uniform): entries of the round, 0 = none pending
-    unsigned long long c0;      // first chunk of the block the entries belong to (wave-uniform)
-};
-__device__ __forceinline__ void scan_round_issue(const ScanArgs &a, unsigned long long blk_c0, const uint32_t *cbuf, uint32_t first, uint32_t n,
-                                                 uint32_t lane, ScanRound &r)
-{
-    r.n = n;
-    r.c0 = blk_c0;
-    r.e = 0;
-    r.w0 = r.w1 = r.w2 = 0;
-    if (lane < n) {
-        r.e = cbuf[first + lane];
-        const unsigned long long p = ((blk_c0 + ((r.e >> 12) & 2047u)) << 12) | (r.e & 4095u);  // global position of the sub-context
-        const unsigned long long i = p >> 4;                                                     // its packed word
-        const uint32_t *pp = a.packed + (i ? i - 1 : 0);  // the word in front (the 4 bases before p may lie there), the word, the next
-        r.w0 = pp[0];
-        r.w1 = pp[1];
-        r.w2 = pp[2];
-    }
-}
-template <int SUBK, int ABL>
-__device__ __forceinline__ uint32_t scan_round_complete(const ScanArgs &a, const uint32_t *bloom, unsigned long long wid,
-                                                        uint32_t stored, uint32_t lane, ScanRound &r, uint32_t &abl_acc)
-{
-    bool pass = false;
-    uint32_t top32 = 0, front = 0;
-    unsigned long long p = 0;
-    if (lane < r.n) {
-        p = ((r.c0 + ((r.e >> 12) & 2047u)) << 12) | (r.e & 4095u);
-        const bool at0 = (p >> 4) == 0;  // no word in front of the batch's first one
-        kssd_carry_from_words(at0 ? 0u : r.w0, at0 ? r.w0 : r.w1, at0 ? r.w1 : r.w2, (uint32_t)p & 15u, top32, front);
-        const uint32_t h = kssd_bloom_hash(top32 >> (32 - 4 * SUBK));
-        const uint32_t bits = kssd_bloom_bits(h);
-        pass = (bloom[kssd_bloom_word(h)] & bits) == bits;
-    }
-    const uint64_t bal = __ballot(pass);
-    if (pass) {
-        const unsigned long long at = (unsigned long long)stored + rank_in(bal);
-        if (ABL != 0) abl_acc ^= r.e;
-        else if (at < a.cand_cap)
-            a.cand[wid * a.cand_cap + at] = make_ulonglong2(p, kssd_carry_payload(top32, front) | ((unsigned long long)((r.e >> 23) & 1u) << 63));
-    }
-    r.n = 0;
-    return (uint32_t)__builtin_popcountll(bal);
-}
-
-// ABL != 0: development-only ablations for profiling (1 = loads only, 2 = + stage 1, 3 = + stage 1.5 without
-// the candidate list); never used by the product path.
-//
-// Software pipeline of one wave over its chunks (c = the chunk whose candidates are being tested):
-//   HBM   chunks c+2 and c+3 are being read into registers while chunk c is worked on
-//   LDS   the table reads of alignment A of chunk c+1 are in flight during the merge / Bloom / push work of
-//         chunk c, those of alignment B across the loop edge: at any time one batch of <= 15 reads is
-//         outstanding behind the one being waited for, which is what s_waitcnt lgkmcnt can express
-template <int SUBK, int ABL = 0>
-__global__ __launch_bounds__(SCAN_THREADS) void sketch_scan_kernel(ScanArgs a)
-{
-    typedef KssdGrp<SUBK, KSSD_GW> Gp;
-    uint32_t abl_acc = 0;
-    // static LDS: the table sits at LDS address 0, so its byte reads need no base add
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SCAN_LDS_BYTES];
-    uint8_t *T1 = smem;
-    const uint32_t *bloom = reinterpret_cast<const uint32_t *>(smem + KSSD_T1_BYTES);
-    // readfirstlane: the compiler cannot know that threadIdx.x >> 6 is wave-uniform; without it the chunk range, the
-    // loop counter and every counter derived from a ballot live in VGPRs and the loops run on exec masks
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t lane = lane_id();
-    // the call's status words start at zero: every kernel that reports into them runs behind this one on the stream, and the
-    // scan itself reports per wave (cand_count / stage1_count, added up by the stage that follows) -- no reset launch in front
-    if (blockIdx.x == 0 && threadIdx.x < sizeof(SketchStatus) / 4) reinterpret_cast<uint32_t *>(a.status)[threadIdx.x] = 0;
-    uint32_t *pbuf = reinterpret_cast<uint32_t *>(smem + SCAN_TAB_BYTES) + wave * CBUF;  // buffered stage-1 candidates (positions, see ScanRound)
-    uint32_t cn = 0, stored = 0;  // buffered stage-1 candidates / listed stage-1.5 survivors (wave-uniform)
-
-    // work distribution: the workgroup's run of blocks, its waves take them in turn (see SCAN_BLOCK)
-    const uint32_t wid = blockIdx.x * SCAN_WAVES + wave;
-    const unsigned long long clast = a.n_chunks - 1;  // reads past the end of the batch are clamped, their results unused
-    const uint32_t n_blocks_all = (uint32_t)((a.n_chunks + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    const uint32_t wg_per = (n_blocks_all + gridDim.x - 1) / gridDim.x;
-    const uint32_t wg_first = blockIdx.x * wg_per;
-    const uint32_t n_blocks = wg_first >= n_blocks_all ? 0u : (n_blocks_all - wg_first < wg_per ? n_blocks_all - wg_first : wg_per);  // of this workgroup
-    uint32_t n_rounded = 0;  // telemetry: stage-1 candidates that went through a Bloom round (in the end: all of them)
-    // rounds in flight (issued, not completed): one per step; two behind a block's last step, whose survivors -- and the block's
-    // blk_info entry -- are completed by the first step of the wave's next block (or after its last one)
-    ScanRound pendA, pendB;
-    pendA.n = pendB.n = 0;
-    pendA.e = pendA.w0 = pendA.w1 = pendA.w2 = pendB.e = pendB.w0 = pendB.w1 = pendB.w2 = 0;
-    pendA.c0 = pendB.c0 = 0;
-    uint32_t defer_blk = 0xFFFFFFFFu, defer_first = 0;  // the block whose blk_info entry waits for those rounds (wave-uniform)
-    uint32_t cur_first = 0;  // where the survivors of the block being worked on begin in the slice: behind the last survivor of the block before
-    auto finish_pending = [&]() {
-        if (pendA.n) stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, pendA, abl_acc);
-        if (pendB.n) stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, pendB, abl_acc);
-        if (defer_blk != 0xFFFFFFFFu) {
-            if (ABL == 0 && lane == 0) {  // where the block's survivors are (clamped to what the slice holds: an overflow is reported below)
-                const unsigned long long cap = a.cand_cap;
-                const unsigned long long f = defer_first < cap ? defer_first : cap, e = stored < cap ? stored : cap;
-                a.blk_info[defer_blk] = scan_blk_pack((unsigned long long)wid * cap + f, (uint32_t)(e - f));
-            }
-            defer_blk = 0xFFFFFFFFu;
-            cur_first = stored;
-        }
-    };
-    KSSD_DEV_STAMP_CYC(dev_t0);
-    auto take = [&](uint32_t prev) -> uint32_t { return prev >= n_blocks ? prev : prev + SCAN_WAVES; };  // the wave's next block of the run
-    auto chunk_at = [&](unsigned long long c) -> unsigned long long { return c < clast ? c : clast; };
-    uint32_t b_cur = wave, b_nxt = take(b_cur);  // indices into the workgroup's run
-
-    // the wave's first three chunks are requested before the tables are copied into LDS: the HBM latency of the
-    // first reads overlaps the 144 KiB copy instead of following it
-    ChunkRegs r0, r1, r2, r3;
-    uint32_t raw[Gp::NMAX];
-    uint32_t alo, ahi;
-    {
-        const unsigned long long c0 = (unsigned long long)(wg_first + b_cur) * SCAN_BLOCK;
-        load_chunk(a, chunk_at(c0), lane, r0);
-        load_chunk(a, chunk_at(c0 + 1), lane, r1);
-        load_chunk(a, chunk_at(c0 + 2), lane, r2);
-    }
-    {   // 144 KiB = nine 16-byte pieces per thread: all nine requested before the first one is stored
-        static_assert(SCAN_TAB_BYTES % (SCAN_THREADS * 16) == 0, "the table copy is written for whole rounds");
-        constexpr int TAB_ROUNDS = SCAN_TAB_BYTES / (SCAN_THREADS * 16);
-        uint4 t[TAB_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < TAB_ROUNDS; r++) t[r] = *reinterpret_cast<const uint4 *>(a.tab + (size_t)(r * SCAN_THREADS + threadIdx.x) * 16);
-#pragma unroll
-        for (int r = 0; r < TAB_ROUNDS; r++) *reinterpret_cast<uint4 *>(smem + (size_t)(r * SCAN_THREADS + threadIdx.x) * 16) = t[r];
-    }
-    __syncthreads();
-    KSSD_DEV_STAMP_CYC(dev_t1);
-    if (b_cur >= n_blocks) {  // a wave without a block (a batch smaller than the grid): nothing listed
-        if (lane == 0) { a.cand_count[wid] = 0; a.stage1_count[wid] = 0; }
-        return;
-    }
-    // whether a lane's neighbours' 64 positions are all bases (ballots of this and the previous chunk; lane 63's right neighbour
-    // is not looked at, and neither is lane 0's left one in the first chunk of a block: their candidates -- ~2 % -- let the
-    // exact stage read the mask)
-    unsigned long long blk_c0 = (unsigned long long)(wg_first + b_cur) * SCAN_BLOCK;  // first chunk of the block being worked on
-    uint64_t vb_prev = 0;
-
-    // prologue: the block's first chunk through both alignments
-    kssd_grp_issue<SUBK, KSSD_GW, 0>(r0.W, T1, raw);
-    kssd_grp_merge<SUBK, KSSD_GW, 0>(raw, alo, ahi);
-    kssd_grp_issue<SUBK, KSSD_GW, 1>(r0.W, T1, raw);  // alignment B of the first chunk in flight
-
-    // one chunk.  The four register sets rotate by name (a block is four steps, written out): copying one
-    // set into another would make every iteration wait for the reads it has just issued.
-    //   c = the chunk of this step, crel = its index in the block, c_far = the chunk three steps ahead in the wave's
-    //   sequence (the next block's chunks once this block's are requested), last = the block's last step
-    auto step = [&](const ChunkRegs &cur_r, ChunkRegs &nxt_r, ChunkRegs &far, const unsigned long long c, const uint32_t crel,
-                    const unsigned long long c_far, const bool last) {
-        // state: cur = chunk c, nxt = the chunk after it (requested two steps ago), the one after that in flight, far = free,
-        //        raw = alignment-B reads of chunk c (in flight), alo/ahi = alignment A of chunk c
-        // Wave priority: the part of an iteration that feeds the memory and LDS pipes runs at high priority (3 while the
-        // loads and table reads are issued, 2 for the merges and the Bloom round), the candidate loop -- a long run of
-        // VALU work that nothing waits for -- at priority 0, so that a SIMD's issue slots go first to the waves that
-        // keep HBM and LDS busy.  Measured on the full batch, same box: 0.555 ms without priorities, 0.544 with only the
-        // table-read issue raised, 0.529 with everything but the loop at 2, 0.526 as it is here.
-        __builtin_amdgcn_s_setprio(3);
-        load_chunk(a, chunk_at(c_far), lane, far);
-        const ChunkRegs &cur = cur_r, &nxt = nxt_r;
-        const uint64_t vb = __ballot((cur.M[0] & cur.M[1]) == 0xFFFFFFFFu);
-        uint32_t rawa[Gp::NMAX];
-        if (ABL != 1) kssd_grp_issue<SUBK, KSSD_GW, 0>(nxt.W, T1, rawa);  // alignment A of the next chunk goes in flight
-        if (ABL == 1) {
-            abl_acc ^= cur.W[0] ^ cur.W[1] ^ cur.W[2] ^ cur.W[3] ^ cur.W[4] ^ cur.M[0] ^ cur.M[1];
-        } else {
-            uint32_t blo, bhi;
-            __builtin_amdgcn_s_setprio(2);
-            kssd_grp_merge<SUBK, KSSD_GW, 1>(raw, blo, bhi);  // waits for the B reads of chunk c only
-            const uint32_t real = c < a.n_chunks ? 0xFFFFFFFFu : 0u;  // (the batch's last block may be short: its missing chunks hold nothing)
-            uint32_t cl = alo & blo & cur.M[0] & real;  // the window start itself must be a base: kills padding / N stretches early
-            uint32_t ch = ahi & bhi & cur.M[1] & real;
-            __builtin_amdgcn_s_setprio(0);
-            if (ABL == 2) {
-                abl_acc ^= cl ^ ch;
-            } else {
-                const uint64_t kvm = vb & ((vb << 1) | (vb_prev >> 63)) & (vb >> 1);  // lane and both neighbours all bases
-                const uint32_t ebase = (crel << 12) | (lane << 6) | ((uint32_t)((kvm >> lane) & 1ull) << 23);
-                // The lanes' candidate bits become one dense list of positions: a prefix sum over the lanes' counts (DPP moves),
-                // then every lane writes its own ~0.5 positions -- a loop over its set bits with nothing but a find-first-bit, a
-                // clear and a 4-byte LDS write per pass, no ballot, no rank, no extraction.
-                // (No vector-memory instruction may sit inside such a loop: one on ANY path through it makes the compiler wait
-                // for all outstanding loads -- the prefetched chunks -- at the loop's head, every pass.)
-                unsigned long long m64 = ((unsigned long long)ch << 32) | cl;
-                const uint32_t mine = (uint32_t)__builtin_popcountll(m64);
-                const uint32_t incl = wave_incl_scan_dpp(mine);
-                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (cn + total > CBUF) {  // dense parameter sets only: rounds completed at once make room (the rounds in flight first: blocks stay in order)
-                    finish_pending();
-                    wave_lds_sync();
-                    while (cn >= 64 && cn + total > CBUF) {
-                        ScanRound tmp;
-                        scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
-                        stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
-                        n_rounded += 64;
-                        cn -= 64;
-                    }
-                    wave_lds_sync();
-                }
-                uint32_t w = cn + incl - mine;
-                if (cn + total <= CBUF) {
-                    while (m64) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(m64);
-                        m64 &= m64 - 1ull;
-                        pbuf[w++] = ebase | b;
-                    }
-                    cn += total;
-                } else {
-                    // more candidates in ONE chunk than the buffer holds (a stretch where nearly every position passes stage 1):
-                    // lane after lane, 64 positions at a time
-                    for (uint32_t l = 0; l < 64; l++) {
-                        const unsigned long long ml = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ch, (int)l) << 32) |
-                                                      (uint32_t)__builtin_amdgcn_readlane((int)cl, (int)l);
-                        if (ml == 0) continue;
-                        const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)ebase, (int)l);
-                        if ((ml >> lane) & 1ull) pbuf[cn + (uint32_t)__builtin_popcountll(ml & ((1ull << lane) - 1ull))] = eb | lane;
-                        cn += (uint32_t)__builtin_popcountll(ml);
-                        if (cn + 64 > CBUF) {
-                            wave_lds_sync();
-                            while (cn >= 64) {
-                                ScanRound tmp;
-                                scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
-                                stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
-                                n_rounded += 64;
-                                cn -= 64;
-                            }
-                            wave_lds_sync();
-                        }
-                    }
-                }
-            }
-            vb_prev = vb;
-            __builtin_amdgcn_s_setprio(2);
-            // the next chunk: alignment A is in; nothing is outstanding in LDS now, which is the cheap moment for a
-            // stage-1.5 round; then alignment B goes in flight across the loop edge.  A block's last step empties the
-            // buffer: the block's survivors then sit in one run of the wave's slice (blk_info), and an entry never waits
-            // longer than a block (it names its chunk relative to the block's first one)
-            kssd_grp_merge<SUBK, KSSD_GW, 0>(rawa, alo, ahi);
-            if (ABL != 2) {
-                // the rounds issued one step ago are completed (their gathers have long arrived) -- with them, behind a block's
-                // last step, the block's blk_info entry -- and the next round is issued.  A block's last step issues everything
-                // that is left (two rounds in flight; more than 128 entries: the rest at once), so that the buffer is empty when
-                // the next block begins and a block's survivors are one run of the slice
-                finish_pending();
-                if (!last) {
-                    if (cn >= 64) {  // (a round in every step whatever it holds -- younger gathers, more L2 hits -- was slower: profiles/r03x)
-                        const uint32_t n = cn < 64 ? cn : 64;
-                        wave_lds_sync();
-                        scan_round_issue(a, blk_c0, pbuf, cn - n, n, lane, pendA);
-                        n_rounded += n;
-                        cn -= n;
-                    }
-                } else if (cn) {
-                    wave_lds_sync();
-                    if (cn > 128) {  // (dense parameter sets)
-                        do {
-                            ScanRound tmp;
-                            scan_round_issue(a, blk_c0, pbuf, cn - 64, 64, lane, tmp);
-                            stored += scan_round_complete<SUBK, ABL>(a, bloom, wid, stored, lane, tmp, abl_acc);
-                            n_rounded += 64;
-                            cn -= 64;
-                        } while (cn > 128);
-                    }
-                    uint32_t n = cn < 64 ? cn : 64;
-                    scan_round_issue(a, blk_c0, pbuf, cn - n, n, lane, pendA);
-                    n_rounded += n;
-                    cn -= n;
-                    if (cn) {
-                        scan_round_issue(a, blk_c0, pbuf, 0, cn, lane, pendB);
-                        n_rounded += cn;
-                        cn = 0;
-                    }
-                }
-            }
-            kssd_grp_issue<SUBK, KSSD_GW, 1>(nxt.W, T1, raw);
-        }
-    };
-    static_assert(SCAN_BLOCK == 4, "a block is the four written-out steps below");
-    for (;;) {
-        const unsigned long long c = blk_c0;
-        const bool more = b_nxt < n_blocks;
-        // chunks of the block after this one (none: reads clamped to the last chunk of the batch, never looked at)
-        const unsigned long long nb = more ? (unsigned long long)(wg_first + b_nxt) * SCAN_BLOCK : clast;
-        const uint32_t b_nn = take(b_nxt);
-        step(r0, r1, r3, c, 0u, c + 3, false);
-        step(r1, r2, r0, c + 1, 1u, nb, false);
-        step(r2, r3, r1, c + 2, 2u, nb + 1, false);
-        step(r3, r0, r2, c + 3, 3u, nb + 2, true);
-        defer_blk = wg_first + b_cur;  // its last rounds are in flight: finish_pending() of the next step (or below) writes the entry
-        defer_first = cur_first;
-        if (!more) {
-            finish_pending();
-            break;
-        }
-        b_cur = b_nxt;
-        b_nxt = b_nn;
-        blk_c0 = nb;
-        vb_prev = 0;
-    }
-    KSSD_DEV_DO(if (a.dev_times && lane == 0) {
-        a.dev_times[wid * 3] = dev_t0;
-        a.dev_times[wid * 3 + 1] = dev_t1;
-        a.dev_times[wid * 3 + 2] = __builtin_readcyclecounter();
-    })
-    if (lane == 0) {
-        a.cand_count[wid] = stored;  // (more than cand_cap: the slice was too small -- scan_totals reports it, the call is repeated larger)
-        a.stage1_count[wid] = n_rounded;
-    }
-    if (ABL != 0) {
-        for (int i = 0; i < Gp::NMAX; i++) abl_acc ^= raw[i];
-        if (abl_acc == 0x9e3779b9u) a.cand[0] = make_ulonglong2(abl_acc, 0);  // keeps the ablated work alive
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// kernel 1b: stage 2, the exact evaluation of the candidates (kssd_stage2 in kssd_core.h: validity of all
-// 2k bases, canonical strand, sub-context -> rank through the cuckoo table, reduced tuple), one lane per
-// candidate at full occupancy.  Survivors are appended to their genome's staging region with one returning
-// atomic per wave and genome.
-// ---------------------------------------------------------------------------------------------------
-// Staged tuples are sorted per genome.  Plain mode: the key is the reduced tuple (u32).  First-position mode
-// (KSSD_SKETCH_FIRST_POS): key = tuple << 32 | position inside the genome, so that the first entry of a run of equal
-// tuples carries the tuple's first occurrence -- what the host needs to replay the reference's hash insertions in
-// sequence order and leave combco.* byte-identical even where two ids of a genome probe the same slot.
-// what the waves of the scan left per slice, added up into the call's status by ONE workgroup of the stage behind the scan
-// (plain stores: no other kernel writes these four words)
-__device__ __forceinline__ void scan_totals(const uint32_t *__restrict__ cand_count, uint32_t n_slices, unsigned long long cand_cap,
-                                            SketchStatus *st, unsigned long long *s_acc /* LDS: 3 words */)
-{
-    const uint32_t *stage1_count = cand_count + n_slices;
-    if (threadIdx.x == 0) s_acc[0] = s_acc[1] = s_acc[2] = 0;
-    __syncthreads();
-    unsigned long long bloom = 0, stage1 = 0, need = 0;
-    for (uint32_t w = threadIdx.x; w < n_slices; w += blockDim.x) {
-        const uint32_t n = cand_count[w];
-        bloom += n;
-        stage1 += stage1_count[w];
-        need = n > need ? n : need;
-    }
-    atomicAdd(&s_acc[0], bloom);
-    atomicAdd(&s_acc[1], stage1);
-    atomicMax(&s_acc[2], need);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        st->n_bloom = s_acc[0];
-        st->n_stage1 = s_acc[1];
-        if (s_acc[2] > cand_cap) {
-            st->cand_overflow = 1u;
-            st->cand_need = (uint32_t)s_acc[2];
-        }
-    }
-}
-
-template <typename K> struct KeyOps;
-template <> struct KeyOps<uint32_t> {
-    static __device__ __forceinline__ uint32_t id(uint32_t k) { return k; }
-    static __device__ __forceinline__ uint32_t pos(uint32_t) { return 0u; }
-    static __device__ __forceinline__ uint32_t make(uint32_t dr, uint32_t) { return dr; }
-    static constexpr uint32_t pad() { return 0xFFFFFFFFu; }
-};
-template <> struct KeyOps<unsigned long long> {
-    static __device__ __forceinline__ uint32_t id(unsigned long long k) { return (uint32_t)(k >> 32); }
-    static __device__ __forceinline__ uint32_t pos(unsigned long long k) { return (uint32_t)k; }
-    static __device__ __forceinline__ unsigned long long make(uint32_t dr, uint32_t p) { return ((unsigned long long)dr << 32) | p; }
-    static constexpr unsigned long long pad() { return 0xFFFFFFFFFFFFFFFFull; }
-};
-
-struct ExactArgs {
-    const uint32_t *packed;
-    const uint32_t *mask;
-    const uint32_t *chunk_gid;
-    const unsigned long long *chunk_off;  // per genome, in chunks
-    const KssdG *G;
-    const ulonglong2 *cand;  // {global position of the sub-context, carried k-mer bits | known-valid << 63}
-    unsigned long long cand_cap;
-    const uint32_t *cand_count;
-    uint32_t n_slices;
-    uint32_t carry;  // kssd_carry_ok: the payload holds the whole k-mer, the packed stream is not read again
-    const unsigned long long *reg_off;
-    uint32_t *cursor;
-    void *regions;  // uint32_t[] or, in first-position mode, unsigned long long[]
-    uint32_t by_pos;  // KSSD_SKETCH_BY_POS: the 64-bit key is position << 32 | tuple, so that the sort leaves sequence order
-    SketchStatus *status;
-    KSSD_DEV_FIELD(uint32_t dev_no_atomic)  // A/B (wrong results): the workgroup's room is not reserved at the genome's cursor
-};
-
-#define EXACT_THREADS 256  // four waves share one reservation of staging room (see below); 1 024 threads: fewer atomics, and 450 us instead of 210 -- too few chains in flight
-#define EXACT_PER 4  // candidates per thread: the kernel is a chain of dependent memory round trips (record -> genome of the chunk ->
-                     // cuckoo slots -> cursor -> staging region), so every thread keeps four chains in flight
-template <typename K>
-__global__ __launch_bounds__(EXACT_THREADS) void sketch_exact_kernel(KssdParams P, ExactArgs x)
-{
-    // grid = (blocks per slice, slices): block (bx, w) takes candidates [1024 bx, 1024 bx + 1024) of scan wave w,
-    // thread t the candidates 1024 bx + 256 j + t
-    const uint32_t lane = lane_id();
-    const uint32_t w = blockIdx.y;
-    const uint32_t want = x.cand_count[w];
-    if (blockIdx.x == 0 && blockIdx.y == 0) {  // (workgroup-uniform)
-        __shared__ unsigned long long s_acc[3];
-        scan_totals(x.cand_count, x.n_slices, x.cand_cap, x.status, s_acc);
-    }
-    const uint32_t n = want < x.cand_cap ? want : (uint32_t)x.cand_cap;
-    const uint32_t i0 = blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) + threadIdx.x;
-    if (blockIdx.x * ((uint32_t)EXACT_THREADS * EXACT_PER) >= n) return;  // whole block past the end of the slice
-    // Same arithmetic as kssd_stage2 (kssd_core.h).  The candidate record carries the k-mer's bases (the scan's Bloom rounds cut
-    // them out of the packed words: kssd_carry_from_words) and whether all of them are known to be bases, so this stage is a streaming
-    // read of 16-byte records plus two probes of the L2-resident cuckoo table; the packed stream is read again only for
-    // parameter sets whose k-mer is longer than the 20 carried bases, the mask only for the ~2 % of the candidates near an
-    // invalid position.  Out-of-genome k-mers are rejected at the end; their reads stay inside the batch (position clamped
-    // at 0, slack words after the last chunk).
-    bool ok[EXACT_PER];
-    uint32_t dr[EXACT_PER], gid[EXACT_PER], gpos[EXACT_PER], dim[EXACT_PER];
-    ulonglong2 cd[EXACT_PER];
-    uint64_t u[EXACT_PER];
-    bool valid[EXACT_PER];
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) {
-        const uint32_t i = i0 + (uint32_t)EXACT_THREADS * j;
-        ok[j] = i < n;
-        cd[j] = ok[j] ? x.cand[(unsigned long long)w * x.cand_cap + i] : make_ulonglong2(0ull, 0ull);
-    }
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) gid[j] = ok[j] ? x.chunk_gid[cd[j].x >> 12] : 0u;
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) {
-        const long long b0 = (long long)cd[j].x - P.out;
-        const unsigned long long b0c = b0 < 0 ? 0ull : (unsigned long long)b0;
-        const bool known = (cd[j].y >> 63) != 0;
-        valid[j] = true;
-        u[j] = 0;
-        dim[j] = 0;
-        if (ok[j]) {
-            if (x.carry) {
-                kssd_s2_canon(P, kssd_carry_fwd(P, cd[j].y & 0xFFFFFFFFFFull), u[j], dim[j]);
-                if (!known) {
-                    const uint32_t *mp = x.mask + (b0c >> 5);
-                    const uint64_t m64 = (uint64_t)mp[0] | ((uint64_t)mp[1] << 32), need = (1ull << P.nb) - 1ull;
-                    valid[j] = ((m64 >> (b0c & 31ull)) & need) == need;
-                }
-            } else {
-                const uint32_t *pp = x.packed + (b0c >> 4), *mp = x.mask + (b0c >> 5);
-                const uint32_t p0 = __builtin_nontemporal_load(pp), p1 = __builtin_nontemporal_load(pp + 1), p2 = __builtin_nontemporal_load(pp + 2);
-                uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
-                if (!known) { m0 = mp[0]; m1 = mp[1]; }
-                valid[j] = kssd_s2_decode(P, p0, p1, p2, m0, m1, (uint32_t)b0c, u[j], dim[j]);
-            }
-        }
-    }
-    const KssdGBucket *GB = reinterpret_cast<const KssdGBucket *>(x.G);
-    KssdGBucket gb[EXACT_PER];  // one 16-byte read per candidate, all in flight together (kssd_core.h: the exact table)
-    unsigned long long glo[EXACT_PER], ghi[EXACT_PER];
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) {
-        gb[j] = GB[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
-        glo[j] = x.chunk_off[gid[j]] * KSSD_CHUNK;
-        ghi[j] = x.chunk_off[gid[j] + 1] * KSSD_CHUNK;
-    }
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) {
-        const long long s = (long long)cd[j].x, b0 = s - P.out;
-        uint32_t rank = 0;
-        int hit = kssd_g_match(gb[j], dim[j], rank);
-        if (hit == 2) hit = kssd_g_match(GB[kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)], dim[j], rank) == 1 ? 1 : 0;  // (1.4 % of the buckets)
-        bool mine;
-        dr[j] = kssd_s2_tuple(P, u[j], rank, mine);
-        ok[j] = ok[j] && valid[j] && hit == 1 && mine && b0 >= (long long)glo[j] && b0 + P.nb <= (long long)ghi[j];
-        gpos[j] = (uint32_t)(s - (long long)glo[j]);  // first-position mode: genomes are < 2^32 positions there (checked on the host)
-    }
-    // Survivors go to their genome's staging region.  Candidates arrive in stream order, so a wave's survivors almost
-    // always belong to ONE genome, and so do the workgroup's: then ONE returning atomic reserves room for all of them.
-    // (One per wave was enough for genome-sized sketches; a read set is one genome, and 34 000 waves queueing at one
-    // address took 0.45 ms for 8.6 M candidates.)
-    uint64_t bal[EXACT_PER];
-    uint32_t total = 0, g0 = 0;
-    bool have = false, same = true;
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) {
-        bal[j] = __ballot(ok[j]);
-        if (bal[j]) {
-            const uint32_t g = __builtin_amdgcn_readlane(gid[j], __builtin_ctzll(bal[j]));
-            if (!have) { g0 = g; have = true; }
-            same = same && (__ballot(ok[j] && gid[j] != g0) == 0);
-            total += (uint32_t)__builtin_popcountll(bal[j]);
-        }
-    }
-    __shared__ uint32_t s_kind[EXACT_THREADS / 64], s_g[EXACT_THREADS / 64], s_tot[EXACT_THREADS / 64], s_base;
-    const uint32_t wave = threadIdx.x >> 6;
-    if (lane == 0) { s_kind[wave] = have ? (same ? 1u : 2u) : 0u; s_g[wave] = g0; s_tot[wave] = total; }
-    __syncthreads();
-    bool wg_same = true;
-    uint32_t wg_g = 0xFFFFFFFFu, wg_before = 0, wg_total = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < EXACT_THREADS / 64; k++) {
-        const uint32_t kind = s_kind[k];
-        if (kind == 2u) wg_same = false;
-        if (kind == 1u) {
-            if (wg_g == 0xFFFFFFFFu) wg_g = s_g[k];
-            else if (s_g[k] != wg_g) wg_same = false;
-            if (k < wave) wg_before += s_tot[k];
-            wg_total += s_tot[k];
-        }
-    }
-    if (wg_same && wg_total) {  // (workgroup-uniform)
-        KSSD_DEV_DO(if (x.dev_no_atomic) { if (threadIdx.x == 0) s_base = (blockIdx.y * gridDim.x + blockIdx.x) * 400u; } else)
-        if (threadIdx.x == 0) s_base = atomicAdd(&x.cursor[wg_g], wg_total);
-        __syncthreads();
-    }
-    if (!have) return;
-    if (same) {
-        uint32_t at = 0;
-        if (wg_same) {
-            at = s_base + wg_before;
-        } else {
-            if (lane == 0) at = atomicAdd(&x.cursor[g0], total);
-            at = __builtin_amdgcn_readfirstlane(at);
-        }
-        const unsigned long long r0 = x.reg_off[g0], cap = x.reg_off[g0 + 1] - r0;
-#pragma unroll
-        for (int j = 0; j < EXACT_PER; j++) {
-            if (ok[j]) {
-                const unsigned long long pos = (unsigned long long)at + rank_in(bal[j]);
-                if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = x.by_pos ? KeyOps<K>::make(gpos[j], dr[j]) : KeyOps<K>::make(dr[j], gpos[j]);
-            }
-            at += (uint32_t)__builtin_popcountll(bal[j]);
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < EXACT_PER; j++) {  // a genome boundary inside the wave's candidates: group by genome
-        uint64_t todo = bal[j];
-        while (todo) {
-            const uint32_t leader = __builtin_ctzll(todo);
-            const uint32_t g = __builtin_amdgcn_readlane(gid[j], leader);
-            const bool mine = ok[j] && gid[j] == g;
-            const uint64_t grp = __ballot(mine);
-            uint32_t at = 0;
-            if (lane == leader) at = atomicAdd(&x.cursor[g], (uint32_t)__builtin_popcountll(grp));
-            at = __builtin_amdgcn_readlane(at, leader);
-            if (mine) {
-                const unsigned long long r0 = x.reg_off[g], cap = x.reg_off[g + 1] - r0;
-                const unsigned long long pos = (unsigned long long)at + rank_in(grp);
-                if (pos < cap) reinterpret_cast<K *>(x.regions)[r0 + pos] = x.by_pos ? KeyOps<K>::make(gpos[j], dr[j]) : KeyOps<K>::make(dr[j], gpos[j]);
-            }
-            todo &= ~grp;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// kernel 2: per-genome dedup.  One workgroup per genome: LDS bitonic sort of the staged tuples, run
-// detection, the reference's keep rules, ballot/scan compaction back into the head of the region.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum /*>=DEDUP_THREADS/64+1*/, uint32_t &total)
-{
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    uint32_t incl = wave_incl_scan(v, lane);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < DEDUP_THREADS / 64; w++) {
-        uint32_t s = wsum[w];
-        if (w < wave) off += s;
-        tot += s;
-    }
-    __syncthreads();
-    total = tot;
-    return off + incl - v;
-}
-
-// Bitonic sort of np = EPT * DEDUP_THREADS keys with the keys in registers: thread t holds elements t*EPT .. t*EPT+EPT-1.
-// A pass whose partner distance j is below EPT stays inside a thread, one below 64*EPT inside a wave (one shuffle per
-// key), and only the few passes beyond that go through LDS -- 6 of the 66 passes of a 2 048-key sort, where the plain
-// LDS version moves every key through LDS (and a block barrier) in all 66.  Leaves the sorted keys in a[0 .. np).
-__device__ __forceinline__ uint32_t shfl_xor_key(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
-__device__ __forceinline__ unsigned long long shfl_xor_key(unsigned long long v, int m)
-{
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-template <typename K, int EPT>
-__device__ __forceinline__ void sort_in_registers(K *a, const K *src /* may be a itself (fused path): no __restrict__ */, uint32_t n, uint32_t tid)
-{
-    constexpr uint32_t np = EPT * DEDUP_THREADS;
-    K x[EPT];
-#pragma unroll
-    for (int r = 0; r < EPT; r++) {
-        const uint32_t e = tid * EPT + r;
-        x[r] = e < n ? src[e] : KeyOps<K>::pad();
-    }
-    for (uint32_t k = 2; k <= np; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j < (uint32_t)EPT) {  // partner in this thread
-#pragma unroll
-                for (int r = 0; r < EPT; r++) {
-                    if ((r & j) == 0) {
-                        const uint32_t e = tid * EPT + r;
-                        const bool asc = (e & k) == 0;
-                        const K lo = x[r], hi = x[r | j];
-                        if ((lo > hi) == asc) { x[r] = hi; x[r | j] = lo; }
-                    }
-                }
-            } else {
-                // j >= EPT (and k > j): whether this thread keeps the smaller or the larger key of a pair is the same for
-                // all its keys
-                const uint32_t e0 = tid * EPT;
-                const bool take_min = ((e0 & j) == 0) == ((e0 & k) == 0);
-                if (j < 64u * EPT) {  // partner in this wave
-                    const int m = (int)(j / EPT);
-#pragma unroll
-                    for (int r = 0; r < EPT; r++) {
-                        const K y = shfl_xor_key(x[r], m);
-                        const K lo = x[r] < y ? x[r] : y, hi = x[r] < y ? y : x[r];
-                        x[r] = take_min ? lo : hi;
-                    }
-                } else {  // partner in another wave: through LDS
-#pragma unroll
-                    for (int r = 0; r < EPT; r++) a[e0 + r] = x[r];
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < EPT; r++) {
-                        const K y = a[(e0 ^ j) + r];
-                        const K lo = x[r] < y ? x[r] : y, hi = x[r] < y ? y : x[r];
-                        x[r] = take_min ? lo : hi;
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < EPT; r++) a[tid * EPT + r] = x[r];
-    __syncthreads();
-}
-
-// Sort of one genome's keys by bucket counting in LDS, for the sizes the per-genome kernel mostly sees (up to
-// DEDUP_BSORT_MAX keys).  The bitonic network in registers moves every key through the LDS crossbar once per pass -- ~45
-// `ds_bpermute` per key at 2 048 keys, and a `ds_bpermute` costs what a conflicted LDS read costs (profiles/r03b_valu_probe.txt):
-// with four workgroups per CU the sort took 45 000 of the kernel's 118 000 cycles.  The ids are reduced tuples -- the
-// outermost bases of the canonical k-mer in their top bits -- so they spread over the id range: as many buckets as key
-// slots (one LDS atomic per key to count, one to place), a workgroup scan of the counters, and an insertion sort of
-// every bucket by the thread that owns it (most hold none or one; the canonical strand makes low prefixes more likely,
-// a bucket of a dozen is rare).  Equal ids (repeats) meet in one bucket.  A batch whose ids do not spread -- low-complexity
-// sequence, crafted input -- shows up as a bucket above DEDUP_BSORT_BUCKET keys: the function says no and the bitonic sort
-// runs as before.  Returns true with the sorted keys in b[0 .. n).
-#define DEDUP_BSORT_MAX 4096u     // key slots (= buckets) at most
-#define DEDUP_BSORT_BUCKET 24u    // a fuller bucket sends the genome to the bitonic sort
-// The ids lie in [id_base, id_base + 2^id_bits) (roughly: beyond it they share the last bucket).  max_bucket: a fuller bucket
-// sends the keys to the bitonic sort up front (DEDUP_BSORT_BUCKET for a genome's keys; none for an item of a large genome,
-// whose ids repeat by the read set's coverage -- equal keys cost an insertion sort nothing); a thread that has MOVED
-// DEDUP_BSORT_MOVES keys in its buckets gives up for the workgroup either way (src is untouched).
-#define DEDUP_BSORT_MOVES 256u
-#define DEDUP_BSORT_HEAVY 256u    // full buckets (more than 16 keys) a workgroup lists at most
-template <typename K>
-__device__ __forceinline__ bool lds_bucket_sort(const K *src, K *b, uint32_t *cnt, uint32_t n, uint32_t nb /*pow2*/, uint32_t id_base, uint32_t id_bits,
-                                                uint32_t max_bucket, uint32_t tid, uint32_t *wsum)
-{
-    uint32_t lg = 0;
-    while ((1u << lg) < nb) lg++;
-    const uint32_t shift = id_bits > lg ? id_bits - lg : 0u, last = nb - 1u;
-    for (uint32_t i = tid; i < nb; i += DEDUP_THREADS) cnt[i] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += DEDUP_THREADS) {
-        const uint32_t bk = (KeyOps<K>::id(src[i]) - id_base) >> shift;
-        atomicAdd(&cnt[bk < last ? bk : last], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the counters: every thread owns nb / DEDUP_THREADS consecutive ones (or none)
-    const uint32_t per = nb >= DEDUP_THREADS ? nb / DEDUP_THREADS : 1u, b0 = tid * per;
-    uint32_t sum = 0, mx = 0;
-    if (b0 < nb)
-        for (uint32_t k = 0; k < per; k++) { const uint32_t c = cnt[b0 + k]; sum += c; mx = c > mx ? c : mx; }
-    uint32_t total;
-    uint32_t run = block_excl_scan(sum, wsum, total);
-    // the fullest bucket decides (workgroup-uniform): packed into the scan's scratch words by a second tiny reduction
-    uint32_t mx_all;
-    {
-        const uint32_t lane = lane_id(), wave = tid >> 6;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, 64); mx = o > mx ? o : mx; }
-        if (lane == 0) wsum[wave] = mx;
-        __syncthreads();
-        mx_all = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < DEDUP_THREADS / 64; w++) mx_all = wsum[w] > mx_all ? wsum[w] : mx_all;
-        __syncthreads();
-    }
-    if (mx_all > max_bucket) return false;
-    if (b0 < nb)
-        for (uint32_t k = 0; k < per; k++) { const uint32_t c = cnt[b0 + k]; cnt[b0 + k] = run; run += c; }  // the bucket's first slot
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += DEDUP_THREADS) {
-        const K kv = src[i];
-        const uint32_t bk = (KeyOps<K>::id(kv) - id_base) >> shift;
-        b[atomicAdd(&cnt[bk < last ? bk : last], 1u)] = kv;
-    }
-    __syncthreads();
-    // small buckets: an insertion sort by the thread that owns the bucket.  A full bucket is nearly always a few ids many
-    // times over (a read set's coverage): those go on a list and a whole wave takes each (below)
-    uint32_t moves = 0;
-    if (tid == 0) wsum[0] = 0;  // the list's length; the list itself: the scan's scratch words do not hold it -> the counters' tail
-    __syncthreads();
-    uint32_t *heavy = cnt + nb;  // [DEDUP_BSORT_HEAVY] bucket numbers (the caller's counter array has this room)
-    for (uint32_t bk = tid; bk < nb; bk += DEDUP_THREADS) {  // (after the scatter cnt[bk] is the bucket's end = the next bucket's first slot)
-        const uint32_t s0 = bk ? cnt[bk - 1] : 0u, e0 = cnt[bk];
-        if (e0 - s0 > 16u) {
-            const uint32_t at = atomicAdd(&wsum[0], 1u);
-            if (at < DEDUP_BSORT_HEAVY) heavy[at] = bk;
-            continue;
-        }
-        for (uint32_t i = s0 + 1; i < e0 && moves < DEDUP_BSORT_MOVES; i++) {
-            const K x = b[i];
-            uint32_t j = i;
-            while (j > s0 && b[j - 1] > x) { b[j] = b[j - 1]; j--; moves++; }
-            b[j] = x;
-        }
-    }
-    __syncthreads();
-    const uint32_t n_heavy = wsum[0];
-    bool fail = moves >= DEDUP_BSORT_MOVES || n_heavy > DEDUP_BSORT_HEAVY;
-    if (!fail && n_heavy) {
-        // a wave per full bucket: its distinct ids (up to eight), how often each is there and the smallest key of each, then the
-        // bucket rewritten as runs in id order -- every run as copies of its SMALLEST key, which is all the keep rules look at
-        // (the run's first entry: the tuple's first position; the run's length)
-        const uint32_t lane = lane_id(), wave = tid >> 6;
-        for (uint32_t hi = wave; hi < n_heavy; hi += DEDUP_THREADS / 64) {
-            const uint32_t bk = heavy[hi];
-            const uint32_t s0 = bk ? cnt[bk - 1] : 0u, e0 = cnt[bk];
-            K mk[8];
-            uint32_t c[8], nd = 0;
-            bool many = false;
-#pragma unroll
-            for (uint32_t d = 0; d < 8; d++) { mk[d] = KeyOps<K>::pad(); c[d] = 0; }
-            for (uint32_t base = s0; base < e0 && !many; base += 64) {
-                const bool valid = base + lane < e0;
-                const K x = valid ? b[base + lane] : KeyOps<K>::pad();
-                uint64_t pending = __ballot(valid);
-                while (pending && !many) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(pending);
-                    const uint32_t idl = (uint32_t)__builtin_amdgcn_readlane((int)KeyOps<K>::id(x), (int)l);
-                    const bool same = valid && KeyOps<K>::id(x) == idl;
-                    const uint64_t sb = __ballot(same);
-                    K mn = same ? x : KeyOps<K>::pad();
-#pragma unroll
-                    for (int m = 1; m < 64; m <<= 1) { const K o = shfl_xor_key(mn, m); mn = o < mn ? o : mn; }
-                    const uint32_t add = (uint32_t)__builtin_popcountll(sb);
-                    bool found = false;
-#pragma unroll
-                    for (uint32_t d = 0; d < 8; d++)
-                        if (!found && d < nd && KeyOps<K>::id(mk[d]) == idl) { c[d] += add; mk[d] = mn < mk[d] ? mn : mk[d]; found = true; }
-                    if (!found) {
-                        if (nd == 8) many = true;
-#pragma unroll
-                        for (uint32_t d = 0; d < 8; d++)
-                            if (d == nd) { mk[d] = mn; c[d] = add; }
-                        nd++;
-                    }
-                    pending &= ~sb;
-                }
-            }
-            if (many) { fail = true; continue; }
-#pragma unroll
-            for (uint32_t r = 0; r < 7; r++)  // the (up to eight) runs by key; unused entries hold the pad key and stay behind
-#pragma unroll
-                for (uint32_t d = 0; d + 1 < 8; d++)
-                    if (mk[d + 1] < mk[d]) { const K tk = mk[d]; mk[d] = mk[d + 1]; mk[d + 1] = tk; const uint32_t tc = c[d]; c[d] = c[d + 1]; c[d + 1] = tc; }
-            uint32_t p = s0;
-#pragma unroll
-            for (uint32_t d = 0; d < 8; d++) {
-                for (uint32_t t = lane; t < c[d]; t += 64) b[p + t] = mk[d];
-                p += c[d];
-            }
-        }
-    }
-    return __syncthreads_or(fail) == 0;
-}
-
-// FUSED: the workgroup takes its genome's candidates straight from the scan's candidate list (the slices of the scan
-// waves whose chunk runs overlap the genome), evaluates them (stage 2, as sketch_exact_kernel does) and collects the
-// survivors in LDS, where the sort needs them anyway: no staging region is written and read back, no cursor atomics, no
-// chunk -> genome map, one kernel less.  Used whenever no genome of the batch needs the global-memory path.
-struct FuseArgs {
-    const ulonglong2 *cand;
-    const unsigned long long *blk_info;  // per block of SCAN_BLOCK chunks: first record and record count (scan_blk_pack)
-    const unsigned long long *chunk_off;
-    const uint32_t *packed, *mask;
-    const KssdG *G;
-    uint32_t carry, by_pos, lds_keys;  // lds_keys: keys the dynamic LDS array holds
-    const uint32_t *cand_count;        // FUSED: the scan's per-slice counts (workgroup 0 adds them up into the status: scan_totals)
-    uint32_t n_slices;
-    unsigned long long cand_cap;
-    uint32_t id_bits, bsort_keys;      // ids are below 2^id_bits (roughly); bsort_keys: key slots of the bucket sort's LDS arrays (0: none)
-    KSSD_DEV_FIELD(unsigned long long *dev_times)  // per workgroup {start, keys in LDS, sorted, done}
-    KSSD_DEV_FIELD(uint32_t dev_split)             // KSSD_DEV_GATHERSPLIT: the four stamps are start, block table in, first round done, keys in LDS
-};
-#define FUSE_PER 4  // candidates a thread evaluates at a time (six spill at 64 VGPRs)
-
-// PARTS: a genome whose staged tuples do not fit one workgroup's LDS sort, but whose ids split by their top bits into 2, 4,
-// 8 or 16 ranges that do (a 3 Gb record at -s 7 -l 5 stages ~45 000 tuples; chromosomes).  Workgroup (m, p) of the launch
-// takes the tuples of medium genome m whose id lies in range p out of the genome's staging region into LDS, sorts them and
-// applies the keep rules like any small genome; the ranges are disjoint and ordered, so their results, one behind the other,
-// are the genome's sorted sketch (dedup_parts_finish_kernel puts them back into the region and adds up the counts).
-// Two launches for all such genomes of a batch, where the global-memory path takes seven per genome.
-#define DEDUP_MAX_PARTS_LOG2 4
-struct PartArgs {
-    const uint2 *list;   // per medium genome: genome index, log2 of its number of parts
-    void *out;           // [n_medium][1 << DEDUP_MAX_PARTS_LOG2][part_cap] kept keys per part
-    uint32_t *cnt;       // [n_medium][1 << DEDUP_MAX_PARTS_LOG2][4]: kept, distinct, occurrences of id 0, overflowed
-    uint32_t part_cap;   // keys one part may hold (the LDS array)
-    uint32_t id_bits;    // ids are below 2^id_bits (a little above it where the rank is ADDED over the outer bases: clamped)
-    // RANGES (one large genome per launch, see big_rng_* below): the genome's keys partitioned by ranges of their leading
-    // field; workgroup k sorts the whole bins that begin inside [k RNG_T, (k+1) RNG_T) of the partitioned array, in place
-    const void *parted;        // partitioned keys (the sort's kept keys go back to the head of the item's span)
-    const uint32_t *bin_start; // [rng_bins + 1]
-    uint32_t *item_cnt;        // [items]: kept keys of the item
-    uint32_t *item_s0;         // [items]: where the item's span begins
-    const uint32_t *item_bin;  // [items + 1]: the item's first bin
-    uint32_t *acc;             // [2]: the genome's distinct tuples, occurrences of id 0
-    uint32_t rng_bins, rng_g;
-};
-enum { DEDUP_STAGED = 0, DEDUP_FUSED = 1, DEDUP_PARTS = 2, DEDUP_RANGES = 3 };
-#define RNG_T 1024u             // span of the partitioned array an item begins in
-#define RNG_BIN_MEAN 512u      // keys per bin aimed at
-#define RNG_MAX_LOG2_BINS 14u
-#define RNG_BSORT_KEYS 2048u    // bucket-sort arrays of an item (items of up to 2 048 keys, nearly all of them): 33 KB of LDS per workgroup,
-                                // four per CU, instead of 49 KB and three (configs[3] step -0.7 %); larger items take the bitonic sort
-#define RNG_PART_CAP 4096u      // keys an item may hold (its LDS array): RNG_T + the largest bin, i.e. a bin six times the mean
-
-template <typename K, int MODE>
-__global__ __launch_bounds__(DEDUP_THREADS, 8) void sketch_dedup_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off,
-                                                                      const uint32_t *__restrict__ cursor,
-                                                                      K *__restrict__ regions, uint32_t *__restrict__ kept,
-                                                                      uint32_t flags, uint32_t min_occ, uint32_t big_min,
-                                                                      SketchStatus *st, FuseArgs fx, PartArgs px)
-{
-    constexpr bool FUSED = MODE == DEDUP_FUSED;
-    KSSD_DEV_STAMP(dev_t0);
-    KSSD_DEV_VAR(dev_t1);
-    KSSD_DEV_VAR(dev_t2);
-    KSSD_DEV_VAR(dev_tA);
-    KSSD_DEV_VAR(dev_tB);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    K *a = reinterpret_cast<K *>(smem);
-    uint32_t g = blockIdx.x, part = 0, lg_parts = 0;
-    if (MODE == DEDUP_RANGES) {
-        g = px.rng_g;
-    } else if (MODE == DEDUP_PARTS) {
-        const uint2 md = px.list[blockIdx.x];
-        g = md.x;
-        lg_parts = md.y;
-        part = blockIdx.y;
-        if (part >> lg_parts) return;  // this genome has fewer parts than the launch is wide
-    } else if (reg_off[blockIdx.x + 1] - reg_off[blockIdx.x] > big_min) {
-        return;  // too large for one workgroup's LDS: the parts launch or the global-memory path below
-    }
-    __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
-    __shared__ uint32_t s_distinct, s_zero_occ;
-    const uint32_t tid = threadIdx.x;
-    const unsigned long long r0 = reg_off[g];
-    const uint32_t cap = (uint32_t)(reg_off[g + 1] - r0);
-    uint32_t *pcnt = MODE == DEDUP_PARTS ? px.cnt + ((size_t)blockIdx.x << (DEDUP_MAX_PARTS_LOG2 + 2)) + part * 4u : nullptr;
-    uint32_t n;
-    unsigned long long rng_s0 = 0;
-    uint32_t rng_id_base = 0, rng_id_bits = 0;  // the item's ids lie in [base, base + 2^bits)
-    if (MODE == DEDUP_RANGES) {
-        __shared__ uint32_t s_span[4];
-        const uint32_t staged = cursor[g];
-        if (staged > cap) return;  // (big_rng_hist_kernel has reported the overflow)
-        const unsigned long long lo = (unsigned long long)blockIdx.x * RNG_T;
-        if (tid == 0) {  // the bins whose first key lies in [lo, hi) (big_rng_binscan_kernel has looked them up)
-            const uint32_t b0 = px.item_bin[blockIdx.x], b1 = px.item_bin[blockIdx.x + 1];
-            s_span[0] = px.bin_start[b0];
-            s_span[1] = px.bin_start[b1];  // (bin_start[rng_bins] = all keys)
-            s_span[2] = b0;
-            s_span[3] = b1 > b0 ? b1 - b0 : 1u;
-        }
-        __syncthreads();
-        rng_s0 = s_span[0];
-        {
-            uint32_t lgb = 0;
-            while ((1u << lgb) < px.rng_bins) lgb++;
-            const uint32_t bin_shift = px.id_bits - lgb;  // (big_rng_hist_kernel's shift)
-            uint32_t wb = 0;
-            while ((1u << wb) < s_span[3]) wb++;
-            rng_id_base = s_span[2] << bin_shift;
-            rng_id_bits = wb + bin_shift;
-        }
-        n = lo < staged ? s_span[1] - s_span[0] : 0u;
-        if (n > px.part_cap) {  // the keys do not spread (or one id is there tens of thousands of times): the caller repeats with the global sort
-            if (tid == 0) atomicOr(&st->ranges_skew, 1u);
-            n = 0;
-        }
-        if (n == 0) {
-            if (tid == 0) { px.item_cnt[blockIdx.x] = 0; px.item_s0[blockIdx.x] = 0; }
-            return;
-        }
-        const K *src_g = reinterpret_cast<const K *>(px.parted) + rng_s0;
-        for (uint32_t i = tid; i < n; i += DEDUP_THREADS) a[i] = src_g[i];
-        __syncthreads();
-    } else if (MODE == DEDUP_PARTS) {
-        __shared__ uint32_t s_np;
-        const uint32_t lane = lane_id();
-        if (tid == 0) s_np = 0;
-        __syncthreads();
-        const uint32_t staged = cursor[g];
-        if (staged > cap) {  // the exact stage wanted to stage more than the region holds: the call is repeated larger
-            if (tid == 0) {
-                if (part == 0) {
-                    atomicOr(&st->region_overflow, 1u);
-                    unsigned long long need = ((unsigned long long)staged * 256ull + cap - 1) / (cap ? cap : 1);
-                    atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
-                }
-                pcnt[0] = pcnt[1] = pcnt[2] = 0;
-                pcnt[3] = 1;
-            }
-            return;
-        }
-        const uint32_t shift = px.id_bits - lg_parts, last_part = (1u << lg_parts) - 1u;
-        // eight tuples per thread and round, their reads in flight together (one per round: 88 dependent round trips for the
-        // 45 000 tuples of a 3 Gb record, 143 us for the launch)
-        for (uint32_t i0 = 0; i0 < staged; i0 += DEDUP_THREADS * 8) {
-            K kv[8];
-            bool mine[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t i = i0 + (uint32_t)j * DEDUP_THREADS + tid;
-                kv[j] = i < staged ? regions[r0 + i] : KeyOps<K>::pad();
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t i = i0 + (uint32_t)j * DEDUP_THREADS + tid;
-                const uint32_t pp = KeyOps<K>::id(kv[j]) >> shift;
-                mine[j] = i < staged && (pp < last_part ? pp : last_part) == part;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint64_t bal = __ballot(mine[j]);
-                if (bal) {  // one LDS atomic per wave reserves room for its tuples
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&s_np, (uint32_t)__builtin_popcountll(bal));
-                    at = __builtin_amdgcn_readfirstlane(at) + rank_in(bal);
-                    if (mine[j] && at < px.part_cap) a[at] = kv[j];
-                }
-            }
-        }
-        __syncthreads();
-        n = s_np;
-        if (n > px.part_cap) {  // this id range holds more than the LDS sort takes: larger regions mean more, narrower parts
-            if (tid == 0) {
-                atomicOr(&st->region_overflow, 1u);
-                const unsigned long long need = ((unsigned long long)n * 256ull + px.part_cap - 1) / px.part_cap;
-                atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
-                pcnt[0] = pcnt[1] = pcnt[2] = 0;
-                pcnt[3] = 1;
-            }
-            return;
-        }
-    } else if (FUSED) {
-        __shared__ uint32_t s_n, s_pref[DEDUP_THREADS];
-        __shared__ unsigned long long s_first[DEDUP_THREADS];
-        const uint32_t lane = lane_id();
-        if (blockIdx.x == 0 && fx.n_slices) scan_totals(fx.cand_count, fx.n_slices, fx.cand_cap, st, s_first);  // (s_first: not in use yet)
-        if (tid == 0) s_n = 0;
-        const unsigned long long cb = fx.chunk_off[g], ce = fx.chunk_off[g + 1];
-        const long long glo = (long long)(cb * KSSD_CHUNK), ghi = (long long)(ce * KSSD_CHUNK);
-        // the blocks of the scan that overlap the genome's chunks (an empty genome: none)
-        const unsigned long long w0 = ce > cb ? cb / SCAN_BLOCK : 1, w1 = ce > cb ? (ce - 1) / SCAN_BLOCK : 0;
-        __syncthreads();
-        for (unsigned long long wbase = w0; wbase <= w1; wbase += DEDUP_THREADS) {
-            // candidates of up to 512 blocks, flattened: prefix of their counts in LDS, then FUSE_PER per thread and round
-            const unsigned long long w = wbase + tid;
-            uint32_t cw = 0;
-            unsigned long long first = 0;
-            if (w <= w1) {
-                const unsigned long long info = fx.blk_info[w];
-                cw = scan_blk_count(info);
-                first = scan_blk_first(info);
-            }
-            uint32_t total;
-            const uint32_t before = block_excl_scan(cw, wsum, total);
-            s_pref[tid] = before;
-            s_first[tid] = first;
-            // which block a flattened record index belongs to: a table of owners in the LDS room the sort uses later (2 bytes per
-            // record; the nine-step search of the prefix array per record otherwise: 36 dependent LDS reads per thread and round)
-            uint16_t *owner = reinterpret_cast<uint16_t *>(a + fx.lds_keys);
-            const bool owned = total <= fx.bsort_keys * (uint32_t)(sizeof(K) / 2);
-            if (owned)
-                for (uint32_t j = 0; j < cw; j++) owner[before + j] = (uint16_t)tid;
-            __syncthreads();
-            KSSD_DEV_MARK_ONCE(dev_tA);
-            for (uint32_t f0 = 0; f0 < total; f0 += DEDUP_THREADS * FUSE_PER) {
-                bool ok[FUSE_PER];
-                ulonglong2 cd[FUSE_PER];
-                uint32_t dim[FUSE_PER];
-                uint64_t u[FUSE_PER];
-#pragma unroll
-                for (int j = 0; j < FUSE_PER; j++) {
-                    const uint32_t f = f0 + (uint32_t)j * DEDUP_THREADS + tid;
-                    ok[j] = f < total;
-                    cd[j] = make_ulonglong2(0ull, 0ull);
-                    if (ok[j]) {
-                        uint32_t lo = 0;
-                        if (owned) {
-                            lo = owner[f];
-                        } else {
-                            uint32_t hi = DEDUP_THREADS - 1;  // last block s with s_pref[s] <= f
-                            while (lo < hi) {
-                                const uint32_t mid = (lo + hi + 1) >> 1;
-                                if (s_pref[mid] <= f) lo = mid;
-                                else hi = mid - 1;
-                            }
-                        }
-                        cd[j] = fx.cand[s_first[lo] + (f - s_pref[lo])];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < FUSE_PER; j++) {
-                    const long long sp = (long long)cd[j].x, b0 = sp - P.out;
-                    ok[j] = ok[j] && sp >= glo && sp < ghi && b0 >= glo && b0 + P.nb <= ghi;  // this genome's, and inside it
-                    u[j] = 0;
-                    dim[j] = 0;
-                    if (ok[j]) {
-                        const unsigned long long b0c = (unsigned long long)b0;
-                        const bool known = (cd[j].y >> 63) != 0;
-                        if (fx.carry) {
-                            kssd_s2_canon(P, kssd_carry_fwd(P, cd[j].y & 0xFFFFFFFFFFull), u[j], dim[j]);
-                            if (!known) {
-                                const uint32_t *mp = fx.mask + (b0c >> 5);
-                                const uint64_t m64 = (uint64_t)mp[0] | ((uint64_t)mp[1] << 32), need = (1ull << P.nb) - 1ull;
-                                ok[j] = ((m64 >> (b0c & 31ull)) & need) == need;
-                            }
-                        } else {
-                            const uint32_t *pp = fx.packed + (b0c >> 4), *mp = fx.mask + (b0c >> 5);
-                            uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
-                            if (!known) { m0 = mp[0]; m1 = mp[1]; }
-                            ok[j] = kssd_s2_decode(P, pp[0], pp[1], pp[2], m0, m1, (uint32_t)b0c, u[j], dim[j]);
-                        }
-                    }
-                }
-                const KssdGBucket *GB = reinterpret_cast<const KssdGBucket *>(fx.G);
-                KssdGBucket gb[FUSE_PER];
-#pragma unroll
-                for (int j = 0; j < FUSE_PER; j++) gb[j] = GB[kssd_g_slot(dim[j], P.g_mul[0], P.g_log2)];
-#pragma unroll
-                for (int j = 0; j < FUSE_PER; j++) {
-                    uint32_t rank = 0;
-                    int hit = kssd_g_match(gb[j], dim[j], rank);
-                    if (hit == 2) hit = kssd_g_match(GB[kssd_g_slot(dim[j], P.g_mul[1], P.g_log2)], dim[j], rank) == 1 ? 1 : 0;
-                    bool mine;
-                    const uint32_t dr = kssd_s2_tuple(P, u[j], rank, mine);
-                    ok[j] = ok[j] && hit == 1 && mine;
-                    const uint64_t bal = __ballot(ok[j]);
-                    if (bal) {  // one LDS atomic per wave reserves room for its survivors
-                        uint32_t at = 0;
-                        if (lane == 0) at = atomicAdd(&s_n, (uint32_t)__builtin_popcountll(bal));
-                        at = __builtin_amdgcn_readfirstlane(at) + rank_in(bal);
-                        if (ok[j] && at < fx.lds_keys) {
-                            const uint32_t gpos = (uint32_t)((long long)cd[j].x - glo);
-                            a[at] = fx.by_pos ? KeyOps<K>::make(gpos, dr) : KeyOps<K>::make(dr, gpos);
-                        }
-                    }
-                }
-                KSSD_DEV_MARK_ONCE(dev_tB);
-            }
-            __syncthreads();  // s_pref is rewritten by the next round of slices
-        }
-        __syncthreads();
-        n = s_n;
-    } else {
-        n = cursor[g];
-    }
-    KSSD_DEV_MARK(dev_t1);
-    const K *src = MODE != DEDUP_STAGED ? a : regions + r0;
-    K *outp = regions + r0;  // where the kept keys go
-    if (MODE == DEDUP_PARTS) outp = reinterpret_cast<K *>(px.out) + (((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) + part) * px.part_cap;
-    if (MODE == DEDUP_RANGES) outp = reinterpret_cast<K *>(const_cast<void *>(px.parted)) + rng_s0;
-    if (MODE != DEDUP_PARTS && MODE != DEDUP_RANGES && (n > cap || n > fx.lds_keys)) {
-        if (tid == 0) {
-            atomicOr(&st->region_overflow, 1u);
-            // what the regions must grow by: the key array is 5/8 of the largest region (finish_sketch), and it is the array
-            // that this genome may have outgrown
-            const unsigned long long room = ((unsigned long long)cap * 5ull) / 8ull;
-            unsigned long long need = ((unsigned long long)n * 256ull + room - 1) / (room ? room : 1);
-            atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
-            kept[g] = 0;
-        }
-        return;
-    }
-    if (MODE != DEDUP_RANGES && (flags & SKETCH_TRACK_FILL) && tid == 0)  // only while the regions are oversized after an overflow (see sketch_status)
-        atomicMax(&st->max_need_q8, (uint32_t)(((unsigned long long)n * 256ull + cap - 1) / (cap ? cap : 1)));
-    uint32_t np = 1;
-    while (np < n) np <<= 1;
-    if (tid == 0) { s_distinct = 0; s_zero_occ = 0; }
-    // dynamic LDS: a[lds_keys] | b[bsort_keys] | counters[bsort_keys]  (lds_keys: the launch's array -- part_cap in PARTS mode)
-    const K *sorted = a;
-    bool bsorted = false;
-    if (fx.bsort_keys && n > 64 && np <= fx.bsort_keys && !(MODE == DEDUP_RANGES && fx.by_pos)) {
-        K *b = a + (MODE == DEDUP_PARTS || MODE == DEDUP_RANGES ? px.part_cap : fx.lds_keys);
-        uint32_t *bcnt = reinterpret_cast<uint32_t *>(b + fx.bsort_keys);
-        if (MODE == DEDUP_RANGES) bsorted = lds_bucket_sort<K>(src, b, bcnt, n, np, rng_id_base, rng_id_bits, 0xFFFFFFFFu, tid, wsum);
-        else bsorted = lds_bucket_sort<K>(src, b, bcnt, n, np, 0u, fx.id_bits, DEDUP_BSORT_BUCKET, tid, wsum);
-        if (bsorted) sorted = b;
-    }
-    if (bsorted) {
-    } else if (np == 2 * DEDUP_THREADS) sort_in_registers<K, 2>(a, src, n, tid);
-    else if (np == 4 * DEDUP_THREADS) sort_in_registers<K, 4>(a, src, n, tid);
-    else if (np == 8 * DEDUP_THREADS) sort_in_registers<K, 8>(a, src, n, tid);
-    else {
-    for (uint32_t i = tid; i < np; i += DEDUP_THREADS)
-        if (MODE == DEDUP_STAGED || i >= n) a[i] = i < n ? src[i] : KeyOps<K>::pad();  // (fused, parts: the keys are in place already)
-    __syncthreads();
-    for (uint32_t k = 2; k <= np; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (np >> 1); t += DEDUP_THREADS) {
-                // t-th compare-exchange pair of this pass
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t p = i | j;
-                const K x = a[i], y = a[p];
-                const bool asc = (i & k) == 0;
-                if ((x > y) == asc) { a[i] = y; a[p] = x; }
-            }
-            __syncthreads();
-        }
-    }
-    }
-    KSSD_DEV_MARK(dev_t2);
-    // runs of equal tuples; only the first n entries are real (in first-position mode the first entry of a run is
-    // the tuple's first occurrence)
-    uint32_t out_base = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += DEDUP_THREADS) {
-        const uint32_t i = i0 + tid;
-        bool keep = false, counted = false;
-        K kv = 0;
-        if (i < n) {
-            kv = sorted[i];
-            const uint32_t v = KeyOps<K>::id(kv);
-            const bool start = (i == 0) || (KeyOps<K>::id(sorted[i - 1]) != v);
-            if (start) {
-                uint32_t lo = i + 1, hi = n;  // first index > i with a different tuple
-                if (lo < n && KeyOps<K>::id(sorted[lo]) != v) hi = lo;  // the common case: a run of one
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (KeyOps<K>::id(sorted[mid]) == v) lo = mid + 1;
-                    else hi = mid;
-                }
-                const uint32_t len = lo - i;
-                if (flags & KSSD_SKETCH_COUNTS) kv = KeyOps<K>::make(v, len < 65535u ? len : 65535u);  // OCCRC_MAX, global_basic.h
-                keep = len >= min_occ;
-                if ((flags & KSSD_SKETCH_UNIQ) && len > 1) keep = false;
-                if (v == 0 && !(flags & KSSD_SKETCH_KEEP_ZERO)) {
-                    keep = false;  // fasta2co leaves the slot empty (iseq2comem.c:258-261) ...
-                    atomicAdd(&s_zero_occ, len);  // ... but counts every occurrence against the limit
-                } else {
-                    counted = true;
-                }
-            }
-        }
-        {   // distinct tuples: one LDS atomic per wave, not one per tuple (they would queue up on one address)
-            const uint64_t cb = __ballot(counted);
-            if (cb && lane_id() == 0) atomicAdd(&s_distinct, (uint32_t)__builtin_popcountll(cb));
-        }
-        uint32_t tot;
-        const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
-        if (keep) outp[out_base + pos] = kv;  // out_base+pos <= i: never overtakes unread input (input is in LDS)
-        out_base += tot;
-    }
-    __syncthreads();
-    KSSD_DEV_DO(if ((FUSED || MODE == DEDUP_RANGES) && fx.dev_times && tid == 0 && blockIdx.x < 65536) {
-        fx.dev_times[blockIdx.x * 4] = dev_t0;
-        fx.dev_times[blockIdx.x * 4 + 1] = fx.dev_split ? dev_tA : dev_t1;
-        fx.dev_times[blockIdx.x * 4 + 2] = fx.dev_split ? dev_tB : dev_t2;
-        fx.dev_times[blockIdx.x * 4 + 3] = fx.dev_split ? dev_t1 : __builtin_amdgcn_s_memrealtime();
-    })
-    if (tid == 0) {
-        if (MODE == DEDUP_RANGES) {  // the genome's totals and its capacity rule: big_scan_kernel
-            px.item_cnt[blockIdx.x] = out_base;
-            px.item_s0[blockIdx.x] = (uint32_t)rng_s0;
-            if (s_distinct) atomicAdd(&px.acc[0], s_distinct);
-            if (s_zero_occ) atomicAdd(&px.acc[1], s_zero_occ);
-        } else if (MODE == DEDUP_PARTS) {  // the genome's totals (and its capacity rule) are the finish kernel's
-            pcnt[0] = out_base;
-            pcnt[1] = s_distinct;
-            pcnt[2] = s_zero_occ;
-            pcnt[3] = 0;
-        } else {
-            kept[g] = out_base;
-            if (!(flags & KSSD_SKETCH_NO_CAPACITY) && s_distinct + s_zero_occ > P.hashlimit) {
-                // keycount > hashlimit (iseq2comem.c:261-263)
-                atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
-            }
-        }
-    }
-}
-
-// the parts of a medium genome back into its staging region, one behind the other (ascending: the parts are id ranges), and
-// the genome's totals: kept ids, the capacity rule over all its distinct ids (iseq2comem.c:261-263)
-template <typename K>
-__global__ __launch_bounds__(256) void dedup_parts_finish_kernel(KssdParams P, const unsigned long long *__restrict__ reg_off, K *__restrict__ regions,
-                                                                 uint32_t *__restrict__ kept, uint32_t flags, SketchStatus *st, PartArgs px)
-{
-    __shared__ uint32_t s_pre[(1 << DEDUP_MAX_PARTS_LOG2) + 1];
-    __shared__ uint32_t s_bad;
-    const uint2 md = px.list[blockIdx.x];
-    const uint32_t g = md.x, n_parts = 1u << md.y;
-    const uint32_t *cnt = px.cnt + ((size_t)blockIdx.x << (DEDUP_MAX_PARTS_LOG2 + 2));
-    if (threadIdx.x == 0) {
-        uint32_t run = 0, distinct = 0, zero_occ = 0, bad = 0;
-        for (uint32_t p = 0; p < n_parts; p++) {
-            s_pre[p] = run;
-            run += cnt[p * 4];
-            distinct += cnt[p * 4 + 1];
-            zero_occ += cnt[p * 4 + 2];
-            bad |= cnt[p * 4 + 3];
-        }
-        s_pre[n_parts] = run;
-        s_bad = bad;
-        if (blockIdx.y == 0) {
-            kept[g] = bad ? 0u : run;
-            if (!bad && !(flags & KSSD_SKETCH_NO_CAPACITY) && (unsigned long long)distinct + zero_occ > P.hashlimit)
-                atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
-        }
-    }
-    __syncthreads();
-    if (s_bad) return;
-    const unsigned long long r0 = reg_off[g];
-    const K *out = reinterpret_cast<const K *>(px.out) + ((size_t)blockIdx.x << DEDUP_MAX_PARTS_LOG2) * px.part_cap;
-    const uint32_t p = blockIdx.y;  // this workgroup's part (every workgroup of the genome computes the same prefix, the first one publishes the totals)
-    if (p >= n_parts) return;
-    const uint32_t b = s_pre[p], m = s_pre[p + 1] - b;
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) regions[r0 + b + i] = out[(size_t)p * px.part_cap + i];
-}
-
-// ---------------------------------------------------------------------------------------------------
-// kernel 2b: dedup of a genome whose staged tuples do not fit LDS (> DEDUP_MAX_N: > ~60 Mb at L3K10, FASTQ
-// runs, chromosomes).  The staging region is padded with 0xFFFFFFFF, sorted by rocPRIM's device radix sort
-// (a plain library sort: not worth a hand-written kernel for a handful of genomes per batch), then the same
-// keep rules as sketch_dedup_kernel are applied by a count pass, a one-block scan and a write pass.
-// ---------------------------------------------------------------------------------------------------
-#define BIG_THREADS DEDUP_THREADS  // block_excl_scan is sized for it
-#define BIG_TILE 2048  // sorted entries per workgroup
-
-template <typename K>
-__global__ void big_pad_kernel(K *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
-                               uint32_t *__restrict__ kept_g, uint32_t *__restrict__ acc /*[2]: distinct, zero occurrences*/,
-                               SketchStatus *st)
-{
-    const unsigned long long n = *cursor_g;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        acc[0] = acc[1] = 0;
-        if (n > cap) {
-            atomicOr(&st->region_overflow, 1u);
-            unsigned long long need = (n * 256ull + cap - 1) / (cap ? cap : 1);
-            atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
-            *kept_g = 0;
-        } else {
-            atomicMax(&st->max_need_q8, (uint32_t)((n * 256ull + cap - 1) / (cap ? cap : 1)));
-        }
-    }
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (unsigned long long)gridDim.x * blockDim.x)
-        if (i >= n) region[i] = KeyOps<K>::pad();
-}
-
-// WRITE = false: per-tile count of kept ids (+ the genome's distinct / zero-occurrence totals);
-// WRITE = true: compaction into `out` at the tile's scanned offset
-template <typename K, bool WRITE>
-__global__ __launch_bounds__(BIG_THREADS) void big_runs_kernel(const K *__restrict__ a /*sorted*/, unsigned long long cap,
-                                                                const uint32_t *__restrict__ cursor_g, uint32_t flags,
-                                                                uint32_t min_occ, uint32_t *__restrict__ tile_cnt,
-                                                                uint32_t *__restrict__ acc, K *__restrict__ out)
-{
-    __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
-    const unsigned long long n = *cursor_g;
-    if (n > cap) return;
-    const unsigned long long t0 = (unsigned long long)blockIdx.x * BIG_TILE;
-    if (t0 >= n) { if (!WRITE && threadIdx.x == 0) tile_cnt[blockIdx.x] = 0; return; }
-    uint32_t out_base = WRITE ? tile_cnt[blockIdx.x] : 0, distinct = 0, zero_occ = 0;
-    for (uint32_t i0 = 0; i0 < BIG_TILE; i0 += BIG_THREADS) {
-        const unsigned long long i = t0 + i0 + threadIdx.x;
-        bool keep = false;
-        K kv = 0;
-        uint32_t v = 0;
-        if (i < n) {
-            kv = a[i];
-            v = KeyOps<K>::id(kv);
-            if (i == 0 || KeyOps<K>::id(a[i - 1]) != v) {
-                // first index > i with a different tuple: gallop (runs are short -- one entry in a genome, a dozen in a read
-                // set -- and a bisection of the whole array is 22 dependent reads for every one of them), then bisect the last stride
-                unsigned long long lo = i + 1, d = 1;
-                while (lo + d - 1 < n && KeyOps<K>::id(a[lo + d - 1]) == v) { lo += d; d <<= 1; }
-                unsigned long long hi = lo + d - 1 < n ? lo + d - 1 : n;
-                while (lo < hi) {
-                    const unsigned long long mid = (lo + hi) >> 1;
-                    if (KeyOps<K>::id(a[mid]) == v) lo = mid + 1;
-                    else hi = mid;
-                }
-                const unsigned long long len = lo - i;
-                if (flags & KSSD_SKETCH_COUNTS) kv = KeyOps<K>::make(v, len < 65535ull ? (uint32_t)len : 65535u);
-                keep = len >= min_occ;
-                if ((flags & KSSD_SKETCH_UNIQ) && len > 1) keep = false;
-                if (v == 0 && !(flags & KSSD_SKETCH_KEEP_ZERO)) {
-                    keep = false;  // fasta2co leaves the slot empty (iseq2comem.c:258-261) ...
-                    zero_occ += (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len);  // ... but counts every occurrence
-                } else {
-                    distinct++;
-                }
-            }
-        }
-        uint32_t tot;
-        const uint32_t pos = block_excl_scan(keep ? 1u : 0u, wsum, tot);
-        if (WRITE && keep) out[out_base + pos] = kv;
-        out_base += tot;
-    }
-    if (!WRITE) {
-        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = out_base;
-        uint32_t d_tot, z_tot;  // one atomic per workgroup, not one per thread
-        block_excl_scan(distinct, wsum, d_tot);
-        block_excl_scan(zero_occ, wsum, z_tot);
-        if (threadIdx.x == 0) {
-            if (d_tot) atomicAdd(&acc[0], d_tot);
-            if (z_tot) atomicAdd(&acc[1], z_tot);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// kernel 2c: a large genome sorted in LDS after all (RANGES) -- the way read sets, chromosomes and --byread files take.
-// The staged keys are partitioned by ranges of their leading field (id: its top bits are the canonical k-mer's outermost
-// bases; --byread: the position), RNG_BIN_MEAN keys per bin on average:
-//   big_rng_hist     every workgroup counts its share of the region per bin in LDS and writes its row of counts
-//   big_rng_colscan  per bin: exclusive prefix over the workgroups' rows (where a workgroup's keys of the bin go), bin totals
-//   big_rng_binscan  one workgroup: bin starts
-//   big_rng_scatter  the same shares again: keys to their places (LDS cursors, no global atomic anywhere)
-//   sketch_dedup_kernel<K, RANGES>  item k = the whole bins that begin in [k RNG_T, (k+1) RNG_T): LDS sort, keep rules, in place
-//   big_scan_kernel  the items' kept counts -> offsets, the genome's total and capacity rule
-//   big_rng_copy     the items' kept keys, one behind the other (the bins are ordered ranges: ascending), into the region
-// Seven short launches (~50 us at 3.7 M staged keys) where the device radix sort of the whole region took four passes over
-// all keys (0.2 ms).  Keys that do not spread -- ONE id tens of thousands of times (an amplicon, a spike-in), crafted ids --
-// overflow an item's LDS array: the status says so (ranges_skew) and the repeated call sorts in global memory as before.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rng_bin(uint32_t lead, uint32_t shift, uint32_t last)
-{
-    const uint32_t b = lead >> shift;
-    return b < last ? b : last;
-}
-__device__ __forceinline__ void rng_share(unsigned long long n, unsigned long long &lo, unsigned long long &hi)
-{
-    const unsigned long long per = (((n + gridDim.x - 1) / gridDim.x) + 1023ull) & ~1023ull;
-    lo = (unsigned long long)blockIdx.x * per;
-    hi = lo + per < n ? lo + per : n;
-    if (lo > n) lo = n;
-}
-
-template <typename K>
-__global__ __launch_bounds__(1024) void big_rng_hist_kernel(const K *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
-                                                            uint32_t *__restrict__ kept_g, uint32_t *__restrict__ acc, SketchStatus *st,
-                                                            uint32_t nb, uint32_t shift, uint32_t *__restrict__ wg_hist /*[gridDim.x][nb]*/)
-{
-    extern __shared__ uint32_t rng_h[];
-    const unsigned long long n = *cursor_g;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        acc[0] = acc[1] = 0;
-        const unsigned long long need = (n * 256ull + cap - 1) / (cap ? cap : 1);
-        atomicMax(&st->max_need_q8, (uint32_t)(need > 0xFFFFFFFFull ? 0xFFFFFFFFull : need));
-        if (n > cap) {
-            atomicOr(&st->region_overflow, 1u);
-            *kept_g = 0;
-        }
-    }
-    if (n > cap) return;
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) rng_h[b] = 0;
-    __syncthreads();
-    unsigned long long lo, hi;
-    rng_share(n, lo, hi);
-    for (unsigned long long i0 = lo + threadIdx.x; i0 < hi; i0 += 4ull * blockDim.x) {
-        K kv[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) kv[j] = i0 + (unsigned long long)j * blockDim.x < hi ? region[i0 + (unsigned long long)j * blockDim.x] : (K)0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (i0 + (unsigned long long)j * blockDim.x < hi) atomicAdd(&rng_h[rng_bin(KeyOps<K>::id(kv[j]), shift, nb - 1u)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) wg_hist[(size_t)blockIdx.x * nb + b] = rng_h[b];
-}
-
-__global__ __launch_bounds__(256) void big_rng_colscan_kernel(unsigned long long cap, const uint32_t *__restrict__ cursor_g, uint32_t nb, uint32_t rows,
-                                                               uint32_t *__restrict__ wg_hist, uint32_t *__restrict__ bin_tot)
-{
-    if (*cursor_g > cap) return;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    uint32_t run = 0;
-    for (uint32_t w0 = 0; w0 < rows; w0 += 8) {  // eight rows' counts in flight
-        uint32_t t[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) t[j] = w0 + j < rows ? wg_hist[(size_t)(w0 + j) * nb + b] : 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            if (w0 + j < rows) wg_hist[(size_t)(w0 + j) * nb + b] = run;
-            run += t[j];
-        }
-    }
-    bin_tot[b] = run;
-}
-
-__global__ __launch_bounds__(DEDUP_THREADS) void big_rng_binscan_kernel(unsigned long long cap, const uint32_t *__restrict__ cursor_g, uint32_t nb,
-                                                                         const uint32_t *__restrict__ bin_tot, uint32_t *__restrict__ bin_start /*nb+1*/,
-                                                                         uint32_t *__restrict__ item_bin /*n_items+1*/, uint32_t n_items)
-{
-    extern __shared__ uint32_t rng_h[];  // nb + 1 bin starts
-    __shared__ uint32_t wsum[DEDUP_THREADS / 64 + 1];
-    if (*cursor_g > cap) return;
-    for (uint32_t b = threadIdx.x; b < nb; b += DEDUP_THREADS) rng_h[b] = bin_tot[b];  // coalesced in, scanned in LDS, coalesced out
-    __syncthreads();
-    // tiles of DEDUP_THREADS consecutive bins, one per thread (a thread that walks its own run of the array meets every other
-    // lane of its wave in one LDS bank)
-    uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < nb; t0 += DEDUP_THREADS) {
-        const uint32_t b = t0 + threadIdx.x;
-        const uint32_t v = b < nb ? rng_h[b] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(v, wsum, total);
-        if (b < nb) rng_h[b] = carry + ex;
-        carry += total;
-    }
-    const uint32_t total = carry;
-    if (threadIdx.x == 0) rng_h[nb] = total;
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b <= nb; b += DEDUP_THREADS) bin_start[b] = rng_h[b];
-    // item k = the whole bins that begin in [k RNG_T, (k+1) RNG_T): item_bin[k] = the first bin whose start is >= k RNG_T
-    // (bin b is that bin for every k with start[b-1] < k RNG_T <= start[b]); beyond the last bin: nb
-    for (uint32_t b = threadIdx.x; b <= nb; b += DEDUP_THREADS) {
-        const uint32_t s1 = rng_h[b];
-        uint32_t k0 = b ? rng_h[b - 1] / RNG_T + 1u : 0u;  // first k with k RNG_T > start[b-1]
-        for (uint32_t k = k0; k <= n_items && (unsigned long long)k * RNG_T <= s1; k++) item_bin[k] = b;
-    }
-    for (uint32_t k = total / RNG_T + 1u + threadIdx.x; k <= n_items; k += DEDUP_THREADS) item_bin[k] = nb;
-}
-
-template <typename K>
-__global__ __launch_bounds__(1024) void big_rng_scatter_kernel(const K *__restrict__ region, unsigned long long cap, const uint32_t *__restrict__ cursor_g,
-                                                               uint32_t nb, uint32_t shift, const uint32_t *__restrict__ wg_hist,
-                                                               const uint32_t *__restrict__ bin_start, K *__restrict__ parted)
-{
-    extern __shared__ uint32_t rng_h[];
-    const unsigned long long n = *cursor_g;
-    if (n > cap) return;
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) rng_h[b] = bin_start[b] + wg_hist[(size_t)blockIdx.x * nb + b];
-    __syncthreads();
-    unsigned long long lo, hi;
-    rng_share(n, lo, hi);
-    for (unsigned long long i0 = lo + threadIdx.x; i0 < hi; i0 += 4ull * blockDim.x) {
-        K kv[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) kv[j] = i0 + (unsigned long long)j * blockDim.x < hi ? region[i0 + (unsigned long long)j * blockDim.x] : (K)0;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (i0 + (unsigned long long)j * blockDim.x < hi) parted[atomicAdd(&rng_h[rng_bin(KeyOps<K>::id(kv[j]), shift, nb - 1u)], 1u)] = kv[j];
-    }
-}
-
-template <typename K>
-__global__ __launch_bounds__(256) void big_rng_copy_kernel(unsigned long long cap, const uint32_t *__restrict__ cursor_g, const K *__restrict__ parted,
-                                                            const uint32_t *__restrict__ item_off /*scanned*/, const uint32_t *__restrict__ item_s0,
-                                                            uint32_t n_items, const uint32_t *__restrict__ kept_g, K *__restrict__ region)
-{
-    if (*cursor_g > cap) return;
-    const uint32_t k = blockIdx.x;
-    const uint32_t o0 = item_off[k], o1 = k + 1 < n_items ? item_off[k + 1] : *kept_g;
-    const K *src = parted + item_s0[k];
-    for (uint32_t i = threadIdx.x; i < o1 - o0; i += blockDim.x) region[o0 + i] = src[i];
-}
-
-// one workgroup: exclusive scan of the tile counts, kept[g], the capacity rule (iseq2comem.c:261-263)
-__global__ __launch_bounds__(1024) void big_scan_kernel(uint32_t *__restrict__ tile_cnt, uint32_t n_tiles, const uint32_t *__restrict__ acc,
-                                                         uint32_t hashlimit, uint32_t flags, uint32_t g, unsigned long long cap,
-                                                         const uint32_t *__restrict__ cursor_g, uint32_t *__restrict__ kept_g,
-                                                         SketchStatus *st)
-{
-    __shared__ uint32_t part[1024];
-    if (*cursor_g > cap) return;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_tiles + 1023) / 1024;
-    const uint32_t b = tid * per, e = (b + per < n_tiles) ? b + per : n_tiles;
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; i++) sum += tile_cnt[i];
-    part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < 1024; i++) { const uint32_t t = part[i]; part[i] = run; run += t; }
-        *kept_g = run;
-        if (!(flags & KSSD_SKETCH_NO_CAPACITY) && (unsigned long long)acc[0] + acc[1] > hashlimit)
-            atomicMax(&st->capacity_genome_p1, 0xFFFFFFFFu - g);  // keeps the smallest g
-    }
-    __syncthreads();
-    uint32_t run = part[tid];
-    for (uint32_t i = b; i < e; i++) { const uint32_t t = tile_cnt[i]; tile_cnt[i] = run; run += t; }
-}
-
+#include "kssd_scan.inc"
+#include "kssd_exact.inc"
+#include "kssd_dedup.inc"
+#include "kssd_big.inc"
 // kernel 3: exclusive scan of the kept counts -> CSR offsets (single workgroup, n_genomes is small)
 __global__ __launch_bounds__(1024) void sketch_offsets_kernel(const uint32_t *__restrict__ kept, uint32_t n,
                                                                unsigned long long *__restrict__ out_off,
