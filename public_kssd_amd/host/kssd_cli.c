@@ -436,6 +436,12 @@ static uint64_t stream_gz_in(kssd_gpu_ctx *ctx, stream_ring *ring, const char *p
     return total;
 }
 
+static int cmp_u64(const void *a, const void *b)
+{
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
 /* the job's genomes through the device: FASTA text is tokenised there, FASTQ batches arrive tokenised; pos may be NULL */
 static int job_sketch(kssd_gpu_ctx *ctx, job *j, stream_ring *ring, const filelist *fl, uint32_t flags, uint32_t min_occ, uint64_t **off,
                       uint32_t **ids, uint32_t **pos, int64_t *bad)
@@ -470,8 +476,6 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     uint32_t *ids = NULL, *pos = NULL;
     int64_t bad = -1;
     const uint32_t passes = kssd_gpu_tuple_passes(ctx);
-    if (passes > 1 && (o->u || o->abundance || (is_fq && (o->kmerocrs > 1 || o->kmerqlty > 127))))
-        die(ENOTSUP, "-u, -A, -n > 1 with k - drlevel = 9 (36-bit tuples, 256 components) are not built");
     if (passes > 1 && res) die(ENOTSUP, "--allpairs with k - drlevel = 9: a directory of 256 components is not searched (the reference's own stage II does not survive it)");
     if (j->streamed && !j->uploaded) { /* the text's length (a gzip'ed input: only known now) decides what follows */
         const double tu0 = now_s();
@@ -551,6 +555,16 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
                 die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + (bad >= 0 ? bad : 0)], o->k + 1);
             gck(rc, "sketch (tuple pass)");
         }
+        /* -u, fastq -n > 1 (the keep rule is replayed on the host: the tuples the dump drops sit in the reference's table all the
+         * same) and -A need every tuple's number of occurrences: sixteen more passes over the candidates of the same scan */
+        const int want_counts = replay_all || o->abundance;
+        uint64_t *coff[16] = {0};
+        uint32_t *cids[16] = {0}, *ccnt[16] = {0};
+        for (uint32_t sp = 0; want_counts && sp < passes; sp++) {
+            gck(kssd_gpu_set_tuple_pass(ctx, sp), "kssd_gpu_set_tuple_pass");
+            gck(kssd_gpu_sketch_again(ctx, flags | KSSD_SKETCH_NO_CAPACITY | KSSD_SKETCH_COUNTS, 1u, &coff[sp], &cids[sp], &ccnt[sp], &bad), "sketch (occurrences, tuple pass)");
+            if (coff[sp][n] != poff[sp][n]) die(EIO, "sketch (occurrences): %llu ids against %llu", (unsigned long long)coff[sp][n], (unsigned long long)poff[sp][n]);
+        }
         gck(kssd_gpu_set_tuple_pass(ctx, 0), "kssd_gpu_set_tuple_pass");
         uint64_t *moff = calloc((size_t)n + 1, sizeof *moff);
         if (!moff) die(ENOMEM, "out of memory");
@@ -558,41 +572,86 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
             uint64_t m = 0;
             for (uint32_t sp = 0; sp < passes; sp++) m += poff[sp][g + 1] - poff[sp][g];
             moff[g + 1] = moff[g] + m;
-            /* keycount > hashlimit over the ONE table of whole tuples (iseq2comem.c:261-263).  The device applies the rule per pass
-             * (a sixteenth of the keys against the whole limit: it never fires first); here the passes' distinct tuples are added
-             * up.  What is not added: the occurrences of the tuple 0 itself, which the reference counts one by one (:255-263) --
-             * they decide only for a genome within a handful of k-mers of 322 million distinct ones. */
-            if (!is_fq && m > (uint64_t)hashlimit)
+            /* keycount > hashlimit over the ONE table of whole tuples (iseq2comem.c:261-263; -u :686-688; -A :598-600).  The device
+             * applies the rule per pass (a sixteenth of the keys against the whole limit: it never fires first); here the passes'
+             * distinct tuples are added up.  What is not added: the occurrences of the tuple 0 itself, which fasta2co counts one
+             * by one (:255-263) -- they decide only for a genome within a handful of k-mers of 322 million distinct ones. */
+            if ((!is_fq || o->abundance) && m > (uint64_t)hashlimit)
                 die(ENOSPC, "%s: the context space is too crowd, try rerun the program using -k%d", fl->path[first_file + g], o->k + 1);
         }
         uint32_t *mids = malloc((size_t)(moff[n] ? moff[n] : 1) * 4);
         uint8_t *msub = malloc((size_t)(moff[n] ? moff[n] : 1));
-        if (!mids || !msub) die(ENOMEM, "out of memory");
+        uint16_t *mcnt = o->abundance ? malloc((size_t)(moff[n] ? moff[n] : 1) * 2) : NULL;
+        uint64_t *kept = calloc((size_t)n + 1, sizeof *kept);
+        if (!mids || !msub || !kept || (o->abundance && !mcnt)) die(ENOMEM, "out of memory");
 #pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 16)
         for (uint32_t g = 0; g < n; g++) {
-            const uint64_t m = moff[g + 1] - moff[g];
+            uint64_t m = moff[g + 1] - moff[g];
             uint64_t *t = malloc((size_t)(m ? m : 1) * 8);
             uint32_t *p = malloc((size_t)(m ? m : 1) * 4);
-            if (!t || !p) die(ENOMEM, "out of memory");
+            uint8_t *keep = replay_all ? malloc((size_t)(m ? m : 1)) : NULL;
+            uint64_t *ct = o->abundance ? malloc((size_t)(m ? m : 1) * 8) : NULL; /* tuple << 16 | occurrences, ascending: looked up behind the ordering */
+            if (!t || !p || (replay_all && !keep) || (o->abundance && !ct)) die(ENOMEM, "out of memory");
             uint64_t w = 0;
             for (uint32_t sp = 0; sp < passes; sp++)
-                for (uint64_t i = poff[sp][g]; i < poff[sp][g + 1]; i++) {
+                for (uint64_t i = poff[sp][g], c = want_counts ? coff[sp][g] : 0; i < poff[sp][g + 1]; i++, c++) {
                     t[w] = ((uint64_t)pids[sp][i] << 4) | sp;
-                    p[w++] = ppos[sp][i];
+                    p[w] = ppos[sp][i];
+                    if (want_counts && cids[sp][c] != pids[sp][i]) die(EIO, "sketch (occurrences): the two passes list different ids");
+                    if (keep) keep[w] = is_fq ? ccnt[sp][c] >= keep_rule_occ : ccnt[sp][c] == 1; /* both passes list a pass's ids ascending */
+                    if (ct) ct[w] = (t[w] << 16) | (ccnt[sp][c] & 0xFFFFu);
+                    w++;
                 }
-            if (kssd_slot_order_pos64(t, p, m, hashsize)) die(ENOMEM, "out of memory");
+            if (keep) {
+                m = kssd_slot_order_pos64_keep(t, p, keep, m, hashsize); /* kept tuples to the front, file order */
+                if (m == UINT64_MAX) die(ENOMEM, "out of memory");
+            } else if (kssd_slot_order_pos64(t, p, m, hashsize)) {
+                die(ENOMEM, "out of memory");
+            }
+            kept[g + 1] = m;
+            if (ct) { /* the counts follow their tuples: ct in ascending tuple order, a bisection per tuple */
+                const uint64_t all = moff[g + 1] - moff[g];
+                qsort(ct, (size_t)all, sizeof *ct, cmp_u64);
+                for (uint64_t i = 0; i < m; i++) {
+                    uint64_t lo = 0, hi = all;
+                    while (lo < hi) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if ((ct[mid] >> 16) < t[i]) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    mcnt[moff[g] + i] = (uint16_t)(ct[lo] & 0xFFFFu);
+                }
+            }
             for (uint64_t i = 0; i < m; i++) {
                 mids[moff[g] + i] = (uint32_t)(t[i] >> 4);
                 msub[moff[g] + i] = (uint8_t)(t[i] & 15u);
             }
             free(t);
             free(p);
+            free(keep);
+            free(ct);
         }
+        if (replay_all) { /* close the gaps the dropped tuples leave */
+            uint64_t at = 0;
+            for (uint32_t g = 0; g < n; g++) {
+                const uint64_t m = kept[g + 1];
+                memmove(mids + at, mids + moff[g], (size_t)m * 4);
+                memmove(msub + at, msub + moff[g], (size_t)m);
+                kept[g + 1] = at + m;
+                at += m;
+            }
+            memcpy(moff, kept, ((size_t)n + 1) * sizeof *moff);
+        }
+        free(kept);
         for (uint32_t sp = 0; sp < passes; sp++) {
             kssd_gpu_free(poff[sp]);
             kssd_gpu_free(pids[sp]);
             kssd_gpu_free(ppos[sp]);
+            kssd_gpu_free(coff[sp]);
+            kssd_gpu_free(cids[sp]);
+            kssd_gpu_free(ccnt[sp]);
         }
+        j->counts = mcnt;
         *t_call += now_s() - tc0;
         j->off = moff;
         j->ids = mids;

@@ -186,6 +186,61 @@ int kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t 
     return 0;
 }
 
+/* the keep variant for tuples beyond 32 bits: every tuple takes its slot (insertions in sequence order), the ones with keep[i] != 0
+ * come back at the front in file order; their number is returned (UINT64_MAX: out of memory) */
+typedef struct {
+    uint32_t pos;
+    uint8_t keep;
+    uint64_t key;
+} pos_keep_key;
+static int cmp_pos_keep_key(const void *a, const void *b)
+{
+    uint32_t x = ((const pos_keep_key *)a)->pos, y = ((const pos_keep_key *)b)->pos;
+    return x < y ? -1 : x > y;
+}
+uint64_t kssd_slot_order_pos64_keep(uint64_t *tuples, const uint32_t *first_pos, const uint8_t *keep, uint64_t n, uint32_t hashsize)
+{
+    if (n == 0) return 0;
+    pos_keep_key *pk = malloc(n * sizeof *pk);
+    slot_key *sl = malloc(n * sizeof *sl);
+    uint64_t cap = 16;
+    while (cap < 4 * n) cap <<= 1;
+    uint32_t *occ = malloc(cap * sizeof(uint32_t));
+    if (!pk || !sl || !occ) { free(pk); free(sl); free(occ); return UINT64_MAX; }
+    for (uint64_t i = 0; i < n; i++) { pk[i].pos = first_pos[i]; pk[i].keep = keep[i]; pk[i].key = tuples[i]; }
+    qsort(pk, n, sizeof *pk, cmp_pos_keep_key); /* first positions are distinct: one k-mer per position */
+    memset(occ, 0xFF, cap * sizeof(uint32_t));
+    const uint64_t S = hashsize;
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t key = pk[i].key, h1 = key % S, h2 = 1 + key % (S - 1); /* global_basic.h:228-230 */
+        for (uint64_t t = 0;; t++) {
+            const uint32_t slot = (uint32_t)((h1 + t * h2) % S);
+            uint64_t p = ((uint64_t)slot * 0x9E3779B97F4A7C15ull) >> 32 & (cap - 1);
+            int taken = 0;
+            while (occ[p] != 0xFFFFFFFFu) {
+                if (occ[p] == slot) { taken = 1; break; }
+                p = (p + 1) & (cap - 1);
+            }
+            if (!taken) {
+                occ[p] = slot;
+                if (pk[i].keep) {
+                    sl[m].slot = slot;
+                    sl[m].key = key;
+                    m++;
+                }
+                break;
+            }
+        }
+    }
+    qsort(sl, m, sizeof *sl, cmp_slot_key);
+    for (uint64_t i = 0; i < m; i++) tuples[i] = sl[i].key;
+    free(pk);
+    free(sl);
+    free(occ);
+    return m;
+}
+
 int kssd_slot_order(uint32_t *ids, uint64_t n, uint32_t hashsize)
 {
     if (n < 2) return 0;
@@ -354,7 +409,7 @@ static int comp_bits_of(int comp_num)
 int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hashsize, int slot_order)
 {
     mkdir(dir, 0777);
-    if (s->sub && (slot_order || s->koc || s->comp_num != 256)) return KSSD_HOST_ERR_PARAM; /* 36-bit tuples: in file order already */
+    if (s->sub && (slot_order || s->comp_num != 256)) return KSSD_HOST_ERR_PARAM; /* 36-bit tuples: in file order already */
     if (slot_order)
         for (uint32_t g = 0; g < s->n; g++) {
             const uint64_t n = s->off[g + 1] - s->off[g];
@@ -399,6 +454,7 @@ int kssd_sketchset_write(const kssd_sketchset *s, const char *dir, uint32_t hash
                     if (((((s->ids[i] & 15u) << 4) | s->sub[i]) & cmask) == (uint32_t)c) {
                         uint32_t id = s->ids[i] >> (cb - 4);
                         fwrite(&id, 4, 1, f);
+                        if (fa) fwrite(s->counts + i, 2, 1, fa); /* write_fqkoc2files, iseq2comem.c:435-469 */
                         run++;
                     }
                 for (uint64_t i = s->off[g]; !s->sub && i < s->off[g + 1]; i++)

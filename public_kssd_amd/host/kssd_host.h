@@ -138,6 +138,8 @@ int kssd_slot_order_pos64(uint64_t *tuples, const uint32_t *first_pos, uint64_t 
  * positions, keep[i] != 0 for the ids the dump writes.  Returns how many are kept; they come back at the front of
  * ids, in the reference's file order.  UINT64_MAX: out of memory. */
 uint64_t kssd_slot_order_pos_keep(uint32_t *ids, const uint32_t *first_pos, const uint8_t *keep, uint64_t n, uint32_t hashsize);
+/* the same for tuples of more than 32 bits */
+uint64_t kssd_slot_order_pos64_keep(uint64_t *tuples, const uint32_t *first_pos, const uint8_t *keep, uint64_t n, uint32_t hashsize);
 
 /* abundances follow a reordering of one genome's (distinct) ids: counts_after[i] = the count ids_after[i] had in
  * (ids_before, counts_before); KSSD_HOST_ERR_PARAM if an id of ids_after is not among ids_before */

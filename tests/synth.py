@@ -137,3 +137,20 @@ def k12_genomes():
     nm[rng.integers(0, len(a), 40)] = True
     return {"a.fa": fasta_text(a, b"a random genome", n_mask=nm), "b.fa": fasta_text(b, b"a with 0.2 % substitutions"),
             "c.fa": fasta_text(c, b"unrelated")}
+
+
+def k12_mode_inputs():
+    """inputs of tests/golden/make_golden_k12_modes.py (k - drlevel = 9 with -u, fastq -n 2, -A): a 1.2 Mb genome whose first
+    300 kb come twice (tuples -u drops), and 30 000 reads of 150 bp from a 600 kb genome (7.5 x: occurrence counts that matter)"""
+    rng = np.random.default_rng(20260412)
+    g = rng.integers(0, 4, 900_000, dtype=np.uint8)
+    dup = np.concatenate([g, g[:300_000]])
+    src = rng.integers(0, 4, 600_000, dtype=np.uint8)
+    reads = []
+    for _ in range(30_000):
+        s = int(rng.integers(0, len(src) - 150))
+        r = src[s:s + 150].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(r)
+    return {"dup.fa": fasta_text(dup, b"first 300 kb twice"), "reads.fq": fastq_text(reads)}

@@ -203,3 +203,48 @@ def test_command_line_writes_the_references_256_component_files(tmp_path):
     # indexing / searching such a directory is refused with the reason (the reference crashes there)
     r = subprocess.run([BIN, "dist", "-r", "db", "-o", "res", "db"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode != 0 and b"256 components" in r.stdout
+
+
+def _modes_golden():
+    return np.load(os.path.join(G, "k12_modes.npz"))
+
+
+def test_oracle_equals_the_reference_in_the_modes_beyond_the_plain_one():
+    """-u, fastq -n 2 and -A at k - drlevel = 9: the oracle's tuples (and abundances) against what the reference binary wrote
+    (tests/golden/make_golden_k12_modes.py), component by component, in file order"""
+    from synth import k12_mode_inputs
+    W = _modes_golden()
+    inp = k12_mode_inputs()
+    sk = ko.Sketcher(K.Shuf.generate(*K12, seed=SEED).table, *K12)
+    ids, comps = sk.fasta(inp["dup.fa"], uniq=True, with_comps=True)
+    for c in range(256):
+        assert np.array_equal(ids[comps == c], W["u.co.%d" % c]), c
+    ids, comps = sk.fastq(inp["reads.fq"], M=2, with_comps=True)
+    for c in range(256):
+        assert np.array_equal(ids[comps == c], W["n2.co.%d" % c]), c
+    assert sum(len(W["u.co.%d" % c]) for c in range(256)) == 153 and sum(len(W["n2.co.%d" % c]) for c in range(256)) == 140
+
+
+@pytest.mark.gpu
+def test_command_line_in_the_modes_beyond_the_plain_one(tmp_path):
+    """`kssd dist -L k12.shuf` with -u, -n 2 and -A: one scan, sixteen passes for the tuples and sixteen for their occurrences;
+    combco.<0..255>, combco.index.*, combco.*.a and cofiles.stat byte for byte the reference binary's"""
+    from synth import k12_mode_inputs
+    W = _modes_golden()
+    d = str(tmp_path)
+    K.Shuf.generate(*K12, seed=SEED).write(os.path.join(d, "k12.shuf"))
+    for nm, t in k12_mode_inputs().items():
+        open(os.path.join(d, nm), "wb").write(t)
+    for tag, extra, inp in (("u", ["-u"], "dup.fa"), ("n2", ["-n", "2"], "reads.fq"), ("A", ["-A"], "reads.fq")):
+        r = subprocess.run([BIN, "dist", "-L", "k12.shuf"] + extra + ["-o", "db_" + tag, inp], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=900)
+        assert r.returncode == 0, r.stdout.decode()
+        for c in range(256):
+            assert np.array_equal(np.fromfile(os.path.join(d, "db_" + tag, "combco.%d" % c), np.uint32), W["%s.co.%d" % (tag, c)]), (tag, c)
+            assert np.array_equal(np.fromfile(os.path.join(d, "db_" + tag, "combco.index.%d" % c), np.uint64), W["%s.idx.%d" % (tag, c)]), (tag, c)
+            if tag == "A":
+                assert np.array_equal(np.fromfile(os.path.join(d, "db_A", "combco.%d.a" % c), np.uint16), W["A.a.%d" % c]), c
+        stat = np.fromfile(os.path.join(d, "db_" + tag, "cofiles.stat"), np.uint8)
+        want = W[tag + ".stat"]
+        keep = np.r_[0:5, 8:len(want)]                                              # (bytes 5..7: padding of the bool)
+        assert np.array_equal(stat[:len(want)][keep], want[keep]), tag
