@@ -287,9 +287,7 @@ typedef struct job {
     kssd_batch *b;      /* FASTQ with -Q > 0, -A: tokenised on the host */
     textbuf *tx;        /* FASTA, FASTQ with -Q 0: the raw bytes, tokenised on the device (kssd_gpu_sketch_fast[aq]_text) */
     kssd_batch *own_b;  /* a text job the device handed back: the host tokeniser's batch of it */
-    int streamed;       /* one long file: the worker streams it into the device's text buffer (1 plain: stream_file_in, 2 gzip'ed: stream_gz_in);
-                         * 3: plain files mapped from the page cache, copied to the device straight from their mappings (maps) */
-    unsigned char **maps; /* streamed == 3: n_files mappings (NULL: an empty file) */
+    int streamed;       /* one long file: the worker streams it into the device's text buffer (1 plain: stream_file_in, 2 gzip'ed: stream_gz_in) */
     int uploaded;
     uint64_t *toff, *tlen, *lines;
     int is_fq, first_file, n_files;
@@ -313,7 +311,6 @@ static uint64_t STREAM_MIN = 256ull << 20;  /* files from this size on (KSSD_STR
 static uint64_t STREAM_MIN_GZ = 64ull << 20; /* gzip'ed files from this compressed size on (KSSD_STREAM_MIN_GZ) */
 static uint64_t STREAM_SLICE = 8ull << 20; /* (KSSD_STREAM_SLICE, bytes; a multiple of 4096) */
 #define STREAM_BUFS 16
-#define MAP_LIMIT (8ull << 30) /* bytes of mapped inputs queued ahead of the device workers */
 #define STREAM_READERS 8 /* slices read at a time, one thread each (the ring holds two such groups) */
 static void stream_env(void)
 {
@@ -480,21 +477,7 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
     int64_t bad = -1;
     const uint32_t passes = kssd_gpu_tuple_passes(ctx);
     if (passes > 1 && res) die(ENOTSUP, "--allpairs with k - drlevel = 9: a directory of 256 components is not searched (the reference's own stage II does not survive it)");
-    if (j->streamed == 3 && !j->uploaded) {
-        /* plain files, mapped: the copies leave from the page cache itself (the runtime pins the pages it is handed for the
-         * duration of a copy): no page-locked buffer on the host, no CPU copy into one (profiles/r04c_mmap_probe.txt) */
-        const double tu0 = now_s();
-        uint64_t total = 0;
-        for (uint32_t g = 0; g < n; g++) total = j->toff[g] + j->tlen[g] > total ? j->toff[g] + j->tlen[g] : total;
-        gck(kssd_gpu_text_reserve(ctx, total + 64), "kssd_gpu_text_reserve");
-        for (uint32_t g = 0; g < n; g++)
-            if (j->tlen[g]) {
-                const int64_t t = kssd_gpu_text_put(ctx, j->toff[g], j->maps[g], j->tlen[g]);
-                if (t < 0) gck((int)t, "kssd_gpu_text_put");
-            }
-        j->uploaded = 1;
-        *t_call += now_s() - tu0;
-    } else if (j->streamed && !j->uploaded) { /* the text's length (a gzip'ed input: only known now) decides what follows */
+    if (j->streamed && !j->uploaded) { /* the text's length (a gzip'ed input: only known now) decides what follows */
         const double tu0 = now_s();
         j->tlen[0] = j->streamed == 2 ? stream_gz_in(ctx, ring, fl->path[j->first_file], j->tlen[0])
                                       : stream_file_in(ctx, ring, fl->path[j->first_file], j->tlen[0]);
@@ -533,14 +516,7 @@ static void process_job(kssd_gpu_ctx *ctx, stream_ring *ring, job *j, const dist
         if (kssd_batch_reserve(j->own_b, n, maxpos, &first)) die(ENOMEM, "out of memory");
         free(maxpos);
         int trc = 0;
-        if (j->streamed == 3) { /* the mappings are the text */
-#pragma omp parallel for num_threads(WORKER_OMP) schedule(dynamic, 1) reduction(| : trc)
-            for (uint32_t g = 0; g < n; g++) {
-                const int r = kssd_batch_fill_text(j->own_b, first + g, o->abundance ? 2 : 1, j->maps[g] ? j->maps[g] : (const unsigned char *)"", j->tlen[g],
-                                                   o->kmerqlty, &j->lines[g]);
-                if (r && r != KSSD_HOST_ERR_EMPTY) trc |= 1;
-            }
-        } else if (j->streamed) { /* (the bytes are on the device only) */
+        if (j->streamed) { /* (the bytes are on the device only) */
             unsigned char *txt = NULL;
             size_t cap = 0, len = 0;
             trc = kssd_slurp_reuse(fl->path[first_file], &txt, &cap, &len);
@@ -778,7 +754,6 @@ typedef struct {
     kssd_shuf_hdr hdr;
     const uint32_t *accepted; /* the .shuf's accepted sub-contexts (load_shuf) */
     uint32_t n_accepted;
-    uint64_t mapped_bytes;      /* inputs mapped and queued, not yet through a worker (bounded: MAP_LIMIT) */
     double t_ctx_destroy;
     double t_ctx;   /* the slowest worker's context creation (HIP initialisation, code object load, table upload) */
     double t_gpu;   /* summed over the workers: seconds inside process_job */
@@ -818,23 +793,12 @@ static void *worker_main(void *arg)
         double tcall = 0;
         process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, pl->hashlimit, &tcall, pl->res ? pl->res[w->q] : NULL, pl->res ? pl->first[w->q] : 0u);
         const double dt = now_s() - t0;
-        uint64_t unmapped = 0;
-        if (j->maps) {
-            for (int g = 0; g < j->n_files; g++)
-                if (j->maps[g]) {
-                    munmap(j->maps[g], (size_t)j->tlen[g]);
-                    unmapped += j->tlen[g];
-                }
-            free(j->maps);
-            j->maps = NULL;
-        }
         if (j->b) kssd_batch_clear(j->b);
         if (j->own_b) kssd_batch_destroy(j->own_b);
         j->own_b = NULL;
         free(j->lines);
         j->lines = NULL;
         pthread_mutex_lock(&pl->mu);
-        pl->mapped_bytes -= unmapped;
         if (j->b) pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
         if (j->tx) pl->tpool[pl->n_tpool++] = j->tx;
         j->b = NULL;
@@ -971,8 +935,13 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
     const double t_shuf = now_s() - t_start;
-    /* (nothing on this thread waits for the runtime: the workers create their contexts -- and report a missing device -- while
-     * this thread already maps and reads the first inputs; the warm-up thread is joined at the end) */
+    if (warming) pthread_join(warm, NULL);
+    {
+        const int have = kssd_gpu_device_count();
+        if (have <= 0) die(ENODEV, "kssd_gpu_create: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
+        for (int i = 0; i < n_dev; i++)
+            if (o->devs[i] >= have) die(ENODEV, "device %d of the list: only %d device(s) visible", o->devs[i], have);
+    }
     const int n_workers = 2 * n_dev;
     const int threads = o->p > 0 ? o->p : 1;
     pipeline pl;
@@ -1029,7 +998,6 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
      * sequence reproduces come back (KSSD_ERR_UNSUPPORTED) and go through the host tokeniser */
     const int fq_dev = (o->abundance || (o->kmerqlty >= 0 && o->kmerqlty <= 127)) && !getenv("KSSD_HOST_FASTQ");
     stream_env();
-    const int use_maps = !getenv("KSSD_NO_MMAP"); /* (KSSD_NO_MMAP=1: plain files are read into page-locked buffers as before) */
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
         const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
         double t0 = now_s();
@@ -1096,43 +1064,6 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     n_bytes += len[r0]; /* (a gzip'ed one: its compressed size) */
                     printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + r0]);
                     goto queue_job;
-                }
-                int all_plain = use_maps;
-                for (int i = r0; i < r1 && all_plain; i++) all_plain = direct[i] == 1;
-                if (all_plain) {
-                    /* plain files the device tokenises: mapped, not read -- the worker hands the mappings to the copy engine */
-                    unsigned char **maps = calloc((size_t)(r1 - r0), sizeof *maps);
-                    if (!maps) die(ENOMEM, "out of memory");
-                    t0 = now_s();
-                    int map_err = 0;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1) reduction(| : map_err)
-                    for (int i = r0; i < r1; i++) {
-                        if (!len[i]) continue;
-                        const int fd = open(fl->path[i0 + i], O_RDONLY);
-                        void *m = fd >= 0 ? mmap(NULL, len[i], PROT_READ, MAP_SHARED | MAP_POPULATE, fd, 0) : MAP_FAILED;
-                        if (fd >= 0) close(fd);
-                        if (m == MAP_FAILED) map_err |= 1;
-                        else maps[i - r0] = m;
-                    }
-                    t_read += now_s() - t0;
-                    if (!map_err) {
-                        uint64_t mb = 0;
-                        for (int i = r0; i < r1; i++) {
-                            n_bytes += len[i];
-                            mb += len[i];
-                            printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + i]);
-                        }
-                        j->maps = maps;
-                        j->streamed = 3;
-                        pthread_mutex_lock(&pl.mu); /* not arbitrarily far ahead of the workers (inputs on a disk: the read-ahead of MAP_POPULATE) */
-                        while (pl.mapped_bytes > MAP_LIMIT) pthread_cond_wait(&pl.cv, &pl.mu);
-                        pl.mapped_bytes += mb;
-                        pthread_mutex_unlock(&pl.mu);
-                        goto queue_job;
-                    }
-                    for (int i = r0; i < r1; i++) /* (a file system without mappings: read like before) */
-                        if (maps[i - r0]) munmap(maps[i - r0], len[i]);
-                    free(maps);
                 }
                 pthread_mutex_lock(&pl.mu);
                 while (pl.n_tpool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
@@ -1212,7 +1143,6 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pthread_cond_broadcast(&pl.cv);
     pthread_mutex_unlock(&pl.mu);
     for (int i = 0; i < n_workers; i++) pthread_join(ws[i].th, NULL);
-    if (warming) pthread_join(warm, NULL);
     printf("\n");
     free(sc.accepted);
     const double t_sketched = now_s();

@@ -148,22 +148,36 @@ def test_errors_match_the_reference(tmp_path):
 
 
 def test_config1_tutorial_on_real_test_fna_genomes(tmp_path):
-    """BASELINE configs[0] through the HIP command line on real sequence: two of the reference's own test_fna genomes
-    (B. cereus AE016877 and a mutated copy; tests/golden/test_fna, goldens written by the reference binary:
-    make_golden_testfna.py), the README quick-tutorial flow.  combco.0 of both sketch directories, sharedk_ct.dat and
-    distance.out must be the reference's byte for byte."""
+    """BASELINE configs[0] through the HIP command line on real sequence: four of the reference's own test_fna genomes
+    (B. cereus AE016877, its 10 %, 25 % and 29 % mutated copies; tests/golden/test_fna) and the multi-record edge-case file
+    as a third query, the README quick-tutorial flow; goldens written by the reference binary (make_golden_testfna.py).
+    Every genome's slice of combco.0 byte for byte (the reference's file order inside a genome; across genomes its input
+    order is shuffled by the clock, ours is sorted: by name), sharedk_ct.dat by names, distance.out as a set of lines."""
     d = str(tmp_path)
     F = os.path.join(G, "test_fna")
     want = np.load(os.path.join(G, "test_fna.npz"))
+    os.mkdir(os.path.join(d, "qin"))
+    for fn in os.listdir(os.path.join(F, "seqs2")):
+        os.symlink(os.path.join(F, "seqs2", fn), os.path.join(d, "qin", fn))
+    os.symlink(os.path.join(G, "qry_fa", "edge.fa"), os.path.join(d, "qin", "edge.fa"))
     run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
     run(["dist", "-L", "L3K10.shuf", "-r", os.path.join(F, "seqs1"), "-o", "refdb"], d)      # sketch + index files
-    run(["dist", "-L", "L3K10.shuf", "-o", "qry", os.path.join(F, "seqs2")], d)
+    run(["dist", "-L", "L3K10.shuf", "-o", "qry", "qin"], d)
     run(["dist", "-r", "refdb", "-o", "out", "--keepskf", "qry"], d)
-    assert np.array_equal(np.fromfile(os.path.join(d, "refdb", "combco.0"), np.uint32), want["ref_combco"])
-    assert np.array_equal(np.fromfile(os.path.join(d, "qry", "combco.0"), np.uint32), want["qry_combco"])
-    assert np.array_equal(np.fromfile(os.path.join(d, "out", "sharedk_ct.dat"), np.uint32), want["shared"])
-    got = open(os.path.join(d, "out", "distance.out")).read().replace(os.path.join(F, "seqs1"), "REF").replace(os.path.join(F, "seqs2"), "QRY")
-    assert got == bytes(want["distance_out"]).decode()
+    order = {}
+    for sub, dd in (("ref", "refdb"), ("qry", "qry")):
+        hdr, names, off, ids = ko.read_sketch_dir(os.path.join(d, dd))
+        order[sub] = [os.path.basename(n) for n in names]
+        assert len(names) == (2 if sub == "ref" else 3)
+        for i, nm in enumerate(order[sub]):
+            assert np.array_equal(ids[int(off[i]):int(off[i + 1])], want["%s/%s" % (sub, nm)]), (sub, nm)
+    sh = np.fromfile(os.path.join(d, "out", "sharedk_ct.dat"), np.uint32).reshape(3, 2)
+    qi = [order["qry"].index(str(n)) for n in want["qry_names"]]
+    ri = [order["ref"].index(str(n)) for n in want["ref_names"]]
+    assert np.array_equal(sh[np.ix_(qi, ri)], want["shared"])
+    got = open(os.path.join(d, "out", "distance.out")).read().replace(os.path.join(F, "seqs1"), "REF").replace("qin", "QRY")
+    wt = bytes(want["distance_out"]).decode()
+    assert got.splitlines()[0] == wt.splitlines()[0] and sorted(got.splitlines()[1:]) == sorted(wt.splitlines()[1:])
     assert os.path.getsize(os.path.join(d, "refdb", "mco.index.0")) == 8 << 28      # the reference's dense index file
 
 
