@@ -417,7 +417,8 @@ int kssd_gpu_allgather_sketches(kssd_gpu_ctx *const *ctxs, int n, const uint64_t
  *   kssd_gpu_resident_allpairs  all-pairs among the genomes of `sets` (global numbering: set 0's slots, then set 1's, ...;
  *                               every set but the last holds the same number of slots -- kssd_shard_plan of the host
  *                               library deals the inputs out that way): ONE RCCL all-gather of every device's packed
- *                               sketches (kssd_gpu_allgather_sketches; one device: a one-rank communicator), the full index
+ *                               sketches (kssd_gpu_allgather_sketches; one device: its unit is unpacked in place, or -- with
+ *                               KSSD_EXCHANGE_ONE_RANK=1 in the environment -- sent through a one-rank communicator), the full index
  *                               on every device, every device's own genomes as its block of query rows, written into the
  *                               caller's HOST matrices (N x N row-major; `shared` may be a mapped sharedk_ct.dat, the f64
  *                               planes may be NULL).  One host thread per device.  KSSD_ERR_PARAM when a device is named
@@ -431,6 +432,10 @@ int kssd_gpu_resident_put_host(kssd_gpu_resident *r, uint32_t first_slot, uint32
 int kssd_gpu_resident_sizes(const kssd_gpu_resident *r, uint32_t *sizes);
 int kssd_gpu_resident_allpairs(kssd_gpu_resident *const *sets, int n_sets, int kmerlen, uint32_t *shared, double *jaccard,
                                double *mashd, double *contain, double *aafd);
+/* Loads librccl.so and sets the communicators of a device list up ahead of the first kssd_gpu_allgather_sketches /
+ * kssd_gpu_resident_allpairs over that list (one to two seconds: a command runs it on a thread of its own while its devices
+ * sketch).  KSSD_ERR_PARAM for a list with a repeat, KSSD_ERR_HIP with the RCCL text otherwise. */
+int kssd_gpu_exchange_warm_up(const int *devices, int n);
 /* which == 0: the file of the HIP runtime this library is bound to; 1: the RCCL the first exchange loaded ("" before it).
  * For the line a multi-GPU run prints about itself; the string is the calling thread's until its next call. */
 const char *kssd_gpu_runtime_path(int which);

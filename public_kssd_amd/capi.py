@@ -47,7 +47,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_index_set_filter", "kssd_gpu_set_scan_grid", "kssd_gpu_warm_up", "kssd_gpu_set_fastq_quality", "kssd_gpu_set_fastq_reads", "kssd_gpu_allgather_sketches", "kssd_gpu_fasta_read_starts", "kssd_gpu_tuple_passes", "kssd_gpu_set_tuple_pass", "kssd_gpu_sketch_again",
     "kssd_gpu_index_status", "kssd_gpu_index_set_exact",
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
-    "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path",
+    "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
 ]
 
 

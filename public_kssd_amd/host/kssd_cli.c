@@ -266,6 +266,18 @@ static void load_shuf(const dist_opt *o, shuf_core *s)
 
 /* HIP initialisation (driver, device context, code object) costs 0.1 - 0.2 s per process: started on a thread of its own
  * at the top of a command, it runs while the command reads its .shuf or its sketch directories */
+/* --allpairs over several devices: librccl.so and the communicators come up while stage I runs (kssd_gpu_exchange_warm_up) */
+typedef struct {
+    const int *devs;
+    int n;
+} xwarm_arg;
+static void *warm_exchange(void *arg)
+{
+    const xwarm_arg *x = arg;
+    kssd_gpu_exchange_warm_up(x->devs, x->n); /* (a failure is reported by the exchange itself) */
+    return NULL;
+}
+
 static void *warm_device(void *arg)
 {
     kssd_gpu_warm_up(*(const int *)arg); /* (a missing device is reported by the call that needs it) */
@@ -942,6 +954,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         for (int i = 0; i < n_dev; i++)
             if (o->devs[i] >= have) die(ENODEV, "device %d of the list: only %d device(s) visible", o->devs[i], have);
     }
+    pthread_t xwarm;
+    xwarm_arg xa = {o->devs, n_dev};
+    const int xwarming = o->allpairs && (n_dev > 1 || getenv("KSSD_EXCHANGE_ONE_RANK")) && pthread_create(&xwarm, NULL, warm_exchange, &xa) == 0;
     const int n_workers = 2 * n_dev;
     const int threads = o->p > 0 ? o->p : 1;
     pipeline pl;
@@ -1228,6 +1243,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             }
             free(sz);
         }
+        if (xwarming) pthread_join(xwarm, NULL);
         gck(kssd_gpu_resident_allpairs(res, n_dev, d.kmerlen, shared, NULL, NULL, NULL, NULL), "all-pairs on the resident sketches");
         if (o->keep_skf && cells && msync(shared, cells * 4, MS_SYNC) != 0) die(errno, "mco_cbdco_nobin_dist()::%s", skf);
         t_allpairs = now_s() - t_written;

@@ -82,8 +82,12 @@ def test_one_command_all_pairs_equals_the_two_command_flow_and_the_reference(tmp
     d = str(tmp_path)
     fa = os.path.join(G, "ref_fa")
     K.Shuf.generate(10, 6, 3, seed=meta["seed"]).write(os.path.join(d, "L3K10.shuf"))
-    out, err = _run(["dist", "-L", "L3K10.shuf", "-o", "one", "--allpairs", "--keepskf", "--gpus", 1, fa], d, env={"KSSD_TIMING": "1"})
+    out, err = _run(["dist", "-L", "L3K10.shuf", "-o", "one", "--allpairs", "--keepskf", "--gpus", 1, fa], d,
+                    env={"KSSD_TIMING": "1", "KSSD_EXCHANGE_ONE_RANK": "1"})     # through RCCL although there is nobody to exchange with
     assert '"kssd_timing": "allpairs"' in err and '"gpus": 1' in err
+    _run(["dist", "-L", "L3K10.shuf", "-o", "one_local", "--allpairs", "--keepskf", fa], d)   # the default on one device: unpacked in place
+    for f in ("sharedk_ct.dat", "distance.out"):
+        assert open(os.path.join(d, "one", f), "rb").read() == open(os.path.join(d, "one_local", f), "rb").read(), f
     _run(["dist", "-L", "L3K10.shuf", "-o", "two", fa], d)
     _run(["dist", "-r", "two", "-o", "two_out", "--keepskf", "two"], d)
     for f in ("combco.0", "combco.index.0", "cofiles.stat"):
