@@ -307,15 +307,19 @@ struct KssdG {  // one slot of the exact table: accepted sub-context -> permutat
 // takes per second, ~85 G/s: 8.6 M candidates of a read set took 210 us, the 2.9 M of the default batch 71.)
 #define KSSD_G_MOVED 0x80000000u
 KSSD_HD uint32_t kssd_g_slot(uint32_t dim, uint32_t mul, uint32_t g_log2) { return (dim * mul) >> (32 - g_log2); }
-struct KssdGBucket {  // = KssdG[2]
+// (16-byte aligned: ONE 16-byte load per lookup -- without the attribute the compiler read a bucket as four separate words, and a CU
+// pays for every vector-memory instruction of a wave whatever it fetches: 12 of the per-genome kernel's ~20 loads per candidate round)
+struct __attribute__((aligned(16))) KssdGBucket {  // = KssdG[2]
     uint32_t key0, rank0, key1, rank1;
 };
 // the bucket's verdict: 1 = found (rank set), 0 = not in the table, 2 = look into the second bucket
+// (written without branches: every word of the bucket is used on every path, so the bucket stays ONE 16-byte load -- with early
+// returns the compiler fetched the words one by one, under the branches, as four vector-memory instructions)
 KSSD_HD int kssd_g_match(const KssdGBucket &b, uint32_t dim, uint32_t &rank)
 {
-    if (b.key0 == dim) { rank = b.rank0 & ~KSSD_G_MOVED; return 1; }
-    if (b.key1 == dim) { rank = b.rank1; return 1; }
-    return (b.rank0 & KSSD_G_MOVED) ? 2 : 0;
+    const bool m0 = b.key0 == dim, m1 = b.key1 == dim;
+    rank = m0 ? (b.rank0 & ~KSSD_G_MOVED) : b.rank1;  // (meaningful only when 1 is returned)
+    return (m0 | m1) ? 1 : ((b.rank0 & KSSD_G_MOVED) ? 2 : 0);
 }
 KSSD_HD bool kssd_g_find(const KssdParams &P, const KssdG *__restrict__ G, uint32_t dim, uint32_t &rank)
 {
