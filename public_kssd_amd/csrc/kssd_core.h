@@ -245,62 +245,6 @@ KSSD_HD void kssd_stage1g(const uint32_t (&Wd)[5], T1PTR T1, uint32_t &cand_lo, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Stage 1, the bit-table form (round 4's structural experiment on the scan's bank conflicts; development build only, SUBK = 6):
-// ONE bit per 20-bit index -- the 10 bases three consecutive windows share -- says "some pattern of S, placed at one of the
-// three windows, has this core".  One alignment, 22 table reads per 64 positions instead of 27, no per-window answer: a set bit
-// makes all three positions candidates (2.3 % of the positions instead of 0.8 %), which the Bloom rounds then sort out.
-// The reads are issued in two halves of 11 (s_waitcnt lgkmcnt counts to 15) and merged by OR.
-// ---------------------------------------------------------------------------------------------------
-#define KSSD_BT_W 3
-#define KSSD_BT_HALF 11  // groups per half: Q = 3 q (first half), 33 + 3 q (second half); the last group (Q = 63) covers position 63 alone
-template <int SUBK>
-struct KssdBit {
-    static constexpr int LP = 2 * SUBK;
-    static constexpr int C = LP + 1 - KSSD_BT_W;  // bases of the shared core
-    static constexpr int IDXB = 2 * C;            // index bits: one table bit each
-    static_assert(IDXB == 20, "the bit table is sized for SUBK = 6 (2^20 bits = 128 KiB)");
-};
-// index of the group that starts at lane position Q: IDXB stream bits from the core (position Q + W - 1) on
-template <int SUBK>
-KSSD_HD uint32_t kssd_bit_index(const uint32_t (&Wd)[5], int Q)
-{
-    const int start = 2 * (Q + KSSD_BT_W - 1), i = start >> 5, off = start & 31;
-    const uint64_t win = ((uint64_t)Wd[i] << 32) | (i < 4 ? Wd[i + 1] : 0u);
-    return (uint32_t)(win >> (64 - off - KssdBit<SUBK>::IDXB)) & ((1u << KssdBit<SUBK>::IDXB) - 1u);
-}
-template <int SUBK, int HALF, typename T1PTR>
-KSSD_HD void kssd_bit_issue(const uint32_t (&Wd)[5], T1PTR T1, uint32_t (&raw)[KSSD_BT_HALF])
-{
-#pragma unroll
-    for (int q = 0; q < KSSD_BT_HALF; q++) raw[q] = T1[kssd_bit_index<SUBK>(Wd, 3 * (q + HALF * KSSD_BT_HALF)) >> 3];
-}
-template <int SUBK, int HALF>
-KSSD_HD void kssd_bit_merge(const uint32_t (&Wd)[5], const uint32_t (&raw)[KSSD_BT_HALF], uint32_t &lo, uint32_t &hi)
-{
-    uint64_t m = 0;
-#pragma unroll
-    for (int q = 0; q < KSSD_BT_HALF; q++) {
-        const int Q = 3 * (q + HALF * KSSD_BT_HALF);
-        const uint32_t bit = (raw[q] >> (kssd_bit_index<SUBK>(Wd, Q) & 7u)) & 1u;
-        m |= (uint64_t)((0u - bit) & 7u) << Q;  // all three windows of the group (positions beyond 63 fall off the top)
-    }
-    lo = (uint32_t)m;
-    hi = (uint32_t)(m >> 32);
-}
-// both halves at once (CPU emulation in tests/emu)
-template <int SUBK, typename T1PTR>
-KSSD_HD void kssd_stage1b(const uint32_t (&Wd)[5], T1PTR T1, uint32_t &cand_lo, uint32_t &cand_hi)
-{
-    uint32_t ra[KSSD_BT_HALF], rb[KSSD_BT_HALF], alo, ahi, blo, bhi;
-    kssd_bit_issue<SUBK, 0>(Wd, T1, ra);
-    kssd_bit_issue<SUBK, 1>(Wd, T1, rb);
-    kssd_bit_merge<SUBK, 0>(Wd, ra, alo, ahi);
-    kssd_bit_merge<SUBK, 1>(Wd, rb, blo, bhi);
-    cand_lo = alo | blo;
-    cand_hi = ahi | bhi;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Stage 1.5: exact-pattern Bloom test of the few candidates stage 1 lets through.  Stage 1 only proves that
 // each alignment agrees with SOME pattern of S; 94 % of its candidates are not in S at all.  Candidates are buffered as
 // positions; the lane that takes one into a dense round of 64 fetches the packed words around it (kssd_carry_from_words),
@@ -564,13 +508,6 @@ static inline bool kssd_build_tables(KssdParams &P, const std::vector<uint32_t> 
     const int IDXB = (2 * LP < 17) ? 2 * LP : 17;
     T1.assign(KSSD_T1_BYTES, 0);
     auto add = [&](uint64_t x) {
-        if (GW < 0) {  // the bit-table form (KssdBit): the pattern's core under each of the three windows it can sit in
-            for (int j = 0; j < KSSD_BT_W; j++) {
-                const uint32_t core = (uint32_t)(x >> (2 * j)) & ((1u << (2 * (LP + 1 - KSSD_BT_W))) - 1u);
-                T1[core >> 3] |= (uint8_t)(1u << (core & 7u));
-            }
-            return;
-        }
         for (int j = 0; j < W; j++) {
             const int start = 2 * (W - 1 - j);                                // index field starts here, counted from the pattern's top bit
             const int avail = IDXB < 2 * LP - start ? IDXB : 2 * LP - start;  // field bits that lie inside window j

@@ -14,7 +14,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -164,7 +163,6 @@ struct kssd_gpu_ctx {
     uint32_t idx_lg_cap = 0;      // capped build in place: log2 of every bucket's slots (0: exact build, descriptors)
     uint32_t idx_serial = 0;      // number of the build in place
     uint32_t *d_idx_flag = nullptr;  // serial of the last capped build that met a bucket fuller than its run
-    bool dev_bit_table = false;   // development build only (KSSD_DEV_BITTAB)
     bool idx_exact = false;       // builds of this context count first (a capped build of it has overflowed, or the caller asked)
     uint32_t *d_bkt;        // per bucket: counters | starts | cursors | descriptors (kssd_dist.inc)
     size_t cap_bkt;
@@ -215,12 +213,7 @@ static int ctx_upload_tables(kssd_gpu_ctx *c, const std::vector<uint32_t> &accep
     std::vector<uint8_t> T1;
     std::vector<uint32_t> bloom;
     std::vector<KssdG> G;
-    int gw = KSSD_GW;
-#ifdef KSSD_DEV  // development build: KSSD_DEV_BITTAB=1 gives contexts with subk = 6 the bit-table form of stage 1 (KssdBit)
-    c->dev_bit_table = getenv("KSSD_DEV_BITTAB") != nullptr && P.subk == 6;
-    if (c->dev_bit_table) gw = -1;
-#endif
-    if (!kssd_build_tables(P, accepted, gw, T1, bloom, G)) return KSSD_ERR_PARAM;
+    if (!kssd_build_tables(P, accepted, KSSD_GW, T1, bloom, G)) return KSSD_ERR_PARAM;
     const size_t gn = G.size();
     HIPCK(hipMalloc(&c->d_T1, SCAN_TAB_BYTES));
     HIPCK(hipMalloc(&c->d_G, gn * sizeof(KssdG)));
@@ -564,10 +557,10 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
 // the launch carries its own start / stop events (hipExtLaunchKernelGGL): they take the timestamps of the dispatch itself,
 // so kssd_gpu_kernel_time reports the kernel's execution time like the profiler does, not the distance between two
 // stream markers (which also holds the launch latency whenever the kernel in front is too short to hide it)
-template <int SUBK, int ABL = 0, int TAB = 0>
+template <int SUBK, int ABL = 0>
 static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL, TAB>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
+    hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -1018,7 +1011,6 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
         if (abl == 1) { rc = launch_scan<6, 1>(c, a, grid, s, e0, e1); break; }
         if (abl == 2) { rc = launch_scan<6, 2>(c, a, grid, s, e0, e1); break; }
         if (abl == 3) { rc = launch_scan<6, 3>(c, a, grid, s, e0, e1); break; }
-        if (c->dev_bit_table) { rc = launch_scan<6, 0, 1>(c, a, grid, s, e0, e1); break; }  // KSSD_DEV_BITTAB: the bit-table form of stage 1
 #endif
         rc = launch_scan<6>(c, a, grid, s, e0, e1);
         break;

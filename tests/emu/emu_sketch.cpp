@@ -24,8 +24,7 @@ static void run(const KssdParams &P, const uint32_t *packed, const uint32_t *mas
             uint32_t W[5];
             for (int i = 0; i < 5; i++) W[i] = packed[c * 256 + lane * 4 + i];
             uint32_t cl, ch;
-            if constexpr (GW < 0) kssd_stage1b<SUBK>(W, T1, cl, ch);  // the bit-table form (round 4's experiment, SUBK = 6)
-            else kssd_stage1g<SUBK, GW>(W, T1, cl, ch);
+            kssd_stage1g<SUBK, GW>(W, T1, cl, ch);
             cl &= mask[c * 128 + lane * 2];
             ch &= mask[c * 128 + lane * 2 + 1];
             for (int b = 0; b < 64; b++) {
@@ -124,7 +123,6 @@ static long emu_impl(int k, int subk, int drlevel, const int32_t *table, const u
     case S:                                                                                              \
         if (gw == 4) run<S, 4>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand, wp); \
         else if (gw == 5) run<S, 5>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand, wp); \
-        else if (gw == -1 && S == 6) run<6, -1>(P, packed, mask, n_chunks, chunk_gid, T1.data(), bloom.data(), G.data(), res, n_cand, wp); \
         else return -5;                                                                                  \
         break;
         switch (subk) {

@@ -57,7 +57,6 @@ def texts(rng):
 # (one subk = 7 case: its 1 GiB .shuf takes most of this module's time; 10/7/5 is covered by the -m gpu tests)
 CASES = [(k, s, d, 0) for k, s, d in [(10, 6, 3), (8, 5, 2), (9, 6, 3), (11, 6, 3), (8, 4, 1), (12, 7, 4), (9, 3, 1)]]
 CASES += [(10, 6, 3, 4)]  # gw = 0: the kernel's KSSD_GW; 4: another instantiation of the same templates
-CASES += [(10, 6, 3, -1), (9, 6, 3, -1)]  # -1: the bit-table form of stage 1 (KssdBit: one bit per 10-base core, three windows per read)
 
 
 @pytest.mark.parametrize("k,subk,dr,gw", CASES)
