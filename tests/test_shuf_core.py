@@ -62,3 +62,40 @@ def test_a_table_that_is_not_a_permutation_is_refused(tmp_path, shuf_l3k10):
     except K.KssdError:
         pass
     assert not os.path.exists(p + ".core")
+
+
+def test_a_core_whose_values_are_off_is_not_believed(tmp_path, shuf_l3k10):
+    """the header of a cached core may match while its payload does not: a flipped value (checksum), a value twice or beyond
+    16^subk with the checksum recomputed (plausibility), a table rewritten inside one mtime tick at the same size (the 64 sampled
+    ranks are read back from the .shuf itself) -- every time the table is scanned again and the core rewritten"""
+    import struct
+    p = str(tmp_path / "L3K10.shuf")
+    shuf_l3k10.write(p)
+    want = _accepted(shuf_l3k10)
+    K.Shuf.read_core(p)
+
+    def fnv(acc):
+        h = 2166136261
+        for b in acc.astype("<u4").tobytes():
+            h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+        return h
+
+    def rewrite(acc, fix_sum):
+        raw = bytearray(open(p + ".core", "rb").read())
+        raw[48:] = acc.astype("<u4").tobytes()
+        if fix_sum:
+            raw[44:48] = struct.pack("<I", fnv(acc))
+        open(p + ".core", "wb").write(bytes(raw))
+
+    good = open(p + ".core", "rb").read()
+    assert struct.unpack("<I", good[44:48])[0] == fnv(want)
+    for name, mutate, fix in (("flipped value", lambda a: a.__setitem__(7, a[7] ^ 1), False),
+                              ("a value twice", lambda a: a.__setitem__(9, a[10]), True),
+                              ("a value beyond 16^subk", lambda a: a.__setitem__(11, 1 << 24), True),
+                              ("two ranks swapped", lambda a: a.__setitem__(slice(0, 2), a[1::-1].copy()), True)):
+        acc = want.copy()
+        mutate(acc)
+        rewrite(acc, fix)
+        hdr, got, cached = K.Shuf.read_core(p)
+        assert not cached and np.array_equal(got, want), name
+        assert open(p + ".core", "rb").read() == good, name          # rewritten from the table

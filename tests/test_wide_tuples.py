@@ -248,3 +248,37 @@ def test_command_line_in_the_modes_beyond_the_plain_one(tmp_path):
         want = W[tag + ".stat"]
         keep = np.r_[0:5, 8:len(want)]                                              # (bytes 5..7: padding of the bool)
         assert np.array_equal(stat[:len(want)][keep], want[keep]), tag
+
+
+def test_slot_order_of_wide_tuples_with_a_keep_rule():
+    """kssd_slot_order_pos64_keep: every tuple takes its slot of the reference's double-hashing table (insertions in sequence order,
+    global_basic.h:228-230), only the kept ones come back, in slot order -- against a plain replay on a table small enough for
+    hundreds of collisions; with every tuple kept it is kssd_slot_order_pos64"""
+    import ctypes as C
+    L = K.host_lib()
+    L.kssd_slot_order_pos64_keep.restype = C.c_uint64
+    L.kssd_slot_order_pos64_keep.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    rng = np.random.default_rng(12)
+    S = 509
+    for n in (0, 1, 2, 300):
+        t = np.unique(rng.integers(1, 1 << 36, n, dtype=np.uint64))
+        n = len(t)
+        pos = rng.permutation(10 * n + 5)[:n].astype(np.uint32)
+        keep = (rng.random(n) < 0.6).astype(np.uint8)
+        table = {}
+        for i in np.argsort(pos):
+            key = int(t[i])
+            h1, h2 = key % S, 1 + key % (S - 1)
+            k = 0
+            while (h1 + k * h2) % S in table:
+                k += 1
+            table[(h1 + k * h2) % S] = i
+        want = np.array([t[table[s]] for s in sorted(table) if keep[table[s]]], dtype=np.uint64)
+        got = t.copy()
+        m = L.kssd_slot_order_pos64_keep(got.ctypes.data, pos.ctypes.data, keep.ctypes.data, n, S)
+        assert m == len(want) and np.array_equal(got[:m], want), n
+        if n:
+            allk = np.ones(n, np.uint8)
+            got2 = t.copy()
+            assert L.kssd_slot_order_pos64_keep(got2.ctypes.data, pos.ctypes.data, allk.ctypes.data, n, S) == n
+            assert np.array_equal(got2, K.slot_order_pos64(t, pos, S))
