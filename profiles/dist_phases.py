@@ -60,3 +60,21 @@ st = np.sort(t[:, 0] - base) / 100.0
 en = np.sort(t[:, 3] - base) / 100.0
 print("  workgroup starts after the first one (us): median %.2f  p90 %.2f  max %.2f;  ends: median %.2f  p90 %.2f  last %.2f"
       % (st[len(st) // 2], st[len(st) * 9 // 10], st[-1], en[len(en) // 2], en[len(en) * 9 // 10], en[-1]))
+# what a row's walk costs: lists (ids more than one genome holds) and holders on them, per row, against the stamped phases
+o = off.cpu().numpy()
+x = ids[:int(o[-1])].cpu().numpy().view(np.uint32)
+u, inv, cnt = np.unique(x, return_inverse=True, return_counts=True)
+c = cnt[inv]
+Lr = np.array([(c[o[g]:o[g + 1]] > 1).sum() for g in range(G)])
+Hr = np.array([c[o[g]:o[g + 1]][c[o[g]:o[g + 1]] > 1].sum() for g in range(G)])
+M16 = np.array([(c[o[g]:o[g + 1]] > 16).sum() for g in range(G)])
+print("  per row: ids %d..%d, lists median %d max %d, holders on lists median %d max %d, lists of more than 16 holders median %d max %d"
+      % ((o[1:] - o[:-1]).min(), (o[1:] - o[:-1]).max(), np.median(Lr), Lr.max(), np.median(Hr), Hr.max(), np.median(M16), M16.max()))
+order = np.argsort(Hr)
+for lo, hi in ((0, G // 10), (G // 10, G // 2), (G // 2, G * 9 // 10), (G * 9 // 10, G)):
+    r = order[lo:hi]
+    print("  rows by holders [%4d, %4d): lists %6.0f  holders %7.0f  >16: %5.0f | probe %6.2f us  walk %6.2f  epilogue %5.2f  whole %6.2f  (means)"
+          % (lo, hi, Lr[r].mean(), Hr[r].mean(), M16[r].mean(), d[r, 0].mean() / 100, d[r, 1].mean() / 100, d[r, 2].mean() / 100, tot[r].mean() / 100))
+A = np.stack([np.ones(G), Lr, Hr, M16], 1)
+coef, *_ = np.linalg.lstsq(A, d[:, 1] / 100.0, rcond=None)
+print("  walk us ~ %.2f + %.4f lists + %.5f holders + %.4f long lists (least squares over the rows)" % tuple(coef))
