@@ -294,6 +294,12 @@ KSSD_HD void kssd_carry_from_words(uint32_t wm, uint32_t wa, uint32_t wb, uint32
     front = (uint32_t)(((((uint64_t)wm << 32) | wa) << sh) >> 32) & 0xFFu;
 }
 
+// A bit per hash value of the accepted sub-contexts, in front of the exact table (per-genome kernel, FUSED): half of the scan's
+// candidates are in S by their reverse complement only and fail the exact lookup of their canonical sub-context -- 65 536 bits
+// (8 KiB of LDS the bucket sort's counters occupy later) answer "not accepted" for 94 % of those without the 16-byte read.
+#define KSSD_GFILT_WORDS 2048u
+KSSD_HD uint32_t kssd_gfilt_bit(uint32_t dim) { return (dim * 0x9E3779B1u) >> 16; }
+
 struct KssdG {  // one slot of the exact table: accepted sub-context -> permutation rank
     uint32_t key;  // sub-context, KSSD_EMPTY_KEY when free
     uint32_t rank;

@@ -90,6 +90,7 @@ struct kssd_gpu_ctx {
     KssdParams P;
     uint8_t *d_T1;
     KssdG *d_G;
+    uint32_t *d_gfilt;      // bit filter of the accepted sub-contexts (behind d_G: kssd_gfilt_bit)
     // sketch workspace
     uint32_t *d_chunk_gid;
     size_t cap_chunks;
@@ -216,7 +217,16 @@ static int ctx_upload_tables(kssd_gpu_ctx *c, const std::vector<uint32_t> &accep
     if (!kssd_build_tables(P, accepted, KSSD_GW, T1, bloom, G)) return KSSD_ERR_PARAM;
     const size_t gn = G.size();
     HIPCK(hipMalloc(&c->d_T1, SCAN_TAB_BYTES));
-    HIPCK(hipMalloc(&c->d_G, gn * sizeof(KssdG)));
+    HIPCK(hipMalloc(&c->d_G, gn * sizeof(KssdG) + KSSD_GFILT_WORDS * 4));  // (the exact table, then its bit filter)
+    {
+        std::vector<uint32_t> gf(KSSD_GFILT_WORDS, 0u);
+        for (uint32_t dim : accepted) {
+            const uint32_t h = kssd_gfilt_bit(dim);
+            gf[h >> 5] |= 1u << (h & 31u);
+        }
+        c->d_gfilt = reinterpret_cast<uint32_t *>(c->d_G + gn);
+        HIPCK(hipMemcpy(c->d_gfilt, gf.data(), KSSD_GFILT_WORDS * 4, hipMemcpyHostToDevice));
+    }
     HIPCK(hipMemcpy(c->d_T1, T1.data(), KSSD_T1_BYTES, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(c->d_T1 + KSSD_T1_BYTES, bloom.data(), KSSD_BLOOM_WORDS * 4, hipMemcpyHostToDevice));
     HIPCK(hipMemcpy(c->d_G, G.data(), gn * sizeof(KssdG), hipMemcpyHostToDevice));
@@ -622,12 +632,13 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
     if (c->h_big.empty() && c->h_med.empty()) {
         // no genome needs staged tuples: exact stage and per-genome sort in one kernel, straight from the candidate list
         const auto &pl = c->plan;
-        fx.cand = reinterpret_cast<const ulonglong2 *>(c->d_cand);
+        fx.cand = reinterpret_cast<const unsigned long long *>(c->d_cand);  // (8-byte records: phase_scan's rec8)
         fx.blk_info = c->d_blk_info;
         fx.chunk_off = (const unsigned long long *)c->d_chunk_off;
         fx.packed = pl.d_packed;
         fx.mask = pl.d_mask;
         fx.G = c->d_G;
+        fx.gfilt = c->d_gfilt;
         fx.carry = kssd_carry_ok(c->P) ? 1u : 0u;
         fx.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
         fx.lds_keys = np;
@@ -986,6 +997,7 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     ScanArgs a;
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
+    a.rec8 = (c->h_big.empty() && c->h_med.empty()) ? 1u : 0u;  // (= scanned.fused below: the FINISH phase evaluates the candidates itself)
     a.stage1_count = c->d_cand_count + pl.n_slices;
     a.blk_info = c->d_blk_info;
     a.status = c->d_status;
