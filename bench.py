@@ -1008,6 +1008,10 @@ def main():
                     help="N > 1: torch = one process per GPU, torch.distributed (RCCL) all-gather (the default; under torch.distributed.run "
                          "rank 0 falls back to `c` when the process group cannot be set up); c = ONE process drives the N devices, the "
                          "exchange is kssd_gpu_allgather_sketches of the C ABI (RCCL inside libkssd_gpu.so, no torch.distributed)")
+    ap.add_argument("--kernel-timing", type=int, default=int(os.environ.get("KSSD_BENCH_KERNEL_TIMING", "4")),
+                    help="allpairs: every N-th launch of the scan / rows kernels inside the timed region carries the HIP events the roofline "
+                         "figures come from (kssd_gpu_set_kernel_timing; 1 = every launch).  A bracketed dispatch does not overlap its "
+                         "neighbours in the stream, which costs the step several microseconds per bracket (profiles/r04E_gaps.txt)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
                     help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial, the default; 3 = pipelined)")
     a = ap.parse_args()
@@ -1229,9 +1233,11 @@ def main():
         spinup_done[0] = spun
         run_steps(a.warmup)
         sync()
+        every = max(1, min(a.kernel_timing, max(1, a.steps // max(1, NF))))    # (at least one timed launch per slot)
         for sl in slots:
             sl.ctx.kernel_time(0, reset=True)
             sl.ctx.kernel_time(1, reset=True)
+            sl.ctx.set_kernel_timing(every)
         t0 = time.perf_counter()
         run_steps(a.steps)
         sync()
@@ -1265,11 +1271,14 @@ def main():
         run_dist(a.warmup)
         sync()
         slots[0].ctx.kernel_time(1, reset=True)
+        slots[0].ctx.set_kernel_timing(every)
         t0 = time.perf_counter()
         run_dist(a.steps)
         sync()
         dt_dist = time.perf_counter() - t0
         dist_only_ms, dist_only_n = slots[0].ctx.kernel_time(1)
+        for sl in slots:
+            sl.ctx.set_kernel_timing(1)
         if slots[0].ctx.index_status(slots[0].stream) != 0:
             raise SystemExit("index status after the distance loop: the build overflowed")
         tmax = torch.tensor([dt_dist], dtype=torch.float64, device=dev)
@@ -1408,6 +1417,7 @@ def main():
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
             "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [m["scan_n"], m["dist_n"]],
+                        "timed_every": a.kernel_timing,   # every N-th launch of the timed region carries the events (--kernel-timing)
                         "dist_rows_GBs": dist_bytes / (dist_ms * 1e-3) / 1e9 if dist_ms > 0 else None,
                         "scan_positions_past_stage1": m["n_stage1"] / n_bases, "scan_positions_past_bloom": m["n_bloom"] / n_bases},
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,

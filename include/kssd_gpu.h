@@ -462,6 +462,13 @@ int kssd_gpu_set_filter(kssd_gpu_ctx *ctx, const uint64_t *off, const uint32_t *
  * reset != 0 empties the ring.
  */
 int kssd_gpu_kernel_time(kssd_gpu_ctx *ctx, int which, int reset, float *avg_ms, uint32_t *launches);
+/*
+ * How many launches carry the events: every `every`-th one of each path from this call on (1: all of them, the default;
+ * 0: none).  A bracketed dispatch does not overlap its neighbours in the stream -- it waits for the kernel in front to drain
+ * and the kernel behind waits for its time stamp --, which costs a step of six short kernels several microseconds per bracket
+ * (profiles/r04E_gaps.txt); a caller that streams steps measures a sample of its launches instead of all.
+ */
+int kssd_gpu_set_kernel_timing(kssd_gpu_ctx *ctx, uint32_t every);
 
 #ifdef __cplusplus
 }

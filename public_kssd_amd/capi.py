@@ -37,7 +37,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_create_for_dist",
     "kssd_gpu_destroy", "kssd_gpu_get_info", "kssd_gpu_sketch_device", "kssd_gpu_sketch_status",
     "kssd_gpu_sketch_batch", "kssd_gpu_free", "kssd_gpu_index_build_device", "kssd_gpu_dist_device",
-    "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
+    "kssd_gpu_dist", "kssd_gpu_kernel_time", "kssd_gpu_set_kernel_timing", "kssd_gpu_scan_stats", "kssd_gpu_sketch_set_pos_output",
     "kssd_gpu_sketch_batch_pos", "kssd_gpu_set_union", "kssd_gpu_set_filter", "kssd_gpu_sketch_plan",
     "kssd_gpu_sketch_phase", "kssd_gpu_set_lds_sort_limit", "kssd_gpu_dist_multi", "kssd_gpu_device_count",
     "kssd_gpu_host_alloc", "kssd_gpu_host_free", "kssd_gpu_dist_select", "kssd_gpu_dist_device_long",
@@ -199,6 +199,7 @@ def gpu_lib():
         L.kssd_gpu_sketch_fasta_text.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                  C.POINTER(C.c_int64)]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
+        L.kssd_gpu_set_kernel_timing.argtypes = [vp, u32]
         L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
         L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
         L.kssd_gpu_set_scan_grid.argtypes = [vp, u32]
@@ -939,6 +940,10 @@ class GpuCtx:
         a, b = C.c_uint64(0), C.c_uint64(0)
         _gck(gpu_lib().kssd_gpu_scan_stats(self.h, C.byref(a), C.byref(b), stream))
         return a.value, b.value
+
+    def set_kernel_timing(self, every):
+        """bracket every `every`-th launch of the scan / rows kernels with events (1: all, 0: none)"""
+        _gck(gpu_lib().kssd_gpu_set_kernel_timing(self.h, int(every)))
 
     def kernel_time(self, which, reset=False):
         """(average ms, launches) of the dominant kernel: 0 = sketch scan, 1 = distance rows"""

@@ -206,6 +206,7 @@ struct kssd_gpu_ctx {
     // timing: ring of HIP event pairs around the dominant kernel of each path (0 = sketch scan, 1 = dist rows)
     hipEvent_t ev_a[2][EV_RING], ev_b[2][EV_RING];
     unsigned ev_n[2];
+    unsigned ev_every[2], ev_launch[2];  // every ev_every-th launch is bracketed (0: none), counted by ev_launch (kssd_gpu_set_kernel_timing)
 };
 
 static int ctx_upload_tables(kssd_gpu_ctx *c, const std::vector<uint32_t> &accepted)
@@ -271,6 +272,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
         for (int i = 0; i < EV_RING; i++) {
             hipEventCreate(&c->ev_a[w][i]);
             hipEventCreate(&c->ev_b[w][i]);
+            c->ev_every[w] = 1;
         }
     *out = c;
     return KSSD_OK;
@@ -317,6 +319,7 @@ extern "C" int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int dev
         for (int i = 0; i < EV_RING; i++) {
             hipEventCreate(&c->ev_a[w][i]);
             hipEventCreate(&c->ev_b[w][i]);
+            c->ev_every[w] = 1;
         }
     *out = c;
     return KSSD_OK;
@@ -567,10 +570,18 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
 // the launch carries its own start / stop events (hipExtLaunchKernelGGL): they take the timestamps of the dispatch itself,
 // so kssd_gpu_kernel_time reports the kernel's execution time like the profiler does, not the distance between two
 // stream markers (which also holds the launch latency whenever the kernel in front is too short to hide it)
+// is this launch of the path's dominant kernel (0 = scan, 1 = rows) one of the bracketed ones?
+static bool kernel_timed(kssd_gpu_ctx *c, int which)
+{
+    const unsigned every = c->ev_every[which], n = c->ev_launch[which]++;
+    return every != 0 && n % every == 0;
+}
+
 template <int SUBK, int ABL = 0>
 static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
+    if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
+    else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -1011,7 +1022,8 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
 #endif
     const int grid = pl.grid;
     const unsigned evi = c->ev_n[0] % EV_RING;
-    hipEvent_t e0 = c->ev_a[0][evi], e1 = c->ev_b[0][evi];
+    const bool timed = kernel_timed(c, 0);
+    hipEvent_t e0 = timed ? c->ev_a[0][evi] : nullptr, e1 = timed ? c->ev_b[0][evi] : nullptr;
     switch (c->P.subk) {
     case 2: rc = launch_scan<2>(c, a, grid, s, e0, e1); break;
     case 3: rc = launch_scan<3>(c, a, grid, s, e0, e1); break;
@@ -1031,7 +1043,7 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     default: rc = KSSD_ERR_UNSUPPORTED;
     }
     if (rc != KSSD_OK) return rc;
-    c->ev_n[0]++;
+    if (timed) c->ev_n[0]++;
     c->scanned.valid = true;  // what a further tuple pass (KSSD_PHASE_REPASS) must find unchanged
     c->scanned.cand = c->d_cand;
     c->scanned.blk_info = c->d_blk_info;
@@ -1357,6 +1369,14 @@ extern "C" int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *c, const uint32_t *packed
 {
     if (!out_pos) return KSSD_ERR_PARAM;
     return sketch_batch_impl(c, packed, mask, chunk_off, n_genomes, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
+}
+
+extern "C" int kssd_gpu_set_kernel_timing(kssd_gpu_ctx *c, uint32_t every)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    c->ev_every[0] = c->ev_every[1] = every;
+    c->ev_launch[0] = c->ev_launch[1] = 0;
+    return KSSD_OK;
 }
 
 extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float *avg_ms, uint32_t *launches)

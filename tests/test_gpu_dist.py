@@ -71,6 +71,25 @@ def test_all_pairs_self(gpu_ctx):
     assert np.array_equal(shared, ko.shared_counts(off, ids, off, ids, threads=4))
 
 
+def test_kernel_timing_is_a_sample_of_the_launches(shuf_l3k10):
+    """kssd_gpu_set_kernel_timing: every launch of the rows kernel carries events by default, every n-th one or none after the call;
+    the results do not depend on it"""
+    rng = np.random.default_rng(5)
+    off, ids = random_sketches(rng, 40, 100, 300, 1 << 28, clades=3)
+    want = ko.shared_counts(off, ids, off, ids)
+    ctx = K.GpuCtx(shuf_l3k10)
+    try:
+        for every, timed in ((1, 6), (0, 0), (4, 2), (1, 6)):
+            ctx.set_kernel_timing(every)
+            ctx.kernel_time(1, reset=True)
+            for _ in range(6):
+                assert np.array_equal(ctx.dist(off, ids, off, ids, planes=False), want)
+            ms, n = ctx.kernel_time(1, reset=True)
+            assert n == timed and (ms > 0) == (timed > 0), (every, n, ms)
+    finally:
+        ctx.close()
+
+
 def test_long_postings_and_empty_rows(gpu_ctx):
     # one id held by every reference (posting as long as the reference set), empty query, empty reference
     R = 300
