@@ -534,27 +534,50 @@ static inline bool kssd_build_tables(KssdParams &P, const std::vector<uint32_t> 
         add_bloom(accepted[r]);
         add_bloom(rc);
     }
-    // every key into the bucket its first multiplier names, or -- that one full -- into its second bucket, the first one marked;
-    // both full (it does not happen at a quarter load, but nothing forbids it): new multipliers, start over
+    // every key into the bucket its first multiplier names, or -- that one full -- into its second bucket, the first one marked.
+    // Both full (3 - 4 keys of 4 096 at a quarter load): one of the four keys that sit there moves to ITS other bucket if that one
+    // has room (a key may sit in its first bucket, or in its second with the first one marked: moving home needs nothing, moving
+    // out marks the bucket it leaves), and the key takes the freed slot.  Without that step an attempt succeeded once in a few
+    // hundred and a context took 20 - 60 ms of multiplier lottery; with it the first attempt nearly always does.  Still nothing
+    // free: new multipliers, start over.
     const size_t nb = (size_t)1 << P.g_log2;
     uint64_t seed = 0x243F6A8885A308D3ull;
+    auto put = [&](size_t b, int k, uint32_t key, uint32_t rank) {
+        G[2 * b + k].key = key;
+        G[2 * b + k].rank = (G[2 * b + k].rank & KSSD_G_MOVED) | rank;  // (slot 0 carries its bucket's mark)
+    };
+    auto free_slot = [&](size_t b) -> int {
+        for (int k = 0; k < 2; k++)
+            if (G[2 * b + k].key == KSSD_EMPTY_KEY) return k;
+        return -1;
+    };
     for (int attempt = 0;; attempt++) {
         if (attempt == (1 << 16)) return false;
         G.assign(2 * nb, KssdG{KSSD_EMPTY_KEY, 0});
         bool ok = true;
         for (size_t r = 0; r < accepted.size() && ok; r++) {
-            const size_t b0 = kssd_g_slot(accepted[r], P.g_mul[0], P.g_log2), b1 = kssd_g_slot(accepted[r], P.g_mul[1], P.g_log2);
+            const uint32_t key = accepted[r];
+            const size_t b0 = kssd_g_slot(key, P.g_mul[0], P.g_log2), b1 = kssd_g_slot(key, P.g_mul[1], P.g_log2);
+            int k = free_slot(b0);
+            if (k >= 0) { put(b0, k, key, (uint32_t)r); continue; }
+            G[2 * b0].rank |= KSSD_G_MOVED;  // (the key will not sit in its first bucket -- unless a slot is freed there below: the mark is harmless then)
+            k = free_slot(b1);
+            if (k >= 0) { put(b1, k, key, (uint32_t)r); continue; }
             ok = false;
             for (int pass = 0; pass < 2 && !ok; pass++) {
                 const size_t b = pass ? b1 : b0;
-                for (int k = 0; k < 2 && !ok; k++) {
-                    if (G[2 * b + k].key == KSSD_EMPTY_KEY) {
-                        G[2 * b + k].key = accepted[r];
-                        G[2 * b + k].rank = (G[2 * b + k].rank & KSSD_G_MOVED) | (uint32_t)r;  // (slot 0 may carry its bucket's mark already)
-                        ok = true;
-                    }
+                for (int v = 0; v < 2 && !ok; v++) {
+                    const uint32_t vkey = G[2 * b + v].key, vrank = G[2 * b + v].rank & ~KSSD_G_MOVED;
+                    const size_t v0 = kssd_g_slot(vkey, P.g_mul[0], P.g_log2), v1 = kssd_g_slot(vkey, P.g_mul[1], P.g_log2);
+                    const size_t alt = b == v0 ? v1 : v0;  // (v0 == v1: no other bucket)
+                    if (alt == b) continue;
+                    const int ka = free_slot(alt);
+                    if (ka < 0) continue;
+                    put(alt, ka, vkey, vrank);
+                    if (alt == v1) G[2 * v0].rank |= KSSD_G_MOVED;  // the victim left its first bucket
+                    put(b, v, key, (uint32_t)r);                    // (b = b1: the key's first bucket is marked above)
+                    ok = true;
                 }
-                if (!ok && pass == 0) G[2 * b0].rank |= KSSD_G_MOVED;
             }
         }
         if (ok) break;

@@ -268,12 +268,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
         delete c;
         return KSSD_ERR_NOMEM;
     }
-    for (int w = 0; w < 2; w++)
-        for (int i = 0; i < EV_RING; i++) {
-            hipEventCreate(&c->ev_a[w][i]);
-            hipEventCreate(&c->ev_b[w][i]);
-            c->ev_every[w] = 1;
-        }
+    c->ev_every[0] = c->ev_every[1] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
     *out = c;
     return KSSD_OK;
 }
@@ -315,12 +310,7 @@ extern "C" int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int dev
     c->dist_only = true;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) { delete c; return KSSD_ERR_NOMEM; }
-    for (int w = 0; w < 2; w++)
-        for (int i = 0; i < EV_RING; i++) {
-            hipEventCreate(&c->ev_a[w][i]);
-            hipEventCreate(&c->ev_b[w][i]);
-            c->ev_every[w] = 1;
-        }
+    c->ev_every[0] = c->ev_every[1] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
     *out = c;
     return KSSD_OK;
 }
@@ -340,8 +330,8 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     for (int w = 0; w < 2; w++)
         for (int i = 0; i < EV_RING; i++) {
-            hipEventDestroy(c->ev_a[w][i]);
-            hipEventDestroy(c->ev_b[w][i]);
+            if (c->ev_a[w][i]) hipEventDestroy(c->ev_a[w][i]);
+            if (c->ev_b[w][i]) hipEventDestroy(c->ev_b[w][i]);
         }
     delete c;
 }
@@ -574,7 +564,11 @@ __global__ __launch_bounds__(256) void sketch_gather_kernel(const unsigned long 
 static bool kernel_timed(kssd_gpu_ctx *c, int which)
 {
     const unsigned every = c->ev_every[which], n = c->ev_launch[which]++;
-    return every != 0 && n % every == 0;
+    if (every == 0 || n % every != 0) return false;
+    const unsigned i = c->ev_n[which] % EV_RING;  // the ring's events are made when a launch first needs them (512 of them up front were
+    if (!c->ev_a[which][i] && hipEventCreate(&c->ev_a[which][i]) != hipSuccess) return false;  // milliseconds of every context's creation)
+    if (!c->ev_b[which][i] && hipEventCreate(&c->ev_b[which][i]) != hipSuccess) return false;
+    return true;
 }
 
 template <int SUBK, int ABL = 0>

@@ -957,7 +957,16 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pthread_t xwarm;
     xwarm_arg xa = {o->devs, n_dev};
     const int xwarming = o->allpairs && (n_dev > 1 || getenv("KSSD_EXCHANGE_ONE_RANK")) && pthread_create(&xwarm, NULL, warm_exchange, &xa) == 0;
-    const int n_workers = 2 * n_dev;
+    /* sketch workers per device (each with its own context and stream) and text buffers beyond one per worker: tuning knobs of the
+     * pipeline, measured in profiles/r04I_e2e_workers_buffers.txt */
+    int wpd = 2, extra_bufs = 1;
+    if (getenv("KSSD_WORKERS_PER_DEVICE")) wpd = atoi(getenv("KSSD_WORKERS_PER_DEVICE"));
+    if (getenv("KSSD_TEXT_BUFFERS_EXTRA")) extra_bufs = atoi(getenv("KSSD_TEXT_BUFFERS_EXTRA"));
+    if (wpd < 1) wpd = 1;
+    if (wpd > 8) wpd = 8;
+    if (extra_bufs < 1) extra_bufs = 1;
+    if (extra_bufs > 32) extra_bufs = 32;
+    const int n_workers = wpd * n_dev;
     const int threads = o->p > 0 ? o->p : 1;
     pipeline pl;
     memset(&pl, 0, sizeof pl);
@@ -977,7 +986,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         pl.res = res;
         pl.first = first;
     }
-    const int n_batches = n_workers + 1; /* one being filled, one per worker */
+    const int n_batches = n_workers + extra_bufs; /* one (or more) being filled, one per worker */
     pl.pool = calloc((size_t)n_batches, sizeof *pl.pool);
     for (int i = 0; i < n_batches; i++) {
         pl.pool[i] = kssd_batch_create_ex(kssd_gpu_host_alloc, kssd_gpu_host_free);
