@@ -45,8 +45,27 @@ int main()
     t[n++] = now();  // 7: first search (library code object loaded)
     if (kssd_gpu_dist(c, off, ids, 2, off, ids, 2, shared, j, m, cc, a) != 0) return 3;
     t[n++] = now();  // 8: second search
+    // a sketch context (tables of 4 096 accepted sub-contexts built and uploaded), then a second one
+    {
+        kssd_shuf_hdr hdr = {1, 10, 6, 3};
+        static uint32_t acc[4096];
+        uint32_t x = 12345u;
+        for (int i = 0; i < 4096; i++) { x = x * 1664525u + 1013904223u; acc[i] = ((x >> 8) & 0xFFF000u) | (uint32_t)i; }  // distinct, below 16^6
+        kssd_gpu_ctx *s1 = nullptr, *s2 = nullptr;
+        if (kssd_gpu_create_compact(&s1, &hdr, acc, 4096, 0) != 0) return 4;
+        t[n++] = now();  // 9
+        if (kssd_gpu_create_compact(&s2, &hdr, acc, 4096, 0) != 0) return 4;
+        t[n++] = now();  // 10
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 5;
+        t[n++] = now();  // 11
+        hipStream_t st;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return 5;
+        t[n++] = now();  // 12
+    }
     const char *what[] = {"hipInit", "hipSetDevice + hipFree(0)", "hipMalloc 1 MiB", "first kernel, own code object", "hipHostMalloc 64 MiB",
-                          "kssd_gpu_create_for_dist", "first kssd_gpu_dist (2 x 2)", "second kssd_gpu_dist"};
+                          "kssd_gpu_create_for_dist", "first kssd_gpu_dist (2 x 2)", "second kssd_gpu_dist",
+                          "kssd_gpu_create_compact (first)", "kssd_gpu_create_compact (second)", "hipGetDeviceProperties", "hipStreamCreateWithFlags"};
     for (int i = 1; i < n; i++) printf("%-36s %8.2f ms\n", what[i - 1], (t[i] - t[i - 1]) * 1e3);
     printf("%-36s %8.2f ms   shared %u %u %u %u\n", "total", (t[n - 1] - t[0]) * 1e3, shared[0], shared[1], shared[2], shared[3]);
     return 0;
