@@ -7,16 +7,15 @@ One step = one pass of the hot path over one batch that is already resident in H
         (shared counts + Jaccard / MashD / containment / AafD, 36 B per pair)
 Workload = BASELINE.json configs[1]: 1 000 synthetic 5 Mb bacterial genomes per GPU (50 clades x 20 members,
 0.5-5 % substitutions, 1e-4 N), L3K10 shuffle, all-pairs.  Weak scaling: every rank sketches its own 1 000
-genomes and computes the block of the all-pairs matrix between ITS genomes and ALL N x 1 000 genomes.  It puts
-its own genomes on the indexed side (all gathered sketches are the query rows): the index build is the part
-that would otherwise be repeated on every rank, and every metric of the path is symmetric in (query, reference),
-so the R x G block a rank writes is the transpose of its G x R query block.
+genomes and computes the block of the all-pairs matrix between ITS genomes and ALL N x 1 000 genomes -- in north_star's
+partition (--partition query, the headline: every rank gathers all sketches, builds the full index and computes the rows of
+its own query block) and, measured beside it, in the transposed one (own sketches indexed, all gathered sketches as query
+rows: the index build stays constant per rank; every metric of the path is symmetric in (query, reference)).
 
 By default the steps run back to back on one stream (--inflight 1): the roofline figure of the scan is then the kernel's
-own.  --inflight 3 pipelines the steps over three contexts and streams, so that the latency-bound kernels of one step
-(exact stage, index build) run underneath the scan of the next one: +8 % genomes/s on one MI355X, at the price of a scan
-that shares the machine (its launch takes a few per cent longer); DESIGN.md section 5 has both sets of numbers and the
-other schedules that were measured.
+own.  --inflight 3 pipelines the steps over three contexts and streams (reported as `pipelined`; within 1 - 3 % of the
+sequential figure since the exact stage moved into the per-genome kernel: the scan holds every CU's LDS, nothing runs under it).
+Every --kernel-timing-th launch of the scan / rows kernels inside the timed region carries the events of the roofline figures.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -38,78 +37,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import public_kssd_amd as K  # noqa: E402
+from benchlib.launch import host_cores, log, self_launch  # noqa: E402
+from benchlib.workloads import make_batch, make_long_records, make_reads_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-
-
-def log(*a):
-    print(*a, file=sys.stderr, flush=True)
-
-
-def host_cores():
-    """host threads worth starting: the machine's processors, but not more than the CPU time the container may use
-    (cgroup cpu.max): on the measurement box 256 processors are visible under a quota of 16"""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = min(n, max(1, -(-int(q) // int(p))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, -(-q // p)))
-        except Exception:
-            pass
-    return n
-
-
-# ------------------------------------------------------------------------------------------------------
-# synthetic batch, generated and packed on the device (setup, untimed)
-# ------------------------------------------------------------------------------------------------------
-def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0, on_genome=None, keep_on_device=False):
-    """returns packed int32[words+slack], mask int32[...], chunk_off uint64[n+1], kept [(codes u8, nmask bool)]
-    on_genome(gi, codes u8 tensor, nmask bool tensor): called for every genome (device tensors, valid during the call);
-    keep_on_device: `kept` holds device tensors instead of numpy arrays"""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    chunks = (length + K.CHUNK_BASES - 1) // K.CHUNK_BASES
-    padded = chunks * K.CHUNK_BASES
-    packed = torch.zeros(n_genomes * chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
-    mask = torch.zeros(n_genomes * chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
-    wsh = (30 - 2 * torch.arange(16, device=dev, dtype=torch.int64))
-    msh = torch.arange(32, device=dev, dtype=torch.int64)
-    per = (n_genomes + n_clades - 1) // n_clades
-    kept = []
-    gi = 0
-    for c in range(n_clades):
-        anc = torch.randint(0, 4, (length,), generator=g, device=dev, dtype=torch.uint8)
-        for m in range(per):
-            if gi >= n_genomes:
-                break
-            rate = 0.005 + 0.045 * float(torch.rand((), generator=g, device=dev))
-            mut = torch.rand(length, generator=g, device=dev) < rate
-            add = torch.randint(1, 4, (length,), generator=g, device=dev, dtype=torch.uint8)
-            codes = torch.where(mut, (anc + add) & 3, anc)
-            nmask = torch.rand(length, generator=g, device=dev) < 1e-4
-            valid = ~nmask
-            codes_v = torch.where(valid, codes, torch.zeros_like(codes))
-            cp = torch.zeros(padded, dtype=torch.int64, device=dev)
-            cp[:length] = codes_v
-            vp = torch.zeros(padded, dtype=torch.int64, device=dev)
-            vp[:length] = valid
-            w = (cp.view(-1, 16) << wsh).sum(1)
-            mw = (vp.view(-1, 32) << msh).sum(1)
-            packed[gi * chunks * K.CHUNK_WORDS:(gi + 1) * chunks * K.CHUNK_WORDS] = w.to(torch.int32)
-            mask[gi * chunks * K.CHUNK_MASKW:(gi + 1) * chunks * K.CHUNK_MASKW] = mw.to(torch.int32)
-            if gi < keep_codes:
-                kept.append((codes, nmask) if keep_on_device else (codes.cpu().numpy(), nmask.cpu().numpy()))
-            if on_genome is not None:
-                on_genome(gi, codes, nmask)
-            gi += 1
-    chunk_off = np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(chunks)
-    return packed, mask, chunk_off, kept
+# (the synthetic workloads -- make_batch, make_reads_batch, make_long_records -- and the launcher plumbing live in benchlib/)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -319,49 +251,6 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
 READ_LEN = 150
 
 
-def make_reads_batch(src_codes, n_reads, seed, dev, err=0.005, keep_reads=0, slice_reads=1 << 21):
-    """packed / mask / chunk_off of n_reads x 150 bp drawn from the device code tensors `src_codes` (equally long),
-    either strand, substitution errors at rate err; the codes of the first keep_reads reads come back as a host array"""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    L = int(src_codes[0].numel())
-    flat = torch.cat(src_codes)
-    stride = READ_LEN + 1
-    n_pos = n_reads * stride
-    chunks = (n_pos + K.CHUNK_BASES - 1) // K.CHUNK_BASES
-    packed = torch.zeros(chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
-    mask = torch.zeros(chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
-    wsh = (30 - 2 * torch.arange(16, device=dev, dtype=torch.int64))
-    msh = torch.arange(32, device=dev, dtype=torch.int64)
-    j = torch.arange(stride, device=dev, dtype=torch.int64)
-    validj = (j < READ_LEN)
-    kept = np.zeros((keep_reads, READ_LEN), dtype=np.uint8)
-    for r0 in range(0, n_reads, slice_reads):
-        S = min(slice_reads, n_reads - r0)
-        S32 = (S + 31) // 32 * 32                       # whole mask words per slice (the surplus reads are cut off below)
-        gi = torch.randint(0, len(src_codes), (S32,), generator=g, device=dev)
-        st = torch.randint(0, L - READ_LEN, (S32,), generator=g, device=dev)
-        rev = torch.rand(S32, generator=g, device=dev) < 0.5
-        jj = torch.where(rev[:, None], (READ_LEN - 1 - j).clamp(min=0)[None, :], j.clamp(max=READ_LEN - 1)[None, :])
-        v = flat[(gi * L + st)[:, None] + jj]
-        v = torch.where(rev[:, None], 3 - v, v)
-        e = torch.rand(v.shape, generator=g, device=dev) < err
-        v = torch.where(e, (v + torch.randint(1, 4, v.shape, generator=g, device=dev, dtype=torch.uint8)) & 3, v)
-        ok = validj[None, :] & (torch.arange(S32, device=dev) < S)[:, None]
-        v = torch.where(ok, v, torch.zeros_like(v))
-        if r0 < keep_reads:
-            m = min(keep_reads - r0, S)
-            kept[r0:r0 + m] = v[:m, :READ_LEN].cpu().numpy()
-        w = (v.reshape(-1, 16).to(torch.int64) << wsh).sum(1).to(torch.int32)
-        mw = (ok.reshape(-1, 32).to(torch.int64) << msh).sum(1).to(torch.int32)
-        p0 = r0 * stride
-        assert p0 % 32 == 0
-        nw = min(len(w), (n_pos - p0 + 15) // 16)
-        nm = min(len(mw), (n_pos - p0 + 31) // 32)
-        packed[p0 // 16:p0 // 16 + nw] = w[:nw]
-        mask[p0 // 32:p0 // 32 + nm] = mw[:nm]
-        del v, e, ok, w, mw, jj
-    return packed, mask, np.array([0, chunks], dtype=np.uint64), kept
 
 
 def fastq_end_to_end(shuf, fq, n_reads, sk, ko):
@@ -597,40 +486,6 @@ def run_fastq(a, shuf, dev):
 #     (and the reference binary when the snapshot carries it): the UNION of their id sets must be record 0's sketch;
 # (b) the first 400 Mb of record 0 as a record of its own WITHOUT the flag: the reference's abort, naming the genome.
 # ------------------------------------------------------------------------------------------------------
-def make_long_records(n, length, seed, dev, keep_first):
-    """n records of `length` uniform random bases with 1e-5 isolated N, packed on the device slice by slice;
-    returns packed, mask, chunk_off and (record 0's codes u8, N mask bool) on the host when keep_first"""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    chunks = (length + K.CHUNK_BASES - 1) // K.CHUNK_BASES
-    packed = torch.zeros(n * chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
-    mask = torch.zeros(n * chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
-    wsh = (30 - 2 * torch.arange(16, device=dev, dtype=torch.int64))
-    msh = torch.arange(32, device=dev, dtype=torch.int64)
-    S = 1 << 26
-    kept_c = np.empty(length, dtype=np.uint8) if keep_first else None
-    kept_n = np.empty(length, dtype=bool) if keep_first else None
-    for gi in range(n):
-        for p0 in range(0, length, S):
-            m = min(S, length - p0)
-            mp = (m + 31) // 32 * 32
-            codes = torch.randint(0, 4, (mp,), generator=g, device=dev, dtype=torch.uint8)
-            isn = torch.rand(mp, generator=g, device=dev) < 1e-5
-            isn[1:] &= ~isn[:-1]                                   # isolated: one N = one invalid position, as the tokeniser lays it out
-            ok = ~isn
-            ok[m:] = False
-            codes = torch.where(ok, codes, torch.zeros_like(codes))
-            if keep_first and gi == 0:
-                kept_c[p0:p0 + m] = codes[:m].cpu().numpy()
-                kept_n[p0:p0 + m] = isn[:m].cpu().numpy()
-            w = (codes.view(-1, 16).to(torch.int64) << wsh).sum(1).to(torch.int32)
-            mw = (ok.view(-1, 32).to(torch.int64) << msh).sum(1).to(torch.int32)
-            b0 = gi * chunks * K.CHUNK_BASES + p0
-            packed[b0 // 16:b0 // 16 + len(w)] = w
-            mask[b0 // 32:b0 // 32 + len(mw)] = mw
-            del codes, isn, ok, w, mw
-    chunk_off = np.arange(n + 1, dtype=np.uint64) * np.uint64(chunks)
-    return packed, mask, chunk_off, (kept_c, kept_n)
 
 
 def run_mammal(a, dev, world, rank):
@@ -814,34 +669,6 @@ def run_mammal(a, dev, world, rank):
 
 
 # ------------------------------------------------------------------------------------------------------
-def self_launch(a):
-    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, as children, BEFORE
-    anything in this process touches the GPU (never an exec from a process that has initialised HIP), relay rank 0's one
-    JSON line and the children's exit code.  Under `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set
-    and this function is not reached."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    log("[bench] --gpus %d without a launcher: starting %s" % (a.gpus, " ".join(cmd[1:10])))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    line = None
-    for ln in r.stdout.decode(errors="replace").splitlines():
-        if ln.startswith('{"metric"'):
-            line = ln
-        elif ln.strip():
-            log(ln)
-    if line is not None:
-        print(line, flush=True)
-    if r.returncode != 0:
-        return r.returncode
-    return 0 if line is not None else 3
 
 
 def run_exchange_c(a, shuf, n_dev, reason=None):
@@ -1025,7 +852,7 @@ def main():
             raise SystemExit("--exchange c --gpus %d: %d device(s) visible" % (a.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0))
         return run_exchange_c(a, K.Shuf.generate(10, 6, 3, seed=20260101), a.gpus)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(a)                             # nothing has touched the GPU yet
+        return self_launch(a, __file__)                             # nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
