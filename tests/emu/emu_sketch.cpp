@@ -142,3 +142,39 @@ extern "C" void emu_log_over_k(const double *x, double k, double *y, uint64_t n)
 {
     for (uint64_t i = 0; i < n; i++) y[i] = kssd_log_over_k(x[i], k);
 }
+
+// the exact table (kssd_build_tables: every key into one of its two buckets, at most one key moved to make room) against its own
+// lookup: every accepted sub-context found with its rank, sub-contexts that are not accepted not found; returns the number of
+// wrong answers over `sets` random sets, -1 if a table could not be built
+extern "C" long emu_check_exact_table(int k, int subk, int drlevel, uint32_t seed, int sets, int absent_per_set)
+{
+    KssdParams P0;
+    if (kssd_params_init(&P0, k, subk, drlevel) != 0) return -2;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 11); };
+    const uint32_t space = 1u << (4 * subk);
+    long bad = 0;
+    for (int t = 0; t < sets; t++) {
+        KssdParams P = P0;
+        std::vector<uint8_t> in(space, 0);
+        std::vector<uint32_t> acc;
+        while (acc.size() < P.dim_end) {
+            const uint32_t v = next() % space;
+            if (!in[v]) { in[v] = 1; acc.push_back(v); }
+        }
+        std::vector<uint8_t> T1;
+        std::vector<uint32_t> bloom;
+        std::vector<KssdG> G;
+        if (!kssd_build_tables(P, acc, KSSD_GW, T1, bloom, G)) return -1;
+        for (uint32_t r = 0; r < acc.size(); r++) {
+            uint32_t rank = ~0u;
+            if (!kssd_g_find(P, G.data(), acc[r], rank) || rank != r) bad++;
+        }
+        for (int i = 0; i < absent_per_set; i++) {
+            const uint32_t v = next() % space;
+            uint32_t rank;
+            if (!in[v] && kssd_g_find(P, G.data(), v, rank)) bad++;
+        }
+    }
+    return bad;
+}

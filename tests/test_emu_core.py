@@ -31,6 +31,8 @@ def emu():
                                                                   C.c_uint64, C.c_void_p, C.c_int]
     L.emu_log_over_k.restype = None
     L.emu_log_over_k.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_uint64]
+    L.emu_check_exact_table.restype = C.c_long
+    L.emu_check_exact_table.argtypes = [C.c_int] * 3 + [C.c_uint32, C.c_int, C.c_int]
     L.emu_sketch_where.restype = C.c_long
     L.emu_sketch_where.argtypes = [C.c_int] * 3 + [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     return L
@@ -170,3 +172,10 @@ def test_distance_epilogue_is_within_one_ulp_of_the_host_formula(emu):
         ulp = Decimal(math.ulp(o))
         worst = max(worst, float(abs(Decimal(float(o)) - exact) / ulp))
     assert worst < 1.35, worst  # like the host, whose two roundings stay within 0.52 * 1.6 + 0.5 ulp of the exact quotient
+
+
+def test_exact_table_placement_finds_every_key_and_nothing_else(emu):
+    """kssd_build_tables places every accepted sub-context in one of its two buckets (moving at most one key to make room) and
+    kssd_g_find reads them back: all ranks right, no sub-context outside the set found, for several parameter sets and many sets"""
+    for k, s, l in ((10, 6, 3), (8, 5, 2), (10, 7, 5), (8, 4, 1), (9, 5, 2)):
+        assert emu.emu_check_exact_table(k, s, l, 7 * k + s, 12, 20000) == 0, (k, s, l)
