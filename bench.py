@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import public_kssd_amd as K  # noqa: E402
 from benchlib.launch import host_cores, log, self_launch  # noqa: E402
-from benchlib.workloads import make_batch, make_long_records, make_reads_batch  # noqa: E402
+from benchlib.workloads import READ_LEN, make_batch, make_long_records, make_reads_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # (the synthetic workloads -- make_batch, make_reads_batch, make_long_records -- and the launcher plumbing live in benchlib/)
@@ -248,7 +248,6 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
 # reference sketches.  The reads are generated and packed on the device exactly as the host tokeniser lays a FASTQ
 # file out (kssd_batch_add_fastq: the reads of a file are ONE genome, one invalid position between two reads).
 # ------------------------------------------------------------------------------------------------------
-READ_LEN = 150
 
 
 

@@ -5,6 +5,8 @@ import torch
 
 import public_kssd_amd as K
 
+READ_LEN = 150  # configs[3]: reads of 150 bp
+
 
 def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0, on_genome=None, keep_on_device=False):
     """returns packed int32[words+slack], mask int32[...], chunk_off uint64[n+1], kept [(codes u8, nmask bool)]

@@ -48,3 +48,28 @@ def test_exchange_c_on_one_device_goes_through_rccl_and_holds_one_runtime():
     assert len(j["runtime"]["mapped"]["hip"]) == 1 and len(j["runtime"]["mapped"]["rccl"]) == 1
     assert os.path.dirname(j["runtime"]["rccl"]) == os.path.dirname(j["runtime"]["hip"])      # the RCCL next to the runtime in use
     assert j["matrix_checksum"] > 0 and j["value"] > 0
+
+
+def test_bench_modules_name_nothing_undefined():
+    """bench.py and benchlib/ are only executed in full on a GPU box: every global name a function of theirs loads is defined in its
+    module (an import, a definition, an assignment) -- what a split of the file can break without any CPU test noticing"""
+    import ast
+    import builtins
+    for f in ("bench.py", os.path.join("benchlib", "workloads.py"), os.path.join("benchlib", "launch.py")):
+        tree = ast.parse(open(os.path.join(ROOT, f)).read())
+        defined = set(dir(builtins)) | {"__file__", "__name__"}
+        for n in ast.walk(tree):
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                defined.add(n.name)
+            elif isinstance(n, ast.Import):
+                defined.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, ast.ImportFrom):
+                defined.update(a.asname or a.name for a in n.names)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                defined.add(n.id)
+            elif isinstance(n, ast.arg):
+                defined.add(n.arg)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                defined.add(n.name)
+        used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+        assert not (used - defined), (f, sorted(used - defined))
