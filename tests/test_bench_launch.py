@@ -50,6 +50,22 @@ def test_exchange_c_on_one_device_goes_through_rccl_and_holds_one_runtime():
     assert j["matrix_checksum"] > 0 and j["value"] > 0
 
 
+@pytest.mark.gpu
+def test_two_ranks_share_one_device_over_gloo():
+    """bench.py --gpus 2 on a one-GPU box: both ranks on cuda:0 (KSSD_BENCH_ONE_DEVICE), the exchange over gloo -- the whole N > 1 flow of
+    the line (self-launch, process group, both partitions, max over ranks) except the transport"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KSSD_BENCH_ONE_DEVICE="1", KSSD_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--spinup", "0",
+                        "--genomes", "60", "--length", "400000", "--clades", "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    j = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["parallelism"]["ranks"] == 2 and j["config"]["parallelism"]["backend"] == "gloo"
+    assert j["kernels"]["launches_timed"][0] >= 1
+
+
 def test_bench_modules_name_nothing_undefined():
     """bench.py and benchlib/ are only executed in full on a GPU box: every global name a function of theirs loads is defined in its
     module (an import, a definition, an assignment) -- what a split of the file can break without any CPU test noticing"""
