@@ -347,6 +347,19 @@ int kssd_gpu_dist_device_long(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const u
                               uint32_t q_begin, uint32_t q_end, uint64_t max_row_ids, uint32_t *d_shared,
                               double *d_jaccard, double *d_mashd, double *d_contain, double *d_aafd, void *stream);
 
+/*
+ * The same rows with the block written TRANSPOSED: for an all-pairs run over several devices in which a device indexes only
+ * the sketches it made and runs everybody's sketches as query rows.  What that device owns of the matrix
+ * are the rows of its OWN genomes (one owner per output row, command_dist.c:774-785) -- the transpose of what the rows kernel
+ * counts, and every metric of the path is symmetric in (X, Y).  d_work: DEVICE u32[(q_end - q_begin) x n_ref] scratch (the
+ * counts row-major by query); the five outputs receive, for indexed sketch r and query q, element r * out_pitch + (q - q_begin)
+ * (out_pitch >= q_end - q_begin, in elements; planes may be NULL).  The bits of a pair are those kssd_gpu_dist_device writes.
+ */
+int kssd_gpu_dist_device_transposed(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32_t *d_qids, uint32_t n_qry,
+                                    uint32_t q_begin, uint32_t q_end, uint32_t *d_work, uint64_t out_pitch,
+                                    uint32_t *d_shared_t, double *d_jaccard_t, double *d_mashd_t, double *d_contain_t,
+                                    double *d_aafd_t, void *stream);
+
 /* host-level convenience: HOST CSR in, HOST matrices out (caller-allocated, Q x R; planes may be NULL) */
 int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref,
                   const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,
@@ -417,12 +430,21 @@ int kssd_gpu_allgather_sketches(kssd_gpu_ctx *const *ctxs, int n, const uint64_t
  *   kssd_gpu_resident_allpairs  all-pairs among the genomes of `sets` (global numbering: set 0's slots, then set 1's, ...;
  *                               every set but the last holds the same number of slots -- kssd_shard_plan of the host
  *                               library deals the inputs out that way): ONE RCCL all-gather of every device's packed
- *                               sketches (kssd_gpu_allgather_sketches; one device: its unit is unpacked in place, or -- with
- *                               KSSD_EXCHANGE_ONE_RANK=1 in the environment -- sent through a one-rank communicator), the full index
- *                               on every device, every device's own genomes as its block of query rows, written into the
- *                               caller's HOST matrices (N x N row-major; `shared` may be a mapped sharedk_ct.dat, the f64
- *                               planes may be NULL).  One host thread per device.  KSSD_ERR_PARAM when a device is named
- *                               twice (RCCL: one rank per device) or a slot was never put.
+ *                               sketches (one device: its unit is unpacked in place, or -- with KSSD_EXCHANGE_ONE_RANK=1 in
+ *                               the environment -- sent through a one-rank communicator); then every device indexes the
+ *                               sketches IT made, runs everybody's as query rows and writes the transpose -- the rows of its
+ *                               own genomes (kssd_gpu_dist_device_transposed: queries = references, every metric symmetric;
+ *                               the index build stays constant per device).  KSSD_ALLPAIRS_FULL_INDEX=1: the full index on
+ *                               every device and its own genomes as query rows instead (also taken when a sketch is a
+ *                               read set of more than 16 384 ids).  Results into the caller's HOST matrices (N x N
+ *                               row-major; `shared` may be a mapped sharedk_ct.dat, the f64 planes may be NULL).  One host
+ *                               thread per device: it unpacks, indexes and computes behind the device's share of the
+ *                               collective on the device's stream.  KSSD_ERR_PARAM when a device is named twice (RCCL: one
+ *                               rank per device) or a slot was never put.  No kssd_gpu_resident_put* may be running on any
+ *                               of the sets (join the workers first).  KSSD_EXCHANGE_FAKE_RANKS=n: development -- the sets
+ *                               may share a device and the collective is replaced by device-to-device copies of the bytes
+ *                               it delivers, everything else runs as on n devices.  KSSD_TIMING: one JSON line on stderr
+ *                               (pack, communicator set-up, exchange, unpack + index + rows).
  */
 typedef struct kssd_gpu_resident kssd_gpu_resident;
 int kssd_gpu_resident_create(kssd_gpu_resident **out, int device, uint32_t n_slots);

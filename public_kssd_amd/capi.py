@@ -48,6 +48,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_index_status", "kssd_gpu_index_set_exact",
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
+    "kssd_gpu_dist_device_transposed",
 ]
 
 
@@ -183,6 +184,7 @@ def gpu_lib():
         L.kssd_gpu_index_set_exact.argtypes = [vp, i32]
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
+        L.kssd_gpu_dist_device_transposed.argtypes = [vp, vp, vp, u32, u32, u32, vp, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
@@ -815,8 +817,15 @@ class GpuCtx:
         rc = gpu_lib().kssd_gpu_sketch_status(self.h, C.byref(tot), C.byref(bad), stream)
         return rc, tot.value, bad.value
 
-    def index_build_device(self, d_roff, d_rids, n_ref, max_ref_ids, stream=None):
+    def index_build_device(self, d_roff, d_rids, n_ref, max_ref_ids, stream=None, check=True):
+        """check (the default): the build's status is read back (this synchronises the stream) and a capped build that overflowed --
+        ids that do not spread over the buckets: a database of near-identical genomes -- is repeated with exact counts, so that the
+        index in place is whole when the call returns.  check=False: nothing is synchronised (a timed loop); the caller then polls
+        index_status() itself -- the rows of an index that is not whole come back as 0xFFFFFFFF counts, never as stale data."""
         _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
+        if check and self.index_status(stream) == ERR_OVERFLOW:
+            _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
+            _gck(self.index_status(stream))
 
     def index_status(self, stream=None):
         """synchronises the stream; 0, or ERR_OVERFLOW when the (capped) build in place met a bucket fuller than its run: build again"""
@@ -834,6 +843,13 @@ class GpuCtx:
             return
         _gck(gpu_lib().kssd_gpu_dist_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_shared),
                                             _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
+
+    def dist_device_transposed(self, d_qoff, d_qids, n_qry, q_begin, q_end, d_work, out_pitch, d_shared_t, d_j=None, d_m=None, d_c=None,
+                               d_a=None, stream=None):
+        """rows [q_begin, q_end) against the index, the block written transposed: element (indexed sketch r, query q) at
+        r * out_pitch + (q - q_begin) of every output; d_work: u32[(q_end - q_begin) x n_ref] scratch"""
+        _gck(gpu_lib().kssd_gpu_dist_device_transposed(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_work), out_pitch,
+                                                       _ptr(d_shared_t), _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
 
     def set_union(self, ids, uniq=False):
         """ascending distinct ids (uniq: the ids that occur exactly once) -- kssd set -u / -q"""

@@ -182,6 +182,7 @@ struct kssd_gpu_ctx {
     unsigned long long *d_hdr_pre = nullptr, *d_hdr_out = nullptr;
     size_t cap_hdr_cnt = 0, cap_hdr_pre = 0, cap_hdr_out = 0;
     bool resident_valid = false;  // the last sketch call was a host-level one: its batch is in d_in_packed / d_in_mask (kssd_gpu_sketch_again)
+    bool results_valid = false;   // ... and it succeeded: d_b_off / d_b_ids hold ITS sketches (kssd_gpu_resident_put copies them)
     uint32_t ranges_off_calls = 0;  // successful calls the switch below still lasts for
     bool ranges_off = false; // a batch of this context has shown keys that do not spread over id ranges: large genomes take the global-memory sort
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
@@ -1246,6 +1247,7 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
     hipStream_t s = c->own_stream;
     const uint64_t n_chunks = chunk_off[n_genomes];
     int rc;
+    c->results_valid = false;  // (a call that fails leaves nothing a later kssd_gpu_resident_put may copy)
     if ((rc = ensure(&c->d_b_off, &c->cap_b_off, (size_t)n_genomes + 1)) != KSSD_OK) return rc;
     if (out_pos && !(flags & (KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS))) flags |= KSSD_SKETCH_FIRST_POS;
     if (!out_pos) flags &= ~(KSSD_SKETCH_FIRST_POS | KSSD_SKETCH_COUNTS | KSSD_SKETCH_BY_POS);
@@ -1289,6 +1291,7 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
     *out_ids = h_ids;
     if (out_pos) *out_pos = h_pos;
     c->resident_valid = true;
+    c->results_valid = true;
     return KSSD_OK;
 }
 

@@ -212,6 +212,7 @@ typedef struct {
     int nargs;
     char **args;
     int device, gpus; /* first device, number of devices (--gpus / KSSD_GPUS) */
+    int fake_ranks;   /* KSSD_EXCHANGE_FAKE_RANKS: the entries of devs[] are ranks that share one device (development) */
     int allpairs;     /* --allpairs: stage I, then all-pairs among the inputs in the same run, sketches resident on the devices */
     int devs[64], n_devs; /* the device list: device .. device + gpus - 1, or KSSD_DEVICE_LIST=a,b,c */
     unsigned long long seed;
@@ -932,7 +933,9 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     uint32_t first[65] = {0};
     if (o->allpairs) {
         if (abundance) die(ENOTSUP, "--allpairs with -A: abundance sketches are not searched (mco_cbdco_nobin_dist reads plain sketches)");
-        if (kssd_shard_plan(o->devs, n_dev, (uint32_t)fl->n, first))
+        int ranks[64];
+        for (int i = 0; i < n_dev; i++) ranks[i] = o->fake_ranks ? i : o->devs[i]; /* (KSSD_EXCHANGE_FAKE_RANKS: the ranks share a device on purpose) */
+        if (kssd_shard_plan(ranks, n_dev, (uint32_t)fl->n, first))
             die(EINVAL, "--allpairs: the device list names a device twice (or none): one rank per device");
     }
     pthread_t warm;
@@ -956,7 +959,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     }
     pthread_t xwarm;
     xwarm_arg xa = {o->devs, n_dev};
-    const int xwarming = o->allpairs && (n_dev > 1 || getenv("KSSD_EXCHANGE_ONE_RANK")) && pthread_create(&xwarm, NULL, warm_exchange, &xa) == 0;
+    const int xwarming = o->allpairs && !o->fake_ranks && (n_dev > 1 || getenv("KSSD_EXCHANGE_ONE_RANK")) && pthread_create(&xwarm, NULL, warm_exchange, &xa) == 0;
     /* sketch workers per device (each with its own context and stream) and text buffers beyond one per worker: tuning knobs of the
      * pipeline, measured in profiles/r04I_e2e_workers_buffers.txt */
     int wpd = 2, extra_bufs = 1;
@@ -1503,19 +1506,44 @@ static int cmd_dist(int argc, char **argv)
     for (int i = 0; i < o.gpus; i++) o.devs[i] = o.device + i;
     if (getenv("KSSD_DEVICE_LIST")) { /* an explicit list, e.g. 2,3,6 (development: 0,0 must be refused by --allpairs) */
         o.n_devs = 0;
-        for (const char *p = getenv("KSSD_DEVICE_LIST"); *p && o.n_devs < 64;) {
-            o.devs[o.n_devs++] = atoi(p);
-            p += strcspn(p, ",");
-            if (*p == ',') p++;
+        for (const char *p = getenv("KSSD_DEVICE_LIST"); *p;) { /* whole non-negative numbers between commas, at most 64 */
+            char *end = NULL;
+            errno = 0;
+            const long v = strtol(p, &end, 10);
+            if (end == p || errno || v < 0 || v > 1 << 20 || (*end && *end != ',')) die(EINVAL, "KSSD_DEVICE_LIST: '%s' is not a list of device numbers", getenv("KSSD_DEVICE_LIST"));
+            if (o.n_devs >= 64) die(EINVAL, "KSSD_DEVICE_LIST: more than 64 devices");
+            o.devs[o.n_devs++] = (int)v;
+            p = *end == ',' ? end + 1 : end;
+            if (*end == ',' && !*p) die(EINVAL, "KSSD_DEVICE_LIST: '%s' ends in a comma", getenv("KSSD_DEVICE_LIST"));
         }
         if (o.n_devs < 1) die(EINVAL, "KSSD_DEVICE_LIST: no device");
         o.gpus = o.n_devs;
         o.device = o.devs[0];
     }
+    if (o.allpairs && getenv("KSSD_EXCHANGE_FAKE_RANKS")) {
+        /* development: n "ranks" on the FIRST device of the list -- the whole N-rank orchestration of --allpairs (plan, residents, one
+         * host thread per rank, unit padding, the ranks' rows into one mapping) with the collective replaced by device-to-device
+         * copies (kssd_gpu_resident_allpairs): what a one-GPU box can execute of --gpus n */
+        const long n = strtol(getenv("KSSD_EXCHANGE_FAKE_RANKS"), NULL, 10);
+        if (n < 1 || n > 64) die(EINVAL, "KSSD_EXCHANGE_FAKE_RANKS: between 1 and 64 ranks");
+        o.n_devs = o.gpus = (int)n;
+        for (int i = 0; i < o.n_devs; i++) o.devs[i] = o.device;
+        o.fake_ranks = 1;
+    }
     if (o.allpairs && (o.byread || o.pipecmd[0])) die(ENOTSUP, "--allpairs with --byread / --pipecmd");
-    if (o.p == 0) o.p = default_threads();
     o.nargs = argc - optind;
     o.args = argv + optind;
+    if (o.allpairs) {
+        /* --allpairs is stage I + the search in one run: it needs raw sequences as its inputs and no -r (dist_dispatch,
+         * command_dist.c:159-189, is the branch it extends).  Said here, before anything is sketched or overwritten. */
+        if (o.refpath[0]) die(EINVAL, "--allpairs: all-pairs among the inputs of this run; -r <reference> names another search (sketch first, then kssd dist -r)");
+        if (o.nargs > 0 && !o.pipecmd[0] && kssd_probe_dir(o.args[0])) die(EINVAL, "--allpairs: %s holds sketches; all-pairs among sketches is kssd dist -r %s -o <out> %s", o.args[0], o.args[0], o.args[0]);
+        if (o.nargs < 1 && !o.fpath[0]) die(EINVAL, "--allpairs: no input sequences");
+        char skf[KSSD_PATHLEN + 32];
+        snprintf(skf, sizeof skf, "%s/sharedk_ct.dat", o.outdir);
+        if (access(skf, F_OK) == 0) die(EEXIST, " mco_cbdco_nobin_dist():%s", skf); /* the reference refuses to overwrite (command_dist.c:707-748): before stage I runs */
+    }
+    if (o.p == 0) o.p = default_threads();
 
     /* dist_dispatch (command_dist.c:53-192) */
     if (o.refpath[0]) {

@@ -8,10 +8,13 @@ command_dist.c:774-785):
   "query"      the north_star partition, valid for any query set: every rank gathers ALL reference sketches, builds
                the full index, and computes the rows of ITS OWN query block against all references.  Rank r writes
                rows [r*Q, (r+1)*Q) x all columns.  Per-rank cost at N ranks: index over N x the ids, Q probes rows.
-  "transpose"  all-pairs only (queries = references, every metric of the path is symmetric): every rank indexes
-               only ITS OWN sketches and uses all gathered sketches as query rows; the [all] x [own] block it writes
-               is the transpose of its query block.  The index build, the part "query" repeats on every rank, stays
-               constant per rank; the price is N x the probes, most of which miss.
+  "own"        all-pairs only (queries = references, every metric of the path is symmetric): every rank indexes
+               only ITS OWN sketches, runs all gathered sketches as query rows and writes the block TRANSPOSED
+               (kssd_gpu_dist_device_transposed: counts row-major by query, then a tiled transpose that computes the
+               metrics) -- so what it leaves is what "query" leaves: rows [r*G, (r+1)*G) x all columns, row-major,
+               one owner per output row.  The index build, the part "query" repeats on every rank, stays constant
+               per rank; the price is N x the probes, most of which miss (a negative filter in front of the table).
+               ("transpose" is the name rounds 2-4 used for it, when the block was left as [all] x [own].)
 
 Everything is static-shape tensor code on the caller's device: no size ever visits the host, so a step stays free
 of host synchronisation.  The compute calls go through an `engine` with the two device-level entry points of the
@@ -79,41 +82,53 @@ class ShardedSearch:
         rows, cols, transposed = s.block(Q)     # where `shared` sits in the global matrix
 
     `shared` (and each plane) is a flat tensor the caller preallocates with s.cells(Q) elements.
+    gather: the exchange; the default is SketchGather (torch.distributed).  bench.py --emulate-world plugs in one that
+    delivers the other ranks' units by device-to-device copies.
+    check_index: read the index build's status back and repeat an overflowed build (synchronises; GpuCtx's default).
+    A timed loop sets it False and polls engine.index_status() itself.
     """
 
-    def __init__(self, world, rank, G, cap, device, engine, partition="query"):
-        if partition not in ("query", "transpose"):
-            raise ValueError("partition must be 'query' or 'transpose'")
+    def __init__(self, world, rank, G, cap, device, engine, partition="query", gather=None, check_index=True):
+        if partition == "transpose":
+            partition = "own"
+        if partition not in ("query", "own"):
+            raise ValueError("partition must be 'query' or 'own'")
         self.world, self.rank, self.G, self.cap = world, rank, G, cap
-        self.engine, self.partition = engine, partition
-        self.gather = SketchGather(world, G, cap, device, engine) if world > 1 else None
-        self._filter = world > 1 and partition == "transpose" and hasattr(engine, "index_set_filter")
+        self.engine, self.partition, self.check_index = engine, partition, check_index
+        self.gather = gather if gather is not None else (SketchGather(world, G, cap, device, engine) if world > 1 else None)
+        self._filter = world > 1 and partition == "own" and hasattr(engine, "index_set_filter")
         if self._filter:
             # (world - 1) / world of the query rows are other ranks' sketches and share next to nothing with the own index:
             # a negative filter in front of the table for them, the own block of rows exempt
             engine.index_set_filter(True, rank * G, (rank + 1) * G)
-        # "transpose" on GPUs: the exchange runs on a stream of its own, under the index build and the rank's OWN block of
+        # "own" on GPUs: the exchange runs on a stream of its own, under the index build and the rank's OWN block of
         # rows -- neither needs anybody else's sketches; only the foreign rows wait for it
-        self._overlap = world > 1 and partition == "transpose" and torch.device(device).type == "cuda"
+        self._overlap = world > 1 and partition == "own" and torch.device(device).type == "cuda"
         if self._overlap:
             self._cstream = torch.cuda.Stream(device=device)
             self._ev_ready, self._ev_gathered = torch.cuda.Event(), torch.cuda.Event()
+        # the counts of the rows in flight, row-major by query, before they are turned around (own-index partition)
+        self._work = torch.zeros(world * G * G, dtype=torch.int32, device=device) if partition == "own" and world > 1 else None
 
     def cells(self, Q=None):
         Q = self.G if Q is None else Q
-        return Q * self.G * self.world if self.partition == "query" else self.G * self.world * self.G
+        return Q * self.G * self.world
 
     def block(self, Q=None):
-        """(row range, column range, transposed) of this rank's output in the global [world*Q] x [world*G] matrix.
-        transposed: `shared` holds the block as [columns-of-the-block-as-rows]: shared.view(world*G, G) is the
-        transpose of rows [rank*G, (rank+1)*G) (all-pairs, symmetric)."""
+        """(row range, column range, transposed) of this rank's output in the global [world*Q] x [world*G] matrix: in either
+        partition the rows of the rank's own block, row-major (transposed is always False since round 5: the own-index
+        partition turns its block around on the device)"""
         Q = self.G if Q is None else Q
-        if self.partition == "query":
-            return (self.rank * Q, (self.rank + 1) * Q), (0, self.world * self.G), False
-        return (self.rank * self.G, (self.rank + 1) * self.G), (0, self.world * self.G), True
+        return (self.rank * Q, (self.rank + 1) * Q), (0, self.world * self.G), False
+
+    def _build(self, roff, rids, n_ref, max_ids, stream):
+        if self.check_index:
+            self.engine.index_build_device(roff, rids, n_ref, max_ids, stream)
+        else:
+            self.engine.index_build_device(roff, rids, n_ref, max_ids, stream, check=False)
 
     def index(self, off_l, ids_l, max_ids, stream=None, tstream=None, group=None):
-        """the exchange (N > 1) and the index build of one step; nothing is synchronised.
+        """the exchange (N > 1) and the index build of one step; nothing is synchronised unless check_index is set.
         max_ids: upper bound of the ids one rank holds (sizes the index).  tstream: the torch stream object that
         wraps `stream` (the collective is issued under it)."""
         w, G = self.world, self.G
@@ -131,7 +146,7 @@ class ShardedSearch:
                 self._ev_gathered.record(self._cstream)
             self._gathered = (roff, rids)
             self._cur = cur
-            self.engine.index_build_device(off_l, ids_l, G, max_ids, stream)
+            self._build(off_l, ids_l, G, max_ids, stream)
             return roff, rids
         if w == 1:
             roff, rids = off_l, ids_l
@@ -142,43 +157,47 @@ class ShardedSearch:
             roff, rids = self.gather(off_l, ids_l, group=group, stream=stream)
         self._gathered = (roff, rids)
         if self.partition == "query":   # full index on every rank
-            self.engine.index_build_device(roff, rids, w * G, max_ids * w, stream)
+            self._build(roff, rids, w * G, max_ids * w, stream)
         else:                           # own index only
-            self.engine.index_build_device(off_l, ids_l, G, max_ids, stream)
+            self._build(off_l, ids_l, G, max_ids, stream)
         return roff, rids
 
     def rows(self, off_l, ids_l, shared, planes, q=None, stream=None):
         """the rank's block of the matrix against the index of the last index() call"""
-        w, G = self.world, self.G
+        w, G, r = self.world, self.G, self.rank
         if q is not None and self.partition != "query":
-            raise ValueError("a separate query set needs the 'query' partition (the transpose trick is all-pairs only)")
+            raise ValueError("a separate query set needs the 'query' partition (the own-index trick is all-pairs only)")
         pl = list(planes) if planes is not None else [None] * 4
-        if self.partition == "query":   # own query block as rows
+        if self.partition == "query" or w == 1:   # own query block as rows (one rank: the two partitions are the same calls)
             qoff, qids, Q = (off_l, ids_l, G) if q is None else q
             self.engine.dist_device(qoff, qids, Q, 0, Q, shared, *pl, stream=stream)
-        elif self._overlap:             # own rows from the own sketches first, the foreign rows once the exchange is in
-            r, blk = self.rank, G * G
-            cut = lambda t, a, b: None if t is None else t[a * blk:b * blk]
+            return
+        # everybody's sketches as query rows against the OWN index; query g of the global numbering is column g of the rank's
+        # G rows (pitch w * G): the block leaves the device as the rows of the rank's own genomes
+        pitch = w * G
+        at = lambda t, col: None if t is None else t[col:]
+        tr = lambda qoff, qids, n, a, b, col: self.engine.dist_device_transposed(
+            qoff, qids, n, a, b, self._work, pitch, at(shared, col), *[at(t, col) for t in pl], stream=stream)
+        if self._overlap:               # own rows from the own sketches first, the foreign rows once the exchange is in
             if self._filter:
                 self.engine.index_set_filter(True, 0, G)                     # (the own block: rows 0 .. G of this call)
-            self.engine.dist_device(off_l, ids_l, G, 0, G, cut(shared, r, r + 1), *[cut(t, r, r + 1) for t in pl], stream=stream)
+            tr(off_l, ids_l, G, 0, G, r * G)
             if self._filter:
                 self.engine.index_set_filter(True, r * G, (r + 1) * G)
             self._cur.wait_event(self._ev_gathered)
             roff, rids = self._gathered
             if r > 0:
-                self.engine.dist_device(roff, rids, w * G, 0, r * G, cut(shared, 0, r), *[cut(t, 0, r) for t in pl], stream=stream)
+                tr(roff, rids, w * G, 0, r * G, 0)
             if r + 1 < w:
-                self.engine.dist_device(roff, rids, w * G, (r + 1) * G, w * G, cut(shared, r + 1, w), *[cut(t, r + 1, w) for t in pl],
-                                        stream=stream)
-        else:                           # everybody's sketches as rows: the [w*G] x [G] block = transpose of the own query block
+                tr(roff, rids, w * G, (r + 1) * G, w * G, (r + 1) * G)
+        else:
             roff, rids = self._gathered
-            self.engine.dist_device(roff, rids, w * G, 0, w * G, shared, *pl, stream=stream)
+            tr(roff, rids, w * G, 0, w * G, 0)
 
     def step(self, off_l, ids_l, shared, planes, max_ids, q=None, stream=None, tstream=None, group=None):
         """index() + rows(): the exchange, the index build and the rows of one step; nothing is synchronised"""
         if q is not None and self.partition != "query":
-            raise ValueError("a separate query set needs the 'query' partition (the transpose trick is all-pairs only)")
+            raise ValueError("a separate query set needs the 'query' partition (the own-index trick is all-pairs only)")
         out = self.index(off_l, ids_l, max_ids, stream=stream, tstream=tstream, group=group)
         self.rows(off_l, ids_l, shared, planes, q=q, stream=stream)
         return out

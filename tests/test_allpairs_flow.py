@@ -64,6 +64,35 @@ def test_command_refuses_a_device_list_with_a_repeat_before_it_touches_a_gpu(tmp
     assert r.returncode != 0 and b"--allpairs with --byread" in r.stdout
 
 
+def test_command_says_what_allpairs_cannot_do_before_it_sketches_anything(tmp_path):
+    """--allpairs extends the stage I branch of dist_dispatch (command_dist.c:159-189): with -r, with a sketch directory as its
+    input, or onto an existing sharedk_ct.dat (the reference refuses to overwrite it, :707-748) the command stops with the reason
+    before stage I has run or a file of the output directory has been rewritten; a device list that is not a list of numbers is
+    refused in every mode"""
+    d = str(tmp_path)
+    K.Shuf.generate(10, 6, 3, seed=3).write(os.path.join(d, "s.shuf"))
+    fa = os.path.join(G, "ref_fa")
+    run = lambda args, env=None: subprocess.run([BIN] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120,
+                                                env=dict(os.environ, **(env or {})))
+    r = run(["dist", "-L", "s.shuf", "-o", "out", "--allpairs", "-r", fa, fa])
+    assert r.returncode == 22 and b"--allpairs: all-pairs among the inputs of this run" in r.stdout, r.stdout.decode()
+    os.makedirs(os.path.join(d, "sk"))
+    open(os.path.join(d, "sk", "cofiles.stat"), "wb").write(b"\0" * 32)                           # what dist_dispatch probes for (command_dist.c:62-63)
+    r = run(["dist", "-L", "s.shuf", "-o", "out", "--allpairs", "sk"])
+    assert r.returncode == 22 and b"holds sketches" in r.stdout, r.stdout.decode()
+    os.makedirs(os.path.join(d, "full"))
+    open(os.path.join(d, "full", "sharedk_ct.dat"), "wb").write(b"1234")
+    r = run(["dist", "-L", "s.shuf", "-o", "full", "--allpairs", fa])
+    assert r.returncode == 17 and b"mco_cbdco_nobin_dist()" in r.stdout, r.stdout.decode()        # EEXIST, before stage I
+    assert os.listdir(os.path.join(d, "full")) == ["sharedk_ct.dat"]
+    r = run(["dist", "-L", "s.shuf", "-o", "out", "--allpairs"])
+    assert r.returncode == 22 and b"no input sequences" in r.stdout
+    for bad in ("0,a", "-1", "0,,1", "1,", "x", ",".join(str(i) for i in range(65))):
+        r = run(["dist", "-L", "s.shuf", "-o", "out", fa], env={"KSSD_DEVICE_LIST": bad})
+        assert r.returncode == 22 and b"KSSD_DEVICE_LIST" in r.stdout, (bad, r.stdout.decode())
+    assert not os.path.exists(os.path.join(d, "out", "cofiles.stat"))
+
+
 def _run(args, cwd, env=None):
     r = subprocess.run([BIN] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
                        env=dict(os.environ, **env) if env else None)
@@ -176,3 +205,85 @@ def test_resident_sets_through_the_c_abi(shuf_l3k10):
         L.kssd_gpu_resident_destroy(r)
         a.close()
         b.close()
+
+
+@pytest.mark.gpu
+def test_n_rank_orchestration_on_one_device_leaves_the_one_device_files(tmp_path):
+    """KSSD_EXCHANGE_FAKE_RANKS=n: `kssd dist --allpairs` plans, sketches, keeps, exchanges and searches as n ranks -- every rank's
+    buffers on device 0, the collective replaced by device-to-device copies of the bytes an all-gather delivers -- and must leave
+    byte for byte what --gpus 1 leaves: unit padding, a short and an EMPTY last set, the global numbering base[d] * N, one host
+    thread per rank writing its rows into one mapping, in both partitions of the matrix (own index + transposed write, the
+    default; the full index, KSSD_ALLPAIRS_FULL_INDEX=1)"""
+    import json
+    from synth import clade_genomes, fasta_text
+    meta = json.load(open(os.path.join(G, "golden.json")))
+    d = str(tmp_path)
+    K.Shuf.generate(10, 6, 3, seed=meta["seed"]).write(os.path.join(d, "L3K10.shuf"))
+    fa = os.path.join(d, "fa")
+    os.makedirs(fa)
+    for i, (nm, codes, m) in enumerate(clade_genomes(3, 4, 150_000, seed=23)[:11]):          # 11 genomes: 4 ranks hold 3, 3, 3, 2
+        open(os.path.join(fa, "g%02d.fasta" % i), "w").write(fasta_text(codes, nm, n_mask=m))
+    open(os.path.join(fa, "g11_empty.fasta"), "w").write(">nothing\nACGTNNNN\n")                 # a sketch without ids among them
+    _run(["dist", "-L", "L3K10.shuf", "-o", "one", "--allpairs", "--keepskf", fa], d)
+    want_sk = open(os.path.join(d, "one", "sharedk_ct.dat"), "rb").read()
+    want_txt = open(os.path.join(d, "one", "distance.out"), "rb").read()
+    assert len(want_sk) == 12 * 12 * 4
+    for n, full in ((2, False), (4, False), (5, False), (7, False), (13, False), (4, True), (5, True)):  # 13 ranks: more ranks than genomes
+        out = "r%d%s" % (n, "f" if full else "")
+        env = {"KSSD_EXCHANGE_FAKE_RANKS": str(n), "KSSD_TIMING": "1"}
+        if full:
+            env["KSSD_ALLPAIRS_FULL_INDEX"] = "1"
+        o, err = _run(["dist", "-L", "L3K10.shuf", "-o", out, "--allpairs", "--keepskf", fa], d, env=env)
+        line = [json.loads(l) for l in err.splitlines() if '"resident_allpairs"' in l][0]
+        assert line["ranks"] == n and "device-to-device" in line["exchange"], line
+        assert ("full index" in line["partition"]) == full, line
+        assert open(os.path.join(d, out, "sharedk_ct.dat"), "rb").read() == want_sk, (n, full)
+        assert open(os.path.join(d, out, "distance.out"), "rb").read() == want_txt, (n, full)
+        for f in ("combco.0", "combco.index.0", "cofiles.stat"):
+            assert open(os.path.join(d, out, f), "rb").read() == open(os.path.join(d, "one", f), "rb").read(), (n, f)
+
+
+@pytest.mark.gpu
+def test_resident_sets_as_several_ranks_through_the_c_abi(shuf_l3k10):
+    """kssd_gpu_resident_allpairs over three sets (5 + 5 + 2 genomes, KSSD_EXCHANGE_FAKE_RANKS: all on device 0) with all four
+    planes: the matrix and every plane's bits equal kssd_gpu_dist on the same CSR -- the transposing metrics kernel computes a
+    pair exactly as the rows kernel's epilogue does"""
+    from synth import clade_genomes, fasta_text
+    L = K.gpu_lib()
+    vp = C.c_void_p
+    L.kssd_gpu_resident_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32]
+    L.kssd_gpu_resident_destroy.argtypes = [vp]
+    L.kssd_gpu_resident_destroy.restype = None
+    L.kssd_gpu_resident_put.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.kssd_gpu_resident_allpairs.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    texts = [fasta_text(c, nm, n_mask=m) for nm, c, m in clade_genomes(3, 4, 120_000, seed=12)]     # 12 genomes
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    sets = []
+    os.environ["KSSD_EXCHANGE_FAKE_RANKS"] = "3"
+    try:
+        offs, idl = [np.zeros(1, np.uint64)], []
+        for first, n in ((0, 5), (5, 5), (10, 2)):
+            r = vp()
+            assert L.kssd_gpu_resident_create(C.byref(r), 0, n) == 0
+            sets.append(r)
+            off, ids = ctx.sketch_fasta_texts(texts[first:first + n])
+            assert L.kssd_gpu_resident_put(r, ctx.h, 0, n) == 0
+            offs.append(off[1:] + offs[-1][-1])
+            idl.append(ids)
+        off_all, ids_all = np.concatenate(offs).astype(np.uint64), np.concatenate(idl)
+        want = ctx.dist(off_all, ids_all, off_all, ids_all)
+        for full in (False, True):
+            if full:
+                os.environ["KSSD_ALLPAIRS_FULL_INDEX"] = "1"
+            shared = np.full((12, 12), 77, np.uint32)
+            planes = [np.full((12, 12), 7.0, np.float64) for _ in range(4)]
+            assert L.kssd_gpu_resident_allpairs((vp * 3)(*sets), 3, 20, shared.ctypes.data, *[p.ctypes.data for p in planes]) == 0
+            assert np.array_equal(shared, want[0]) and np.array_equal(shared, shared.T)
+            for p, w in zip(planes, want[1:]):
+                assert np.array_equal(p.view(np.int64), np.asarray(w).view(np.int64)), full
+    finally:
+        os.environ.pop("KSSD_EXCHANGE_FAKE_RANKS", None)
+        os.environ.pop("KSSD_ALLPAIRS_FULL_INDEX", None)
+        for r in sets:
+            L.kssd_gpu_resident_destroy(r)
+        ctx.close()

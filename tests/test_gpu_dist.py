@@ -278,14 +278,21 @@ def test_index_overflow_is_reported_and_the_exact_build_takes_over(shuf_l3k10):
     ctx = K.GpuCtx(shuf_l3k10, 0)
     try:
         d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
-        ctx.index_build_device(d[0], d[1], R, len(rids))
-        assert ctx.index_status() == K.capi.ERR_OVERFLOW          # 6 000 entries in one bucket of four, whose run holds 4 095
-        shared = torch.full((3 * R,), -1, dtype=torch.int32, device=dev)
-        ctx.dist_device(d[2], d[3], 3, 0, 3, shared)              # nothing is computed on an index that is not whole
+        ctx.index_build_device(d[0], d[1], R, len(rids), check=False)   # (the unchecked call of a timed loop)
+        shared = torch.full((3 * R,), 7, dtype=torch.int32, device=dev)
+        ctx.dist_device(d[2], d[3], 3, 0, 3, shared)              # nothing is computed on an index that is not whole ...
         torch.cuda.synchronize()
-        assert int((shared == -1).sum().item()) == 3 * R
-        ctx.index_build_device(d[0], d[1], R, len(rids))          # the context counts first from now on
+        assert int((shared == -1).sum().item()) == 3 * R          # ... and the stale 7s do not pass for an answer: every count is 0xFFFFFFFF
+        assert ctx.index_status() == K.capi.ERR_OVERFLOW          # 6 000 entries in one bucket of four, whose run holds 4 095
+        ctx.index_build_device(d[0], d[1], R, len(rids), check=False)   # the context counts first from now on
         assert ctx.index_status() == 0
+        ctx.dist_device(d[2], d[3], 3, 0, 3, shared)
+        torch.cuda.synchronize()
+        assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(3, R), want)
+        ctx.index_set_exact(False)
+        ctx.index_build_device(d[0], d[1], R, len(rids))          # the binding's default: the status is read and the build repeated
+        assert ctx.index_status() == 0
+        shared.fill_(7)
         ctx.dist_device(d[2], d[3], 3, 0, 3, shared)
         torch.cuda.synchronize()
         assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(3, R), want)
@@ -497,3 +504,53 @@ def test_sketch_gather_over_the_rccl_backend_with_one_rank(shuf_l3k10):
     finally:
         ctx.close()
         dist.destroy_process_group()
+
+
+def test_rows_written_transposed_carry_the_bits_of_the_rows_kernel(shuf_l3k10):
+    """kssd_gpu_dist_device_transposed (the own-index partition of the multi-GPU all-pairs run): counts row-major by query, then
+    the transposing metrics kernel -- element (reference r, query q) at r * pitch + (q - q_begin).  Against kssd_gpu_dist_device
+    on the same index: counts equal the oracle's, every plane's bits equal the rows kernel's epilogue (it is the same device
+    function), for sizes that are no multiples of the 64 x 64 tile, empty sketches on both sides, a sub-range of the rows, a
+    pitch wider than the range, planes left out, the negative filter on"""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        for n_ref, n_qry, filt in ((70, 131, False), (1, 5, False), (65, 64, True), (200, 333, True)):
+            roff, rids = random_sketches(rng, n_ref, 0, 600, 1 << 28, clades=5)
+            qoff, qids = random_sketches(rng, n_qry, 0, 500, 1 << 28, clades=5)
+            if len(rids) and len(qids):
+                qids[: len(qids) // 2] = rng.choice(rids, size=len(qids) // 2)
+                for i in range(n_qry):
+                    s_, e_ = int(qoff[i]), int(qoff[i + 1])
+                    u = np.unique(qids[s_:e_])
+                    fill = rng.choice(1 << 28, size=(e_ - s_) - len(u), replace=False).astype(np.uint32)
+                    qids[s_:e_] = np.sort(np.concatenate([u, fill]))
+            want = ko.shared_counts(roff, rids, qoff, qids, threads=4)
+            d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
+            ctx.index_set_filter(filt, 3, 9)
+            ctx.index_build_device(d[0], d[1], n_ref, len(rids))
+            shared = torch.zeros(n_qry * n_ref, dtype=torch.int32, device=dev)
+            planes = [torch.zeros(n_qry * n_ref, dtype=torch.float64, device=dev) for _ in range(4)]
+            ctx.dist_device(d[2], d[3], n_qry, 0, n_qry, shared, *planes)
+            torch.cuda.synchronize()
+            assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(n_qry, n_ref), want)
+            ref_planes = [p.cpu().numpy().view(np.int64).reshape(n_qry, n_ref) for p in planes]
+            for q0, q1, pitch, with_planes in ((0, n_qry, n_qry, True), (n_qry // 3, n_qry - 1, n_qry + 13, True), (2, 2, 5, True), (0, n_qry, n_qry, False)):
+                rows = q1 - q0
+                work = torch.zeros(max(1, rows * n_ref), dtype=torch.int32, device=dev)
+                sh_t = torch.full((n_ref * pitch,), -5, dtype=torch.int32, device=dev)
+                pl_t = [torch.full((n_ref * pitch,), -5.0, dtype=torch.float64, device=dev) for _ in range(4)] if with_planes else [None] * 4
+                ctx.dist_device_transposed(d[2], d[3], n_qry, q0, q1, work, pitch, sh_t, *pl_t)
+                torch.cuda.synchronize()
+                got = sh_t.cpu().numpy().view(np.uint32).reshape(n_ref, pitch)
+                assert np.array_equal(got[:, :rows], want[q0:q1].T), (n_ref, n_qry, q0, q1)
+                assert (got[:, rows:] == np.uint32(0xFFFFFFFB)).all()                      # nothing beyond the range is touched
+                if with_planes:
+                    for p, w in zip(pl_t, ref_planes):
+                        g = p.cpu().numpy().view(np.int64).reshape(n_ref, pitch)
+                        assert np.array_equal(g[:, :rows], w[q0:q1].T), (n_ref, n_qry, q0, q1)
+        ctx.index_set_filter(False)
+    finally:
+        ctx.close()

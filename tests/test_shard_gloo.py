@@ -85,10 +85,21 @@ class OracleEngine:
     """the two device-level entry points ShardedSearch needs, computed by the CPU oracle on CPU tensors (test
     infrastructure: lets the sharding logic run under gloo without a GPU)"""
 
-    def index_build_device(self, roff, rids, n_ref, max_ids, stream=None):
+    def index_build_device(self, roff, rids, n_ref, max_ids, stream=None, check=True):
         self.roff = roff.numpy()[:n_ref + 1].astype(np.uint64)
         self.rids = rids.numpy()[:int(self.roff[-1])].astype(np.uint32)
         assert int(self.roff[-1]) <= max_ids
+
+    def dist_device_transposed(self, qoff, qids, n_qry, q_begin, q_end, work, out_pitch, shared_t, *planes, stream=None):
+        """kssd_gpu_dist_device_transposed: element (indexed sketch r, query q) at r * out_pitch + (q - q_begin)"""
+        qo = qoff.numpy()[:n_qry + 1].astype(np.uint64)
+        qi = qids.numpy()[:int(qo[-1])].astype(np.uint32)
+        full = ko.shared_counts(self.roff, self.rids, qo, qi)          # [n_qry] x [n_ref]
+        n_ref, rows = full.shape[1], q_end - q_begin
+        assert out_pitch >= rows and work.numel() >= rows * n_ref
+        flat = shared_t.view(-1)
+        for r in range(n_ref):
+            flat[r * out_pitch:r * out_pitch + rows] = torch.from_numpy(full[q_begin:q_end, r].astype(np.int32))
 
     def dist_device(self, qoff, qids, n_qry, q_begin, q_end, shared, *planes, stream=None):
         qo = qoff.numpy()[:n_qry + 1].astype(np.uint64)
@@ -106,11 +117,12 @@ def _search_worker(rank, world, port, G, cap, Qn, q):
         off, ids = make_rank_data(rank, G, cap)
         qoff, qids = make_rank_data(1000 + rank, Qn, cap)
         out = {}
-        for part in ("query", "transpose"):
+        for part in ("query", "own"):
             s = ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition=part)
             shared = torch.zeros(s.cells(), dtype=torch.int32)
             s.step(torch.from_numpy(off), torch.from_numpy(ids), shared, None, cap)
             out[part] = (shared.numpy().copy(), s.block())
+            assert s.block() == ((rank * G, (rank + 1) * G), (0, world * G), False)   # either partition leaves the rank's rows, row-major
         # a query set of its own (Q != R): only the north_star partition can do it
         s = ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition="query")
         shared = torch.zeros(s.cells(Qn), dtype=torch.int32)
@@ -118,7 +130,7 @@ def _search_worker(rank, world, port, G, cap, Qn, q):
                q=(torch.from_numpy(qoff), torch.from_numpy(qids), Qn))
         out["search"] = (shared.numpy().copy(), s.block(Qn))
         try:
-            ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition="transpose").step(
+            ShardedSearch(world, rank, G, cap, torch.device("cpu"), OracleEngine(), partition="own").step(
                 torch.from_numpy(off), torch.from_numpy(ids), shared, None, cap, q=(torch.from_numpy(qoff), torch.from_numpy(qids), Qn))
             out["refused"] = False
         except ValueError:
@@ -140,9 +152,9 @@ def _csr_of(seed0, world, G, cap):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_blocks_of_both_partitions_assemble_into_the_oracle_matrix(world):
-    """every rank computes its block (north_star partition: own query rows x gathered full index; transpose partition:
-    all gathered rows x own index); the blocks put together must be the oracle's full matrix -- for all-pairs in
-    both partitions, and for a query set of its own (Q != R) in the north_star partition"""
+    """every rank computes its block (north_star partition: own query rows x gathered full index; own-index partition:
+    all gathered rows x own index, written transposed); the blocks put together must be the oracle's full matrix -- for
+    all-pairs in both partitions, and for a query set of its own (Q != R) in the north_star partition"""
     from public_kssd_amd.shard import assemble
     G, cap, Qn = 13, 700, 5
     ctx = mp.get_context("spawn")
@@ -157,9 +169,13 @@ def test_blocks_of_both_partitions_assemble_into_the_oracle_matrix(world):
         assert p.exitcode == 0
     roff, rids = _csr_of(0, world, G, cap)
     want = ko.shared_counts(roff, rids, roff, rids)
-    for part in ("query", "transpose"):
+    for part in ("query", "own"):
         full = assemble(world, G, [res[r][part] for r in range(world)])
         assert np.array_equal(full.astype(np.uint32), want), part
+        # the layout `kssd dist --allpairs --gpus N` relies on (csrc/kssd_resident.inc): rank r's flat output IS rows
+        # [r*G, (r+1)*G) of the row-major N x N matrix -- the ranks' outputs one behind the other are sharedk_ct.dat
+        cat = np.concatenate([res[r][part][0] for r in range(world)]).astype(np.uint32)
+        assert np.array_equal(cat, want.reshape(-1)), part
     qoff, qids = _csr_of(1000, world, Qn, cap)
     want_q = ko.shared_counts(roff, rids, qoff, qids)
     full = assemble(world, G, [res[r]["search"] for r in range(world)], Q=Qn)
