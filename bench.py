@@ -7,15 +7,14 @@ One step = one pass of the hot path over one batch that is already resident in H
         (shared counts + Jaccard / MashD / containment / AafD, 36 B per pair)
 Workload = BASELINE.json configs[1]: 1 000 synthetic 5 Mb bacterial genomes per GPU (50 clades x 20 members,
 0.5-5 % substitutions, 1e-4 N), L3K10 shuffle, all-pairs.  Weak scaling: every rank sketches its own 1 000
-genomes and computes the block of the all-pairs matrix between ITS genomes and ALL N x 1 000 genomes -- in north_star's
-partition (--partition query, the headline: every rank gathers all sketches, builds the full index and computes the rows of
-its own query block) and, measured beside it, in the transposed one (own sketches indexed, all gathered sketches as query
-rows: the index build stays constant per rank; every metric of the path is symmetric in (query, reference)).
+genomes and computes the rows of ITS genomes against ALL N x 1 000 genomes (query-block sharding of the matrix, row-major).
+How a rank computes them: --partition own (the headline) indexes only its own sketches, runs all gathered sketches as query
+rows and writes the block transposed (queries = references, every metric symmetric: the index build stays constant per
+rank); --partition query builds the full index of all gathered sketches on every rank (what a search with Q != R needs).
 
-By default the steps run back to back on one stream (--inflight 1): the roofline figure of the scan is then the kernel's
-own.  --inflight 3 pipelines the steps over three contexts and streams (reported as `pipelined`; within 1 - 3 % of the
-sequential figure since the exact stage moved into the per-genome kernel: the scan holds every CU's LDS, nothing runs under it).
-Every --kernel-timing-th launch of the scan / rows kernels inside the timed region carries the events of the roofline figures.
+The steps run back to back on one stream.  Every --kernel-timing-th launch of the scan / rows kernels inside the timed region
+(at least ten of them) carries the events of the roofline figures; their minimum and maximum stand beside the mean.
+--emulate-world N: one GPU plays one rank of N (everything of the rank's step except xGMI), both partitions.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -807,6 +806,38 @@ def run_exchange_c(a, shuf, n_dev, reason=None):
     return 0
 
 
+class EmulatedGather:
+    """The exchange of ONE rank of `world` played on one GPU (bench.py --emulate-world): the other ranks' units were sketched
+    once, untimed, from their own batches; every step they are delivered by device-to-device copies of exactly the bytes the
+    all-gather delivers into this rank's staging -- world x (8 (G + 1) + 4 unit) bytes, the own unit fresh from this step's
+    sketch --, then the same unpacking kernel (kssd_gpu_concat_units_device).  What it leaves out is xGMI: the line says so."""
+
+    def __init__(self, world, rank, G, unit, dev, engine, units):
+        self.world, self.rank, self.G, self.cap, self.engine = world, rank, G, unit, engine
+        self.src_off = torch.zeros(world * (G + 1), dtype=torch.int64, device=dev)
+        self.src_ids = torch.zeros(world * unit, dtype=torch.int32, device=dev)
+        for j, (off_j, ids_j) in units.items():
+            self.src_off[j * (G + 1):(j + 1) * (G + 1)] = off_j
+            n = min(unit, int(ids_j.numel()))
+            self.src_ids[j * unit:j * unit + n] = ids_j[:n]
+        self.off_all = torch.zeros(world * (G + 1), dtype=torch.int64, device=dev)
+        self.ids_all = torch.zeros(world * unit, dtype=torch.int32, device=dev)
+        self.roff = torch.zeros(world * G + 1, dtype=torch.int64, device=dev)
+        self.rids = torch.zeros(world * unit, dtype=torch.int32, device=dev)
+        self.bytes = world * (8 * (G + 1) + 4 * unit)
+
+    def __call__(self, off_l, ids_l, group=None, stream=None):
+        w, r, G, u = self.world, self.rank, self.G, self.cap
+        for dst, src, own, n in ((self.off_all, self.src_off, off_l, G + 1), (self.ids_all, self.src_ids, ids_l, u)):
+            if r > 0:
+                dst[:r * n].copy_(src[:r * n], non_blocking=True)
+            dst[r * n:(r + 1) * n].copy_(own[:n], non_blocking=True)
+            if r + 1 < w:
+                dst[(r + 1) * n:].copy_(src[(r + 1) * n:], non_blocking=True)
+        self.engine.concat_units_device(self.off_all, self.ids_all, w, G, u, self.roff, self.rids, stream)
+        return self.roff, self.rids
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -822,10 +853,18 @@ def main():
                     help="allpairs = BASELINE configs[1] (the metric's config; configs[2] with --genomes 10000 --clades 500); "
                          "fastq = configs[3]: reads -> read-set sketch -> containment against the reference sketches; "
                          "mammal = configs[4]: 3 Gb records at -k 10 -s 7 -l 5, sketch throughput")
-    ap.add_argument("--partition", choices=["both", "query", "transpose"], default="both",
-                    help="N > 1: query = the north_star partition (full index on every rank, own query block as rows): the headline; "
-                         "transpose = own sketches indexed, all gathered sketches as query rows (all-pairs only, the index build stays "
-                         "constant per rank); both (default) = query as the headline value, transpose measured beside it")
+    ap.add_argument("--partition", choices=["both", "own", "query", "transpose"], default="both",
+                    help="N > 1, how a rank computes the rows of the matrix it owns (its query block x all genomes, row-major, in either "
+                         "case): own = it indexes ITS OWN sketches, runs all gathered sketches as query rows and writes the block "
+                         "transposed (all-pairs: queries = references, every metric symmetric; the index build stays constant per rank) -- "
+                         "the headline; query = the full index of all gathered sketches on every rank, own query block as rows (what a "
+                         "search with Q != R needs); both (default) = own as the headline value, query measured beside it")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="N",
+                    help="ONE GPU plays ONE rank (--rank) of N at the per-GPU size: its own batch sketched every step, the other ranks' "
+                         "units (sketched once, untimed) delivered by device-to-device copies of exactly the bytes the all-gather "
+                         "delivers, then index + rows in both partitions.  Everything of a rank's step except xGMI; the line is "
+                         "labelled an emulation and is not a --gpus N result")
+    ap.add_argument("--rank", type=int, default=0, help="--emulate-world: which rank this GPU plays")
     ap.add_argument("--e2e-files", type=int, default=1024, help="files of the end-to-end / reference leg (the CPU sample under several names)")
     ap.add_argument("--e2e-search", type=int, default=1024, help="sketches of the end-to-end search leg (all-pairs among the first N files)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="fastq workload: reads of 150 bp")
@@ -836,17 +875,20 @@ def main():
                          "exchange is kssd_gpu_allgather_sketches of the C ABI (RCCL inside libkssd_gpu.so, no torch.distributed)")
     ap.add_argument("--kernel-timing", type=int, default=int(os.environ.get("KSSD_BENCH_KERNEL_TIMING", "4")),
                     help="allpairs: every N-th launch of the scan / rows kernels inside the timed region carries the HIP events the roofline "
-                         "figures come from (kssd_gpu_set_kernel_timing; 1 = every launch).  A bracketed dispatch does not overlap its "
-                         "neighbours in the stream, which costs the step several microseconds per bracket (profiles/r04E_gaps.txt)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("KSSD_BENCH_INFLIGHT", "1")),
-                    help="batches in flight, each on its own HIP stream with its own context and outputs (1 = serial, the default; 3 = pipelined)")
+                         "figures come from (kssd_gpu_set_kernel_timing; 1 = every launch), lowered until at least ten launches of the timed "
+                         "region carry them.  A bracketed dispatch does not overlap its neighbours in the stream, which costs the step "
+                         "several microseconds per bracket (profiles/r04E_gaps.txt)")
     a = ap.parse_args()
+    if a.partition == "transpose":
+        a.partition = "own"
     if a.genomes is None:
         a.genomes = 8 if a.workload == "mammal" else 1000
     if a.length is None:
         a.length = 3_000_000_000 if a.workload == "mammal" else 5_000_000
+    if a.emulate_world and (a.emulate_world < 2 or a.gpus != 1 or a.workload != "allpairs" or not 0 <= a.rank < a.emulate_world):
+        raise SystemExit("--emulate-world N: N >= 2, --gpus 1, --workload allpairs, 0 <= --rank < N")
 
-    if a.exchange == "c" and a.workload == "allpairs" and "WORLD_SIZE" not in os.environ:
+    if a.exchange == "c" and a.workload == "allpairs" and "WORLD_SIZE" not in os.environ and not a.emulate_world:
         if not torch.cuda.is_available() or torch.cuda.device_count() < a.gpus:
             raise SystemExit("--exchange c --gpus %d: %d device(s) visible" % (a.gpus, torch.cuda.device_count() if torch.cuda.is_available() else 0))
         return run_exchange_c(a, K.Shuf.generate(10, 6, 3, seed=20260101), a.gpus)
@@ -895,7 +937,6 @@ def main():
         backend = dist.get_backend()                      # what the line reports: the transport that really ran
 
     G, L = a.genomes, a.length
-    NF = max(1, a.inflight)
     if a.workload == "mammal":
         if world != 1:
             # the path shards by genome with no exchange: N ranks = N independent replicas of this run
@@ -906,24 +947,52 @@ def main():
         if world != 1:
             raise SystemExit("--workload fastq is a single-GPU run (one read set = one sketch)")
         return run_fastq(a, shuf, dev)
+    # W ranks of G genomes each; this process is rank R_ of them.  --emulate-world: W is the emulated world, one process, no collective
+    emu = a.emulate_world > 0
+    W, R_ = (a.emulate_world, a.rank) if emu else (world, rank)
     t0 = time.time()
-    n_keep = a.cpu_sample if (rank == 0 and world == 1) else 0
-    packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * rank, dev, keep_codes=min(n_keep, G))
+    n_keep = a.cpu_sample if (rank == 0 and W == 1) else 0
+    packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * R_, dev, keep_codes=min(n_keep, G))
     torch.cuda.synchronize()
     if rank == 0:
         log("[bench] batch of %d x %.1f Mb packed on device in %.1f s" % (G, L / 1e6, time.time() - t0))
 
-    # Optional software pipeline over steps (--inflight 3).  Every step is the whole hot path over one batch; NF batches
-    # are in flight, each with its own context (workspaces, index), outputs and HIP stream.  The scan holds every CU's
-    # LDS, so no other LDS user starts while it runs; events between the phases (kssd_gpu_sketch_phase) let the
-    # kernels without LDS of the neighbouring steps (exact stage, index insert) run underneath it and the LDS users
-    # (per-genome sort, all-pairs rows, posting allocation) side by side between two scans.
-    # Nothing is skipped or reused between steps; --inflight 1 (the default) runs the same phases back to back on one
-    # stream.
     exp_ids = int(G * L / 4096)
     cap = int(exp_ids * 1.25) + 4096                      # ids per rank (padded all-gather unit)
-    R = G * world
+    R = G * W
     from public_kssd_amd.shard import ShardedSearch
+
+    emu_units, emu_unit = {}, cap
+    if emu:
+        # the other ranks' sketches: their batches (the seeds a --gpus N run gives them) sketched once, untimed, one at a time
+        t0 = time.time()
+        ctx0 = K.GpuCtx(shuf, local)
+        most = 0
+        for j in range(W):
+            if j == R_:
+                pj, mj, cj = packed, mask, chunk_off
+            else:
+                pj, mj, cj, _ = make_batch(G, L, a.clades, 20260101 + 7919 * j, dev)
+            off_j = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+            ids_j = torch.zeros(cap, dtype=torch.int32, device=dev)
+            for attempt in range(6):
+                ctx0.sketch_device(pj, mj, cj, off_j, ids_j, cap)
+                rc, total, bad = ctx0.sketch_status()
+                if rc == 0:
+                    break
+                if rc != K.capi.ERR_OVERFLOW:
+                    raise SystemExit("sketch of emulated rank %d failed: rc=%d" % (j, rc))
+            else:
+                raise SystemExit("sketch kept overflowing")
+            most = max(most, int(total))
+            if j != R_:
+                emu_units[j] = (off_j, ids_j)
+                del pj, mj
+                torch.cuda.empty_cache()
+        ctx0.close()
+        emu_unit = min(cap, (most + 4096 + 1023) // 1024 * 1024)   # what the fullest rank holds + a margin: the unit of a --gpus N run
+        log("[bench] --emulate-world %d, rank %d: the %d other ranks' batches sketched once in %.1f s (unit %d ids)"
+            % (W, R_, W - 1, time.time() - t0, emu_unit))
 
     def sync():
         if world > 1:
@@ -935,105 +1004,66 @@ def main():
     def measure(partition):
         """the whole measurement (sizing passes, spin-up, warm-up, the timed steps, the size-independent checks of the result)
         in one partition of the matrix; returns the numbers and rank 0's tensors for the line"""
-        class Slot:
-            pass
-        slots = []
-        for j in range(NF):
-            sl = Slot()
-            sl.ctx = K.GpuCtx(shuf, local)
-            # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
-            sl.off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
-            sl.ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
-            sl.shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
-            sl.planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
-            sl.tstream = torch.cuda.Stream(device=dev) if NF > 1 else torch.cuda.current_stream()
-            sl.stream = sl.tstream.cuda_stream
-            sl.scanned, sl.sorted = torch.cuda.Event(), torch.cuda.Event()
-            sl.unit = cap
-            sl.search = ShardedSearch(world, rank, G, cap, dev, sl.ctx, partition=partition)
-            # upper bound of the ids the index has to hold (it sizes the hash table): the padded capacity until the first
-            # status read-back has told the host how many ids this batch really has
-            sl.idx_bound = cap
-            slots.append(sl)
+        ctx = K.GpuCtx(shuf, local)
+        # outputs, all preallocated: nothing is allocated inside the timed region after the warmup
+        off_l = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        ids_l = torch.zeros(cap, dtype=torch.int32, device=dev)
+        shared = torch.zeros(G * R, dtype=torch.int32, device=dev)
+        planes = [None] * 4 if a.no_planes else [torch.zeros(G * R, dtype=torch.float64, device=dev) for _ in range(4)]
+        tstream = torch.cuda.current_stream()
+        stream = tstream.cuda_stream
+        st = {"unit": emu_unit if emu else cap, "idx_bound": cap, "search": None}
 
-        def plan_prep(sl):
-            sl.ctx.sketch_plan(packed, mask, chunk_off, sl.off_l, sl.ids_l, cap, K.SKETCH_FASTA, 1)
-            sl.ctx.sketch_phase(K.PHASE_PREP, sl.stream)
+        def new_search():
+            gather = EmulatedGather(W, R_, G, st["unit"], dev, ctx, emu_units) if emu else None
+            st["search"] = ShardedSearch(W, R_, G, st["unit"], dev, ctx, partition=partition, gather=gather, check_index=False)
+        new_search()
 
-        def index_build(sl):
+        def sketch():
+            ctx.sketch_plan(packed, mask, chunk_off, off_l, ids_l, cap, K.SKETCH_FASTA, 1)
+            for ph in (K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
+                ctx.sketch_phase(ph, stream)
+
+        def index_build():
             # the one exchange step of the path (N > 1): all-gather of every rank's packed sketches (RCCL over xGMI), then the
-            # index in the chosen partition (public_kssd_amd/shard.py).  The unit a rank contributes is its first sl.unit ids.
-            sl.search.index(sl.off_l, sl.ids_l[:sl.unit], sl.idx_bound, stream=sl.stream, tstream=sl.tstream if world > 1 else None)
+            # index in the chosen partition (public_kssd_amd/shard.py).  The unit a rank contributes is its first `unit` ids.
+            st["search"].index(off_l, ids_l[:st["unit"]], st["idx_bound"], stream=stream, tstream=tstream if W > 1 else None)
 
-        def rows(sl):
-            sl.search.rows(sl.off_l, sl.ids_l[:sl.unit], sl.shared, sl.planes, stream=sl.stream)
+        def rows():
+            st["search"].rows(off_l, ids_l[:st["unit"]], shared, planes, stream=stream)
 
         def run_steps(n_steps):
-            """n_steps whole steps, pipelined over the NF slots; everything is enqueued, nothing synchronised"""
-            if NF < 3:
-                for n in range(n_steps):                      # back to back (NF = 2: two independent chains)
-                    sl = slots[n % NF]
-                    plan_prep(sl)
-                    for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
-                        sl.ctx.sketch_phase(ph, sl.stream)
-                    index_build(sl)
-                    rows(sl)
-                return
-            if n_steps > 0:
-                plan_prep(slots[0])
-            for n in range(n_steps + 2):                      # two more rounds drain the pipeline
-                cur, prev, old = slots[n % NF], slots[(n - 1) % NF], slots[(n - 2) % NF]
-                if n < n_steps:
-                    if n >= 2:
-                        cur.tstream.wait_event(old.sorted)    # the gap's LDS users are through (the rows of step n-3
-                    cur.ctx.sketch_phase(K.PHASE_SCAN, cur.stream)   # precede this scan on its own stream)
-                    cur.scanned.record(cur.tstream)
-                if 1 <= n <= n_steps:                         # step n-1: exact stage under scan n, sort after it
-                    prev.ctx.sketch_phase(K.PHASE_EXACT, prev.stream)
-                    if n < n_steps:
-                        prev.tstream.wait_event(cur.scanned)
-                    prev.ctx.sketch_phase(K.PHASE_FINISH, prev.stream)
-                    prev.sorted.record(prev.tstream)
-                    index_build(prev)                         # runs under scan n+1
-                if n + 1 < n_steps:                           # setup of step n+1 ahead of the rows that share its stream
-                    plan_prep(slots[(n + 1) % NF])
-                if 2 <= n:                                    # step n-2: all-pairs rows after scan n
-                    if n < n_steps:
-                        old.tstream.wait_event(cur.scanned)
-                    rows(old)
+            """n_steps whole steps back to back on one stream; everything is enqueued, nothing synchronised"""
+            for _ in range(n_steps):
+                sketch()
+                index_build()
+                rows()
 
-        # first calls size the workspaces of every context; retry if a staging region was too small
-        for sl in slots:
-            for attempt in range(6):
-                plan_prep(sl)
-                for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
-                    sl.ctx.sketch_phase(ph, sl.stream)
-                index_build(sl)
-                rows(sl)
-                rc, total, bad = sl.ctx.sketch_status(sl.stream)
-                irc = sl.ctx.index_status(sl.stream)        # (a capped index build that overflowed: the next one counts first)
-                if rc == 0 and irc == 0:
-                    sl.idx_bound = min(cap, int(total) + 1024)
-                    break
-                if rc not in (0, K.capi.ERR_OVERFLOW) or irc not in (0, K.capi.ERR_OVERFLOW):
-                    raise SystemExit("sketch / index failed: rc=%d, %d" % (rc, irc))
-            else:
-                raise SystemExit("sketch kept overflowing")
+        # first calls size the workspaces of the context; retry if a staging region was too small
+        for attempt in range(6):
+            run_steps(1)
+            rc, total, bad = ctx.sketch_status(stream)
+            irc = ctx.index_status(stream)        # (a capped index build that overflowed: the next one counts first)
+            if rc == 0 and irc == 0:
+                st["idx_bound"] = min(cap, int(total) + 1024)
+                break
+            if rc not in (0, K.capi.ERR_OVERFLOW) or irc not in (0, K.capi.ERR_OVERFLOW):
+                raise SystemExit("sketch / index failed: rc=%d, %d" % (rc, irc))
+        else:
+            raise SystemExit("sketch kept overflowing")
         sync()
         exchange_us = None
-        unit = cap
         if world > 1:
             # the exchange unit shrinks from the padded capacity to what the fullest rank really holds (+ a margin): setup,
             # untimed -- every step then gathers 20 % fewer bytes
-            need = torch.tensor([max(sl.idx_bound for sl in slots)], dtype=torch.int64, device=dev)
+            need = torch.tensor([st["idx_bound"]], dtype=torch.int64, device=dev)
             dist.all_reduce(need, op=dist.ReduceOp.MAX)
-            unit = min(cap, (int(need.item()) + 4096 + 1023) // 1024 * 1024)
-            for sl in slots:
-                sl.unit = unit
-                sl.search = ShardedSearch(world, rank, G, unit, dev, sl.ctx, partition=partition)
-                index_build(sl)
-                rows(sl)
+            st["unit"] = min(cap, (int(need.item()) + 4096 + 1023) // 1024 * 1024)
+            new_search()
+            index_build()
+            rows()
             sync()
+        unit = st["unit"]
         # setup, untimed like the sizing passes above: the clocks of an idle GPU need some tens of milliseconds of work to
         # settle (measured: the scan launch takes 0.54 ms in the first dozen steps after a pause and 0.52 ms from then on)
         # ... and a GPU that has just come out of other work (the test suite, a cold box) can sit in a slower state for seconds: the
@@ -1059,116 +1089,97 @@ def main():
         spinup_done[0] = spun
         run_steps(a.warmup)
         sync()
-        every = max(1, min(a.kernel_timing, max(1, a.steps // max(1, NF))))    # (at least one timed launch per slot)
-        for sl in slots:
-            sl.ctx.kernel_time(0, reset=True)
-            sl.ctx.kernel_time(1, reset=True)
-            sl.ctx.set_kernel_timing(every)
+        # at least ten launches of the timed region carry the events (the driver's 20 steps: every 2nd one)
+        every = max(1, min(a.kernel_timing, a.steps // 10))
+        ctx.kernel_time(0, reset=True)
+        ctx.kernel_time(1, reset=True)
+        ctx.set_kernel_timing(every)
         t0 = time.perf_counter()
         run_steps(a.steps)
         sync()
         dt = time.perf_counter() - t0
-        scan_ms = dist_ms = 0.0
-        scan_n = dist_n = 0
-        for sl in slots:
-            rc, total, bad = sl.ctx.sketch_status(sl.stream)
-            if rc != 0:
-                raise SystemExit("sketch status rc=%d after the timed loop" % rc)
-            ms, n = sl.ctx.kernel_time(0)
-            scan_ms += ms * n
-            scan_n += n
-            ms, n = sl.ctx.kernel_time(1)
-            dist_ms += ms * n
-            dist_n += n
-        scan_ms = scan_ms / scan_n if scan_n else 0.0       # average launch duration over every timed launch
-        dist_ms = dist_ms / dist_n if dist_n else 0.0
-        for sl in slots:
-            if sl.ctx.index_status(sl.stream) != 0:
-                raise SystemExit("index status after the timed loop: the build overflowed")
+        rc, total, bad = ctx.sketch_status(stream)
+        if rc != 0:
+            raise SystemExit("sketch status rc=%d after the timed loop" % rc)
+        scan_t, dist_t = ctx.kernel_times(0), ctx.kernel_times(1)
+        scan_ms = float(scan_t.mean()) if len(scan_t) else 0.0   # average launch duration over every timed launch
+        dist_ms = float(dist_t.mean()) if len(dist_t) else 0.0
+        if ctx.index_status(stream) != 0:
+            raise SystemExit("index status after the timed loop: the build overflowed")
 
         # The distance half alone, timed the same way (same warm-up, same number of steps, barrier + synchronize on both sides,
         # max over ranks): index build + the rank's rows on the sketches that are resident from the steps above -- what
-        # `kssd dist -r` does once stage I is through (command_dist.c:763-790).  N > 1: the exchange is part of it.
-        def run_dist(n):
-            sl = slots[0]
-            for _ in range(n):
-                index_build(sl)
-                rows(sl)
+        # `kssd dist -r` does once stage I is through (command_dist.c:763-790).  N > 1: the exchange is part of it.  Events
+        # between the two halves of every pass: what the exchange + unpacking + index and what the rows cost on their own.
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+
+        def run_dist(n, timed=False):
+            for i in range(n):
+                if timed:
+                    ev[i][0].record(tstream)
+                index_build()
+                if timed:
+                    ev[i][1].record(tstream)
+                rows()
+                if timed:
+                    ev[i][2].record(tstream)
         run_dist(a.warmup)
         sync()
-        slots[0].ctx.kernel_time(1, reset=True)
-        slots[0].ctx.set_kernel_timing(every)
+        ctx.kernel_time(1, reset=True)
+        ctx.set_kernel_timing(every)
         t0 = time.perf_counter()
         run_dist(a.steps)
         sync()
         dt_dist = time.perf_counter() - t0
-        dist_only_ms, dist_only_n = slots[0].ctx.kernel_time(1)
-        for sl in slots:
-            sl.ctx.set_kernel_timing(1)
-        if slots[0].ctx.index_status(slots[0].stream) != 0:
+        dist_only_t = ctx.kernel_times(1)
+        ctx.set_kernel_timing(0)
+        run_dist(a.steps, timed=True)       # (a pass of its own: event records between the halves keep them from overlapping)
+        sync()
+        index_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        rows_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        ctx.set_kernel_timing(1)
+        if ctx.index_status(stream) != 0:
             raise SystemExit("index status after the distance loop: the build overflowed")
         tmax = torch.tensor([dt_dist], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt_dist = float(tmax.item())
-        ctx, stream = slots[0].ctx, slots[0].stream
-        off_l, ids_l, shared = slots[0].off_l, slots[0].ids_l, slots[0].shared
         n_stage1, n_bloom = ctx.scan_stats(stream)
-        for sl in slots[1:]:                                  # every slot worked on the same batch: same results
-            assert torch.equal(sl.off_l, off_l) and torch.equal(sl.shared, shared), "slots disagree"
-            assert torch.equal(sl.ids_l[:int(total)], ids_l[:int(total)]), "slots disagree"
 
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-        if world > 1:
-            # the exchange alone, untimed beside the steps: the two all-gathers + the unpacking kernel of one step, between
-            # events on the stream they run on, averaged over 20 rounds behind a barrier (max over ranks)
-            sl = slots[0]
-            g = sl.search.gather
-            ts = sl.tstream
+        if W > 1:
+            # the exchange alone, untimed beside the steps: the two all-gathers (emulation: the copies of their bytes) + the
+            # unpacking kernel of one step, between events on the stream they run on, averaged over 20 rounds behind a barrier
+            g = st["search"].gather
             for _ in range(3):
-                with torch.cuda.stream(ts):
-                    g(sl.off_l, sl.ids_l[:sl.unit], stream=sl.stream)
+                g(off_l, ids_l[:unit], stream=stream)
             sync()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(ts):
-                e0.record(ts)
-                for _ in range(20):
-                    g(sl.off_l, sl.ids_l[:sl.unit], stream=sl.stream)
-                e1.record(ts)
+            e0.record(tstream)
+            for _ in range(20):
+                g(off_l, ids_l[:unit], stream=stream)
+            e1.record(tstream)
             sync()
             ex = torch.tensor([e0.elapsed_time(e1) * 1e3 / 20], dtype=torch.float64, device=dev)
-            dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+            if world > 1:
+                dist.all_reduce(ex, op=dist.ReduceOp.MAX)
             exchange_us = float(ex.item())
 
-        # outside the timed region: the scan with nothing else on the device (sketch call alone, one stream), for the
-        # kernel's own roofline figure next to the one measured under the pipeline's contention
-        scan_alone_ms = None
-        if NF > 1 and world == 1:
-            sl = slots[0]
-            sl.ctx.kernel_time(0, reset=True)
-            for _ in range(5):
-                plan_prep(sl)
-                for ph in (K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
-                    sl.ctx.sketch_phase(ph, sl.stream)
-            torch.cuda.synchronize()
-            scan_alone_ms, _ = sl.ctx.kernel_time(0)
-
+        szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
+        sh = shared.view(G, R)   # [this rank's genomes (its rows of the matrix)] x [all genomes], in either partition
         if world > 1:
             # size-independent check of the WHOLE distributed result, untimed: every rank's block gathered, the global matrix
-            # assembled as shard.py lays it out -- it must be symmetric and carry every rank's sketch sizes on its diagonal
-            # (the foreign rows of a rank are the transposes of other ranks' foreign rows: any rank computing a wrong block shows)
+            # assembled -- the ranks' rows one behind the other -- must be symmetric and carry every rank's sketch sizes on its
+            # diagonal (any rank computing a wrong block shows: its block is the transpose of the others' columns)
             blocks = torch.zeros(world * G * R, dtype=torch.int32, device=dev)
             sizes_all = torch.zeros(world * G, dtype=torch.int32, device=dev)
             dist.all_gather_into_tensor(blocks, shared)
-            dist.all_gather_into_tensor(sizes_all, (off_l[1:] - off_l[:-1]).to(torch.int32).contiguous())
-            if partition == "query":
-                full = blocks.view(world * G, R)                       # rank r wrote rows [r*G, (r+1)*G) x all columns
-            else:
-                full = blocks.view(world, R, G).permute(1, 0, 2).reshape(R, R)   # rank r wrote [all rows] x its G columns
+            dist.all_gather_into_tensor(sizes_all, szs.contiguous())
+            full = blocks.view(world * G, R)
             assert torch.equal(full.diagonal(), sizes_all), "N > 1: diagonal of the global matrix != the sketch sizes"
             assert torch.equal(full, full.t()), "N > 1: the global all-pairs matrix is not symmetric"
             checksum = int(full.to(torch.int64).sum().item())          # the same number in either partition
@@ -1176,37 +1187,44 @@ def main():
         else:
             checksum = int(shared.to(torch.int64).sum().item())
         # size-independent sanity on this rank's block of the matrix
-        szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
-        if partition == "query":
-            sh = shared.view(G, R)   # [this rank's genomes (query rows)] x [all genomes]
-            own = sh[:, rank * G:(rank + 1) * G]
-        else:
-            sh = shared.view(R, G)   # [all genomes (query rows)] x [this rank's genomes]; world 1: the full G x G matrix
-            own = sh[rank * G:(rank + 1) * G, :]
+        own = sh[:, R_ * G:(R_ + 1) * G]
         assert torch.equal(own.diagonal(), szs), "diagonal of the all-pairs matrix must equal the sketch sizes"
         assert torch.equal(own, own.t()), "all-pairs shared-count matrix must be symmetric"
-        res = dict(dt=dt, dt_dist=dt_dist, dist_only_ms=dist_only_ms, dist_only_n=dist_only_n,
-                   scan_ms=scan_ms, dist_ms=dist_ms, scan_n=scan_n, dist_n=dist_n, total=int(total), n_stage1=n_stage1,
-                   n_bloom=n_bloom, exchange_us=exchange_us, unit=unit, scan_alone_ms=scan_alone_ms, checksum=checksum,
-                   off=off_l.cpu().numpy(), ids=ids_l.cpu().numpy().view(np.uint32))
-        for sl in slots:
-            sl.ctx.close()
-        del slots
+        if emu:
+            # the foreign columns against the other ranks' sketch sizes: a genome shares at most min(|X|, |Y|) ids, and the emulated
+            # ranks' batches are other clades: the block must not be all zero by accident of a wrong layout either -- column sums
+            # of the own block are positive, every count is bounded by both sizes
+            assert int(sh.max().item()) <= int(szs.max().item())
+        res = dict(dt=dt, dt_dist=dt_dist, dist_only_ms=float(dist_only_t.mean()) if len(dist_only_t) else 0.0, dist_only_n=len(dist_only_t),
+                   dist_only_t=dist_only_t, scan_ms=scan_ms, dist_ms=dist_ms, scan_t=scan_t, dist_t=dist_t, total=int(total), n_stage1=n_stage1,
+                   n_bloom=n_bloom, exchange_us=exchange_us, unit=unit, checksum=checksum, index_ms=index_ms, rows_ms=rows_ms,
+                   every=every, off=off_l.cpu().numpy(), ids=ids_l.cpu().numpy().view(np.uint32),
+                   block=shared.cpu().numpy().view(np.uint32).reshape(G, R) if emu else None,
+                   planes=[p.cpu().numpy().view(np.int64) for p in planes] if (emu and not a.no_planes and G * R <= 16_000_000) else None)
+        ctx.close()
+        st["search"] = None
         torch.cuda.empty_cache()
         return res
 
-    PART_DESC = {"query": "full index on every rank, own query block as rows (north_star: query-sharded matrix, all-gather of the reference sketches)",
-                 "transpose": "own genomes indexed, all gathered sketches as query rows (transpose of the query block, all-pairs only)"}
-    if world == 1:
+    PART_DESC = {"own": "own genomes indexed, all gathered sketches as query rows, the block written transposed: the rank's own rows, "
+                        "row-major (all-pairs: queries = references, every metric symmetric; the index build stays constant per rank)",
+                 "query": "full index of all gathered sketches on every rank, own query block as rows (north_star's literal partition; what "
+                          "a search with Q != R needs)"}
+    if W == 1:
         head_part, other_part = "query", None               # one GPU: both partitions are the same calls
     elif a.partition == "both":
-        head_part, other_part = "query", "transpose"
+        head_part, other_part = "own", "query"
     else:
         head_part, other_part = a.partition, None
     m = measure(head_part)
     other = measure(other_part) if other_part else None
     if other is not None:
-        assert other["checksum"] == m["checksum"], "the two partitions assemble different matrices"
+        assert other["checksum"] == m["checksum"], "the two partitions compute different matrices"
+        if emu:
+            assert np.array_equal(other["block"], m["block"]), "the two partitions compute different blocks"
+            if m["planes"] is not None:
+                for x, y in zip(m["planes"], other["planes"]):
+                    assert np.array_equal(x, y), "the two partitions compute different metric bits"
     dt, scan_ms, dist_ms, total = m["dt"], m["scan_ms"], m["dist_ms"], m["total"]
 
     if rank == 0:
@@ -1215,12 +1233,15 @@ def main():
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         pairs = G * R
         dist_bytes = (4 if a.no_planes else 36) * pairs + 4.0 * (total + R / G * total)
-        if world > 1:
-            par = {"ranks": world, "backend": backend, "partition": head_part,
+        spread = lambda t: {"min_ms": float(t.min()), "max_ms": float(t.max())} if len(t) else {}
+        if W > 1:
+            par = {"ranks": W, "backend": backend, "partition": head_part,
                    "what": "genomes sharded x%d for sketching (no communication); ONE exchange per step: all-gather of the packed "
-                           "sketches (torch.distributed backend '%s'%s); partition '%s': %s"
-                           % (world, backend, " = RCCL over xGMI" if backend == "nccl" else " -- NOT RCCL: development check", head_part,
-                              PART_DESC[head_part])}
+                           "sketches (%s); every rank owns the rows of its own genomes (query-block sharding of the matrix); how it computes "
+                           "them, '%s': %s"
+                           % (W, "EMULATED on one GPU: device-to-device copies of the bytes, xGMI not included" if emu else
+                              "torch.distributed backend '%s'%s" % (backend, " = RCCL over xGMI" if backend == "nccl" else " -- NOT RCCL: development check"),
+                              head_part, PART_DESC[head_part])}
         else:
             par = "single GPU"
         res = {
@@ -1234,22 +1255,26 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
                                    "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
-                       "pairs_per_step": world * pairs, "batches_in_flight": NF,
+                       "pairs_per_step": world * pairs,
                        "parallelism": par},
             "spinup": spinup_done[0],
             "pairs_per_s": world * pairs * a.steps / dt,
             "pairs_per_s_dist": world * pairs * a.steps / m["dt_dist"],
             "dist_ms_per_step": m["dt_dist"] / a.steps * 1e3,
+            "dist_halves_ms": {"exchange_unpack_index": m["index_ms"], "rows": m["rows_ms"],
+                               "what": "the distance half's two parts between events on the step's stream (a pass of their own: the "
+                                       "records keep the parts from overlapping)"},
             "mbase_per_s": world * n_bases * a.steps / dt / 1e6,
             "ids_per_batch": int(total),
-            "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [m["scan_n"], m["dist_n"]],
-                        "timed_every": a.kernel_timing,   # every N-th launch of the timed region carries the events (--kernel-timing)
+            "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": dist_ms, "launches_timed": [len(m["scan_t"]), len(m["dist_t"])],
+                        "sketch_scan_spread": spread(m["scan_t"]), "dist_rows_spread": spread(m["dist_t"]),
+                        "timed_every": m["every"],   # every N-th launch of the timed region carries the events (--kernel-timing)
                         "dist_rows_GBs": dist_bytes / (dist_ms * 1e-3) / 1e9 if dist_ms > 0 else None,
                         "scan_positions_past_stage1": m["n_stage1"] / n_bases, "scan_positions_past_bloom": m["n_bloom"] / n_bases},
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
-                         "algorithmic_bytes_per_launch": scan_bytes},
+                         "algorithmic_bytes_per_launch": scan_bytes, "launches_timed": len(m["scan_t"]), **spread(m["scan_t"])},
             # the distance half as its own quantity (BASELINE's metric names two rates): `pairs_per_s_dist` above is its
             # whole-job rate (index build + rows, `steps` timed passes), this is its dominant kernel against the same roofline:
             # 36 B per pair written (4 B shared count + four f64 metrics) + 4 B per query and reference id read
@@ -1259,29 +1284,47 @@ def main():
                               "frac": dist_bytes / (m["dist_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if m["dist_only_ms"] > 0 else 0.0,
                               "traffic": None, "traffic_source": None,
                               "algorithmic_bytes_per_launch": dist_bytes, "launch_ms": m["dist_only_ms"],
-                              "launches_timed": m["dist_only_n"]},
+                              "launches_timed": m["dist_only_n"], **spread(m["dist_only_t"])},
         }
-        if world > 1:
+        if W > 1:
             res["backend"] = backend
             res["ranks_seen"] = world
-            res["runtime"] = {"hip": K.gpu_lib().kssd_gpu_runtime_path(0).decode(), "mapped": K.capi.runtime_paths(),
-                              "what": "the HIP runtime libkssd_gpu.so is bound to and every HIP / RCCL / HSA file mapped into rank 0 (one of each: "
-                                      "public_kssd_amd.capi.assert_single_runtime)"}
-            res["exchange"] = {"us": m["exchange_us"], "unit_ids_per_rank": m["unit"], "bytes_gathered_per_rank": world * (4 * m["unit"] + 8 * (G + 1)),
-                               "what": "two all_gather_into_tensor (offsets, padded id units) + the unpacking kernel, alone on the step's "
-                                       "stream, mean of 20, max over ranks"}
+            res["exchange"] = {"us": m["exchange_us"], "unit_ids_per_rank": m["unit"], "bytes_gathered_per_rank": W * (4 * m["unit"] + 8 * (G + 1)),
+                               "what": ("device-to-device copies of the bytes the two all-gathers deliver + the unpacking kernel (xGMI NOT included)" if emu else
+                                        "two all_gather_into_tensor (offsets, padded id units) + the unpacking kernel") +
+                                       ", alone on the step's stream, mean of 20, max over ranks"}
             res["matrix_checksum"] = m["checksum"]
+            if not emu:
+                res["runtime"] = {"hip": K.gpu_lib().kssd_gpu_runtime_path(0).decode(), "mapped": K.capi.runtime_paths(),
+                                  "what": "the HIP runtime libkssd_gpu.so is bound to and every HIP / RCCL / HSA file mapped into rank 0 (one of each: "
+                                          "public_kssd_amd.capi.assert_single_runtime)"}
+            if W > 1 and head_part == "own":
+                del res["roofline_dist"]      # (the rows kernel of this partition writes counts only; its metrics leave by the transposing kernel)
             if other is not None:
                 res["partition_" + other_part] = {
                     "value": world * G * a.steps / other["dt"], "unit": "genomes/s", "ms_per_step": other["dt"] / a.steps * 1e3,
                     "pairs_per_s": world * pairs * a.steps / other["dt"], "exchange_us": other["exchange_us"],
                     "sketch_scan_ms": other["scan_ms"], "dist_rows_ms": other["dist_ms"],
-                    "what": PART_DESC[other_part] + "; same steps / warmup / batch, measured after the headline; the assembled global "
-                            "matrix has the headline's checksum"}
-        if m["scan_alone_ms"]:
-            res["kernels"]["sketch_scan_ms_alone"] = m["scan_alone_ms"]
-            res["roofline"]["frac_alone"] = scan_bytes / (m["scan_alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if a.cpu_sample and world == 1 and kept:
+                    "dist_ms_per_step": other["dt_dist"] / a.steps * 1e3,
+                    "dist_halves_ms": {"exchange_unpack_index": other["index_ms"], "rows": other["rows_ms"]},
+                    "what": PART_DESC[other_part] + "; same steps / warmup / batch, measured after the headline; the same rows of the "
+                            "matrix, the same checksum"}
+        if emu:
+            # one GPU played one rank: the line is a per-rank cost, not a job's throughput -- `value` is what ONE such rank sketches
+            # per second, and says so
+            res["emulated"] = {"world": W, "rank": R_, "per_rank_ms": dt / a.steps * 1e3, "index_ms": m["index_ms"], "rows_ms": m["rows_ms"],
+                               "exchange_bytes": W * (4 * m["unit"] + 8 * (G + 1)), "exchange_copy_us": m["exchange_us"],
+                               "partition": head_part,
+                               "what": "ONE GPU as rank %d of %d at the per-GPU size: own batch sketched every step, the other ranks' units "
+                                       "(sketched once, untimed) delivered by device-to-device copies of exactly the bytes the all-gather "
+                                       "delivers, then unpacking + index + the rank's rows (%d x %d pairs, 36 B each); xGMI NOT included; "
+                                       "n_gpus stays 1 and `value` is this one rank's genomes/s" % (R_, W, G, R)}
+            if other is not None:
+                res["emulated"]["partition_" + other_part] = {"per_rank_ms": other["dt"] / a.steps * 1e3, "index_ms": other["index_ms"],
+                                                             "rows_ms": other["rows_ms"]}
+                res["emulated"]["blocks_identical"] = "shared counts%s of the two partitions' blocks are bit-identical" % (
+                    " and all four metric planes" if m["planes"] is not None else "")
+        if a.cpu_sample and W == 1 and kept:
             ol, il = m["off"], m["ids"]
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
             cores = host_cores()
@@ -1295,7 +1338,7 @@ def main():
             if "reference_gz" in cb:
                 res["cpu_baseline_gz"] = cb["reference_gz"]
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and G == 1000 and L == 5_000_000 and world == 1:  # the PMC passes were collected on the default workload
+        if os.path.exists(pmc) and G == 1000 and L == 5_000_000 and W == 1:  # the PMC passes were collected on the default workload
             # counters cannot be collected inside a timed run: the figures are RECORDED by profiles/pmc_refresh.py, which stamps
             # them with a hash of the kernel sources they were measured on -- sources that have changed since: no figure
             try:
@@ -1313,21 +1356,6 @@ def main():
                         % (str(pj.get("source_sha"))[:12], K.capi.kernel_source_sha()[:12]))
             except Exception:
                 pass
-        if a.cpu_sample and world == 1 and NF == 1 and not os.environ.get("KSSD_BENCH_NO_PIPELINED"):
-            # beside the headline (steps back to back on one stream): the same steps with three batches in flight on three
-            # streams -- the sort / index / rows kernels of one step under the scan of the next.  A child process (its own
-            # batch, contexts and clocks), untimed here; its line is embedded, the headline above is not touched by it.
-            try:
-                env = dict(os.environ, KSSD_BENCH_NO_PIPELINED="1")
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--inflight", "3", "--cpu-sample", "0", "--steps", str(max(a.steps, 30)),
-                                    "--warmup", "3", "--genomes", str(G), "--length", str(L), "--clades", str(a.clades)],
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
-                pj = json.loads(r.stdout.decode().strip().splitlines()[-1])
-                res["pipelined"] = {"batches_in_flight": 3, "value": pj["value"], "unit": pj["unit"], "ms_per_step": pj["ms_per_step"],
-                                    "steps": pj["steps"], "sketch_scan_ms_under_overlap": pj["kernels"]["sketch_scan_ms"],
-                                    "what": "`bench.py --inflight 3`: every step does the same work; three steps overlap on three HIP streams"}
-            except Exception as e:   # the leg is informational
-                res["pipelined"] = {"error": str(e)[:200]}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -484,6 +484,8 @@ int kssd_gpu_set_filter(kssd_gpu_ctx *ctx, const uint64_t *off, const uint32_t *
  * reset != 0 empties the ring.
  */
 int kssd_gpu_kernel_time(kssd_gpu_ctx *ctx, int which, int reset, float *avg_ms, uint32_t *launches);
+/* the same launches one by one: ms[0 .. min(*launches, cap)) receive their durations (for a minimum / maximum beside the mean) */
+int kssd_gpu_kernel_times(kssd_gpu_ctx *ctx, int which, float *ms, uint32_t cap, uint32_t *launches);
 /*
  * How many launches carry the events: every `every`-th one of each path from this call on (1: all of them, the default;
  * 0: none).  A bracketed dispatch does not overlap its neighbours in the stream -- it waits for the kernel in front to drain

@@ -48,7 +48,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_index_status", "kssd_gpu_index_set_exact",
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
-    "kssd_gpu_dist_device_transposed",
+    "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times",
 ]
 
 
@@ -202,6 +202,7 @@ def gpu_lib():
                                                  C.POINTER(C.c_int64)]
         L.kssd_gpu_kernel_time.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(u32)]
         L.kssd_gpu_set_kernel_timing.argtypes = [vp, u32]
+        L.kssd_gpu_kernel_times.argtypes = [vp, i32, vp, u32, C.POINTER(u32)]
         L.kssd_gpu_scan_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), vp]
         L.kssd_gpu_set_lds_sort_limit.argtypes = [vp, u32]
         L.kssd_gpu_set_scan_grid.argtypes = [vp, u32]
@@ -966,3 +967,10 @@ class GpuCtx:
         ms, n = C.c_float(0), C.c_uint32(0)
         _gck(gpu_lib().kssd_gpu_kernel_time(self.h, which, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_times(self, which):
+        """the bracketed launches' durations one by one (ms, oldest first): 0 = sketch scan, 1 = distance rows"""
+        buf = np.zeros(512, dtype=np.float32)
+        n = C.c_uint32(0)
+        _gck(gpu_lib().kssd_gpu_kernel_times(self.h, which, buf.ctypes.data, len(buf), C.byref(n)))
+        return buf[:min(int(n.value), len(buf))].astype(np.float64)

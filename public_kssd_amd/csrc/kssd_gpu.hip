@@ -1394,6 +1394,21 @@ extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float
     return KSSD_OK;
 }
 
+// the durations one by one (ms[0 .. min(*launches, cap)): the ring's launches, oldest first): for the minimum / maximum a line
+// prints beside the mean
+extern "C" int kssd_gpu_kernel_times(kssd_gpu_ctx *c, int which, float *ms, uint32_t cap, uint32_t *launches)
+{
+    if (!c || which < 0 || which > 1 || (!ms && cap)) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    const unsigned n = c->ev_n[which] < EV_RING ? c->ev_n[which] : EV_RING;
+    for (unsigned i = 0; i < n && i < cap; i++) {
+        HIPCK(hipEventSynchronize(c->ev_b[which][i]));
+        HIPCK(hipEventElapsedTime(&ms[i], c->ev_a[which][i], c->ev_b[which][i]));
+    }
+    if (launches) *launches = n;
+    return KSSD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the FASTA tokeniser on the device lives in kssd_tok.inc
 // ---------------------------------------------------------------------------------------------------

@@ -20,7 +20,9 @@ def test_bench_starts_its_own_ranks():
     err = r.stderr.decode(errors="replace")
     assert r.returncode != 0                                   # the children's failure is the parent's
     assert "starting -m torch.distributed.run" in err and "--nproc-per-node 2" in err
-    assert err.count("bench.py needs a GPU") >= 2, err[-2000:]  # both ranks got as far as the bench's own check
+    # a rank got as far as the bench's own check (the launcher ends the other ranks as soon as the first one has failed: whether
+    # the second one's message still makes it out is a race)
+    assert err.count("bench.py needs a GPU") >= 1, err[-2000:]
     assert r.stdout.decode().strip() == ""                      # no line without a measurement
 
 
@@ -89,3 +91,23 @@ def test_bench_modules_name_nothing_undefined():
                 defined.add(n.name)
         used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
         assert not (used - defined), (f, sorted(used - defined))
+
+
+@pytest.mark.gpu
+def test_one_gpu_plays_one_rank_of_three():
+    """bench.py --emulate-world 3 --rank 1: the rank's whole step except xGMI (own batch sketched every step, the other ranks' units
+    delivered by device-to-device copies, unpacking, index, the rank's rows) in BOTH partitions; the bench itself asserts that the
+    own-index partition (transposed write) and the full index leave the same block, counts and metric bits"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-world", "3", "--rank", "1", "--steps", "10", "--warmup", "1", "--spinup", "0",
+                        "--genomes", "60", "--length", "400000", "--clades", "6", "--cpu-sample", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    j = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith('{"metric"')][-1])
+    e = j["emulated"]
+    assert j["n_gpus"] == 1 and e["world"] == 3 and e["rank"] == 1 and e["partition"] == "own"
+    assert e["per_rank_ms"] > 0 and e["index_ms"] > 0 and e["rows_ms"] > 0 and e["exchange_bytes"] == 3 * (4 * j["exchange"]["unit_ids_per_rank"] + 8 * 61)
+    assert e["partition_query"]["per_rank_ms"] > 0 and "bit-identical" in e["blocks_identical"]
+    assert j["config"]["parallelism"]["ranks"] == 3 and "EMULATED" in j["config"]["parallelism"]["what"]
+    assert j["kernels"]["launches_timed"][0] >= 1 and j["kernels"]["sketch_scan_spread"]["min_ms"] <= j["kernels"]["sketch_scan_ms"]
