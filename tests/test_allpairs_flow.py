@@ -222,8 +222,8 @@ def test_n_rank_orchestration_on_one_device_leaves_the_one_device_files(tmp_path
     fa = os.path.join(d, "fa")
     os.makedirs(fa)
     for i, (nm, codes, m) in enumerate(clade_genomes(3, 4, 150_000, seed=23)[:11]):          # 11 genomes: 4 ranks hold 3, 3, 3, 2
-        open(os.path.join(fa, "g%02d.fasta" % i), "w").write(fasta_text(codes, nm, n_mask=m))
-    open(os.path.join(fa, "g11_empty.fasta"), "w").write(">nothing\nACGTNNNN\n")                 # a sketch without ids among them
+        open(os.path.join(fa, "g%02d.fasta" % i), "wb").write(fasta_text(codes, nm, n_mask=m))
+    open(os.path.join(fa, "g11_empty.fasta"), "wb").write(b">nothing\nACGTNNNN\n")                 # a sketch without ids among them
     _run(["dist", "-L", "L3K10.shuf", "-o", "one", "--allpairs", "--keepskf", fa], d)
     want_sk = open(os.path.join(d, "one", "sharedk_ct.dat"), "rb").read()
     want_txt = open(os.path.join(d, "one", "distance.out"), "rb").read()
