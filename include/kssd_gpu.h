@@ -360,6 +360,20 @@ int kssd_gpu_dist_device_transposed(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, c
                                     uint32_t *d_shared_t, double *d_jaccard_t, double *d_mashd_t, double *d_contain_t,
                                     double *d_aafd_t, void *stream);
 
+/*
+ * The two halves of kssd_gpu_dist_device_transposed on their own, for a caller that computes its query rows in several calls
+ * (its own rows while the exchange is still under way, the others' behind it) and turns all of them around at once:
+ *   kssd_gpu_dist_counts_device        shared counts only, row-major by query: row q of [q_begin, q_end) at
+ *                                      d_counts[(q - q_begin) * n_ref ..] (kssd_gpu_dist_device without planes).
+ *   kssd_gpu_transpose_metrics_device  d_counts (rows [q_begin, q_end) as above) -> the five outputs, element (indexed sketch r,
+ *                                      query q) at r * out_pitch + (q - q_begin); |query| from d_qoff.
+ */
+int kssd_gpu_dist_counts_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32_t *d_qids, uint32_t n_qry, uint32_t q_begin,
+                                uint32_t q_end, uint32_t *d_counts, void *stream);
+int kssd_gpu_transpose_metrics_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, uint32_t n_qry, uint32_t q_begin, uint32_t q_end,
+                                      const uint32_t *d_counts, uint64_t out_pitch, uint32_t *d_shared_t, double *d_jaccard_t,
+                                      double *d_mashd_t, double *d_contain_t, double *d_aafd_t, void *stream);
+
 /* host-level convenience: HOST CSR in, HOST matrices out (caller-allocated, Q x R; planes may be NULL) */
 int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref,
                   const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,

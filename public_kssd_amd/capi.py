@@ -48,7 +48,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_index_status", "kssd_gpu_index_set_exact",
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
-    "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times",
+    "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times", "kssd_gpu_dist_counts_device", "kssd_gpu_transpose_metrics_device",
 ]
 
 
@@ -185,6 +185,8 @@ def gpu_lib():
         L.kssd_gpu_dist_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_transposed.argtypes = [vp, vp, vp, u32, u32, u32, vp, u64, vp, vp, vp, vp, vp, vp]
+        L.kssd_gpu_dist_counts_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp]
+        L.kssd_gpu_transpose_metrics_device.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_status.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
@@ -851,6 +853,16 @@ class GpuCtx:
         r * out_pitch + (q - q_begin) of every output; d_work: u32[(q_end - q_begin) x n_ref] scratch"""
         _gck(gpu_lib().kssd_gpu_dist_device_transposed(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_work), out_pitch,
                                                        _ptr(d_shared_t), _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
+
+    def dist_counts_device(self, d_qoff, d_qids, n_qry, q_begin, q_end, d_counts, stream=None):
+        """shared counts of rows [q_begin, q_end), row-major by query (rows behind the negative filter are walked flat)"""
+        _gck(gpu_lib().kssd_gpu_dist_counts_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_counts), stream))
+
+    def transpose_metrics_device(self, d_qoff, n_qry, q_begin, q_end, d_counts, out_pitch, d_shared_t, d_j=None, d_m=None, d_c=None, d_a=None,
+                                 stream=None):
+        """counts of rows [q_begin, q_end) -> the five outputs, element (indexed sketch r, query q) at r * out_pitch + (q - q_begin)"""
+        _gck(gpu_lib().kssd_gpu_transpose_metrics_device(self.h, _ptr(d_qoff), n_qry, q_begin, q_end, _ptr(d_counts), out_pitch, _ptr(d_shared_t),
+                                                         _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
 
     def set_union(self, ids, uniq=False):
         """ascending distinct ids (uniq: the ids that occur exactly once) -- kssd set -u / -q"""

@@ -181,6 +181,9 @@ struct kssd_gpu_ctx {
     uint32_t *d_hdr_cnt = nullptr;
     unsigned long long *d_hdr_pre = nullptr, *d_hdr_out = nullptr;
     size_t cap_hdr_cnt = 0, cap_hdr_pre = 0, cap_hdr_out = 0;
+    unsigned long long *d_lb = nullptr;  // per genome: the look-back word of the per-genome kernel's DIRECT output (kssd_dedup.inc: FuseArgs)
+    size_t cap_lb = 0;
+    uint32_t lb_serial = 0;
     bool resident_valid = false;  // the last sketch call was a host-level one: its batch is in d_in_packed / d_in_mask (kssd_gpu_sketch_again)
     bool results_valid = false;   // ... and it succeeded: d_b_off / d_b_ids hold ITS sketches (kssd_gpu_resident_put copies them)
     uint32_t ranges_off_calls = 0;  // successful calls the switch below still lasts for
@@ -322,7 +325,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag, c->d_lb};
     for (void *p : ptrs)
         if (p) hipFree(p);
     free(c->tok_args_saved);
@@ -628,6 +631,28 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
 #endif
     fx.id_bits = (uint32_t)(4 * (c->P.k - c->P.drlevel)) - c->P.pass_bits;
     fx.lds_keys = np;
+    // DIRECT: no genome of the batch needs the parts / ranges / global-memory paths (their results arrive in the staging regions
+    // and are gathered below) -- every workgroup of the per-genome launch writes its ids into the CSR itself
+    const bool direct = c->h_big.empty() && c->h_med.empty() && n_genomes > 0 && n_genomes <= DEDUP_DIRECT_MAX;
+    if (direct) {
+        const size_t before = c->cap_lb;
+        if ((rc = ensure(&c->d_lb, &c->cap_lb, (size_t)n_genomes)) != KSSD_OK) return rc;
+        if (c->cap_lb != before) {  // (fresh words carry no launch's serial number ...)
+            HIPCK(hipMemsetAsync(c->d_lb, 0, c->cap_lb * 8, s));
+            c->lb_serial = 0;
+        }
+        if (++c->lb_serial == 0) {  // (... and after 2^32 launches the numbers start over on cleared words)
+            HIPCK(hipMemsetAsync(c->d_lb, 0, c->cap_lb * 8, s));
+            c->lb_serial = 1;
+        }
+        fx.lb = c->d_lb;
+        fx.lb_serial = c->lb_serial;
+        fx.n_genomes = n_genomes;
+        fx.out_off = (unsigned long long *)d_out_off;
+        fx.out_ids = d_out_ids;
+        fx.out_pos = d_out_pos;
+        fx.out_cap = (unsigned long long)out_cap;
+    }
     auto bsort_slots = [&](uint32_t key_slots) -> uint32_t {  // what fits beside the key array and the kernel's static LDS
         if (!bsort) return 0u;
         const uint32_t bs = key_slots < DEDUP_BSORT_MAX ? key_slots : DEDUP_BSORT_MAX;
@@ -782,6 +807,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
                                (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, region);
         }
     }
+    if (direct) return KSSD_OK;  // (the per-genome launch has written the CSR)
     const dim3 ggrid(n_genomes, c->h_big.empty() ? (c->h_med.empty() ? 1u : 16u) : (n_genomes < 64u ? 256u : 16u));
     if (n_genomes <= 4096) {
         hipLaunchKernelGGL((sketch_gather_kernel<K, true>), ggrid, dim3(256), 0, s, (const unsigned long long *)c->d_reg_off, (const K *)regions,

@@ -172,27 +172,27 @@ class ShardedSearch:
             qoff, qids, Q = (off_l, ids_l, G) if q is None else q
             self.engine.dist_device(qoff, qids, Q, 0, Q, shared, *pl, stream=stream)
             return
-        # everybody's sketches as query rows against the OWN index; query g of the global numbering is column g of the rank's
-        # G rows (pitch w * G): the block leaves the device as the rows of the rank's own genomes
-        pitch = w * G
-        at = lambda t, col: None if t is None else t[col:]
-        tr = lambda qoff, qids, n, a, b, col: self.engine.dist_device_transposed(
-            qoff, qids, n, a, b, self._work, pitch, at(shared, col), *[at(t, col) for t in pl], stream=stream)
-        if self._overlap:               # own rows from the own sketches first, the foreign rows once the exchange is in
+        # everybody's sketches as query rows against the OWN index: counts row-major by query into the work array (the rank's own
+        # rows from its own sketches while the exchange is still under way, the others' behind it -- walked flat behind the negative
+        # filter), then ONE launch that turns all of them around: query g of the global numbering is column g of the rank's G rows
+        # (row g of the work array = query g of the global numbering, G counters wide)
+        cnt = lambda qoff, qids, n, a, b, row0: self.engine.dist_counts_device(qoff, qids, n, a, b, self._work[row0 * G:], stream=stream)
+        if self._overlap:
             if self._filter:
                 self.engine.index_set_filter(True, 0, G)                     # (the own block: rows 0 .. G of this call)
-            tr(off_l, ids_l, G, 0, G, r * G)
+            cnt(off_l, ids_l, G, 0, G, r * G)
             if self._filter:
                 self.engine.index_set_filter(True, r * G, (r + 1) * G)
             self._cur.wait_event(self._ev_gathered)
             roff, rids = self._gathered
             if r > 0:
-                tr(roff, rids, w * G, 0, r * G, 0)
+                cnt(roff, rids, w * G, 0, r * G, 0)
             if r + 1 < w:
-                tr(roff, rids, w * G, (r + 1) * G, w * G, (r + 1) * G)
+                cnt(roff, rids, w * G, (r + 1) * G, w * G, (r + 1) * G)
         else:
             roff, rids = self._gathered
-            tr(roff, rids, w * G, 0, w * G, 0)
+            cnt(roff, rids, w * G, 0, w * G, 0)
+        self.engine.transpose_metrics_device(roff, w * G, 0, w * G, self._work, w * G, shared, *pl, stream=stream)
 
     def step(self, off_l, ids_l, shared, planes, max_ids, q=None, stream=None, tstream=None, group=None):
         """index() + rows(): the exchange, the index build and the rows of one step; nothing is synchronised"""

@@ -90,6 +90,21 @@ class OracleEngine:
         self.rids = rids.numpy()[:int(self.roff[-1])].astype(np.uint32)
         assert int(self.roff[-1]) <= max_ids
 
+    def dist_counts_device(self, qoff, qids, n_qry, q_begin, q_end, counts, stream=None):
+        """kssd_gpu_dist_counts_device: row q of [q_begin, q_end) at (q - q_begin) * n_ref"""
+        qo = qoff.numpy()[:n_qry + 1].astype(np.uint64)
+        qi = qids.numpy()[:int(qo[-1])].astype(np.uint32)
+        full = ko.shared_counts(self.roff, self.rids, qo, qi)
+        counts.view(-1)[:(q_end - q_begin) * full.shape[1]] = torch.from_numpy(full[q_begin:q_end].astype(np.int32).reshape(-1))
+
+    def transpose_metrics_device(self, qoff, n_qry, q_begin, q_end, counts, out_pitch, shared_t, *planes, stream=None):
+        """kssd_gpu_transpose_metrics_device: element (indexed sketch r, query q) at r * out_pitch + (q - q_begin)"""
+        n_ref, rows = len(self.roff) - 1, q_end - q_begin
+        c = counts.view(-1)[:rows * n_ref].view(rows, n_ref)
+        flat = shared_t.view(-1)
+        for r in range(n_ref):
+            flat[r * out_pitch:r * out_pitch + rows] = c[:, r]
+
     def dist_device_transposed(self, qoff, qids, n_qry, q_begin, q_end, work, out_pitch, shared_t, *planes, stream=None):
         """kssd_gpu_dist_device_transposed: element (indexed sketch r, query q) at r * out_pitch + (q - q_begin)"""
         qo = qoff.numpy()[:n_qry + 1].astype(np.uint64)
