@@ -279,9 +279,13 @@ static void *warm_exchange(void *arg)
     return NULL;
 }
 
+/* set once the HIP runtime and a device's context are up (warm_device, or the first worker's context): from then on text buffers
+ * are page-locked */
+static volatile int g_runtime_ready;
+
 static void *warm_device(void *arg)
 {
-    kssd_gpu_warm_up(*(const int *)arg); /* (a missing device is reported by the call that needs it) */
+    if (kssd_gpu_warm_up(*(const int *)arg) == KSSD_OK) g_runtime_ready = 1; /* (a missing device is reported by the call that needs it) */
     return NULL;
 }
 
@@ -291,10 +295,35 @@ static void *warm_device(void *arg)
 
 /* One unit of stage-I work: a run of consecutive input files of one kind (FASTA or FASTQ), tokenised into one packed
  * batch in page-locked memory; a device worker sketches it and leaves the genomes' ids in the reference's file order. */
-typedef struct textbuf { /* the raw bytes of a job's files in page-locked memory, every file on a 16-byte boundary */
-    unsigned char *p;
+typedef struct textbuf { /* the raw bytes of a job's files, every file on a 16-byte boundary: page-locked memory once the HIP runtime is up */
+    unsigned char *p; /* (before that -- the first ~0.2 s of a command -- ordinary memory: the files are read while the runtime starts) */
     size_t cap;
+    int pinned;
 } textbuf;
+
+static void textbuf_release(textbuf *tx)
+{
+    if (tx->p) {
+        if (tx->pinned) kssd_gpu_host_free(tx->p);
+        else free(tx->p);
+    }
+    tx->p = NULL;
+    tx->cap = 0;
+}
+
+/* room for `need` bytes: page-locked when the runtime is up (DMA at PCIe speed), ordinary memory before (the copy to the device
+ * then goes through the runtime's staging buffers: 19 - 28 GB/s instead of 55, profiles/r02c_pinned_probe.txt -- on the first
+ * buffers of a command, whose alternative is to wait 0.1 - 0.2 s for hipInit before the first byte is read) */
+static void textbuf_fit(textbuf *tx, size_t need)
+{
+    const int want_pinned = g_runtime_ready;
+    if (tx->p && tx->cap >= need && (tx->pinned || !want_pinned)) return;
+    textbuf_release(tx);
+    tx->cap = need + need / 4 + 64;
+    tx->pinned = want_pinned;
+    tx->p = want_pinned ? kssd_gpu_host_alloc(tx->cap) : malloc(tx->cap);
+    if (!tx->p) die(ENOMEM, "out of %smemory (%zu bytes)", want_pinned ? "page-locked " : "", tx->cap);
+}
 
 typedef struct job {
     kssd_batch *b;      /* FASTQ with -Q > 0, -A: tokenised on the host */
@@ -315,6 +344,7 @@ typedef struct job {
 /* host threads a device worker uses for its own post-processing (file order of the ids): small teams, so that they do not
  * fight the tokenisers' team for the cores (each pthread has its own OpenMP pool, idle pools spin) */
 #define WORKER_OMP 4
+#define TEXT_BUFS_MAX 512 /* text buffers a command may hold at most (read-ahead while the runtime starts; the steady state: a handful) */
 
 /* A long plain input is not read into a host buffer of its size: slices of it go through a small ring of page-locked
  * buffers into the context's device text buffer -- STREAM_READERS slices are read at a time (pread, one thread each) while
@@ -761,6 +791,9 @@ typedef struct {
     kssd_batch **pool;          /* free batches */
     textbuf **tpool;            /* free text buffers */
     int n_pool, n_tpool, closed;
+    int n_text_keep;            /* text buffers of the steady state (one per worker + the ones being filled) */
+    int n_text_made;            /* text buffers in existence: the pool grows while the devices are not taking jobs yet (read-ahead) */
+    size_t text_bytes, text_budget; /* their bytes, and what the read-ahead may hold */
     const dist_opt *o;
     filelist *fl;
     uint32_t hashsize, hashlimit;
@@ -785,7 +818,13 @@ static void *worker_main(void *arg)
     pipeline *pl = w->pl;
     kssd_gpu_ctx *ctx = NULL;
     const double tc0 = now_s();
+    {
+        const int have = kssd_gpu_device_count();
+        if (have <= 0) die(ENODEV, "kssd_gpu_create: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
+        if (w->device >= have) die(ENODEV, "device %d of the list: only %d device(s) visible", w->device, have);
+    }
     gck(kssd_gpu_create_compact(&ctx, &pl->hdr, pl->accepted, pl->n_accepted, w->device), "kssd_gpu_create");
+    g_runtime_ready = 1;
     if (pl->o->abundance) gck(kssd_gpu_set_fastq_reads(ctx, 1), "kssd_gpu_set_fastq_reads");
     else if (pl->o->kmerqlty > 0 && pl->o->kmerqlty <= 127) gck(kssd_gpu_set_fastq_quality(ctx, pl->o->kmerqlty), "kssd_gpu_set_fastq_quality");
     pthread_mutex_lock(&pl->mu);
@@ -804,6 +843,7 @@ static void *worker_main(void *arg)
         if (!j) break;
         const double t0 = now_s();
         double tcall = 0;
+        textbuf *surplus = NULL;
         process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, pl->hashlimit, &tcall, pl->res ? pl->res[w->q] : NULL, pl->res ? pl->first[w->q] : 0u);
         const double dt = now_s() - t0;
         if (j->b) kssd_batch_clear(j->b);
@@ -813,7 +853,16 @@ static void *worker_main(void *arg)
         j->lines = NULL;
         pthread_mutex_lock(&pl->mu);
         if (j->b) pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
-        if (j->tx) pl->tpool[pl->n_tpool++] = j->tx;
+        if (j->tx) {
+            /* read-ahead buffers of ordinary memory are not kept once the runtime is up (the steady state runs on its few page-locked ones) */
+            if (!j->tx->pinned && g_runtime_ready && pl->n_text_made > pl->n_text_keep) {
+                pl->text_bytes -= j->tx->cap;
+                pl->n_text_made--;
+                surplus = j->tx;
+            } else {
+                pl->tpool[pl->n_tpool++] = j->tx;
+            }
+        }
         j->b = NULL;
         j->tx = NULL;
         free(j->toff);
@@ -825,6 +874,10 @@ static void *worker_main(void *arg)
         pl->t_call += tcall;
         pthread_cond_broadcast(&pl->cv);
         pthread_mutex_unlock(&pl->mu);
+        if (surplus) {
+            textbuf_release(surplus);
+            free(surplus);
+        }
     }
     const double td0 = now_s();
     for (int b = 0; b < STREAM_BUFS; b++)
@@ -950,13 +1003,8 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     printf("rand_id=%d\thalf_ctx_len=%d\thashsize=%d\thashlimit=%d\n", shuf.id, shuf.k, (int)d.hashsize, (int)d.hashlimit);
     kssd_shuf_hdr hdr = {shuf.id, shuf.k, shuf.subk, shuf.drlevel};
     const double t_shuf = now_s() - t_start;
-    if (warming) pthread_join(warm, NULL);
-    {
-        const int have = kssd_gpu_device_count();
-        if (have <= 0) die(ENODEV, "kssd_gpu_create: %s", kssd_gpu_strerror(KSSD_ERR_NO_DEVICE));
-        for (int i = 0; i < n_dev; i++)
-            if (o->devs[i] >= have) die(ENODEV, "device %d of the list: only %d device(s) visible", o->devs[i], have);
-    }
+    /* (nobody waits for the runtime here: the workers' context creation does, on their own threads, and the main thread reads the
+     * first inputs into ordinary memory meanwhile -- 0.1 - 0.2 s of hipInit used to stand in front of the first read) */
     pthread_t xwarm;
     xwarm_arg xa = {o->devs, n_dev};
     const int xwarming = o->allpairs && !o->fake_ranks && (n_dev > 1 || getenv("KSSD_EXCHANGE_ONE_RANK")) && pthread_create(&xwarm, NULL, warm_exchange, &xa) == 0;
@@ -996,9 +1044,16 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         if (!pl.pool[i]) die(ENOMEM, "out of memory");
     }
     pl.n_pool = n_batches;
-    pl.tpool = calloc((size_t)n_batches, sizeof *pl.tpool);
+    pl.tpool = calloc((size_t)TEXT_BUFS_MAX, sizeof *pl.tpool);
     for (int i = 0; i < n_batches; i++) pl.tpool[i] = calloc(1, sizeof(textbuf));
-    pl.n_tpool = n_batches;
+    pl.n_tpool = pl.n_text_made = pl.n_text_keep = n_batches;
+    {   /* read-ahead: what may wait in memory for the devices -- a quarter of the machine's free memory, 8 GiB at most (KSSD_READ_AHEAD, bytes) */
+        size_t budget = 8ull << 30;
+        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+        if (pages > 0 && psz > 0 && (size_t)pages * (size_t)psz / 4 < budget) budget = (size_t)pages * (size_t)psz / 4;
+        if (getenv("KSSD_READ_AHEAD")) budget = strtoull(getenv("KSSD_READ_AHEAD"), NULL, 10);
+        pl.text_budget = budget;
+    }
     worker *ws = calloc((size_t)n_workers, sizeof *ws);
     for (int i = 0; i < n_workers; i++) {
         ws[i].pl = &pl;
@@ -1092,16 +1147,23 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + r0]);
                     goto queue_job;
                 }
+                /* a free text buffer -- or, while the devices lag behind the readers (the runtime is still starting: nothing is
+                 * taken off the queues yet), one more: the inputs are read ahead into memory up to the budget */
                 pthread_mutex_lock(&pl.mu);
-                while (pl.n_tpool == 0) pthread_cond_wait(&pl.cv, &pl.mu);
-                textbuf *tx = pl.tpool[--pl.n_tpool];
-                pthread_mutex_unlock(&pl.mu);
-                if (tx->cap < at + 64) {
-                    if (tx->p) kssd_gpu_host_free(tx->p);
-                    tx->cap = at + at / 4 + 64;
-                    tx->p = kssd_gpu_host_alloc(tx->cap);
-                    if (!tx->p) die(ENOMEM, "out of page-locked memory (%zu bytes)", tx->cap);
+                while (pl.n_tpool == 0 && (pl.n_text_made >= TEXT_BUFS_MAX || pl.text_bytes + at > pl.text_budget)) pthread_cond_wait(&pl.cv, &pl.mu);
+                textbuf *tx;
+                if (pl.n_tpool) {
+                    tx = pl.tpool[--pl.n_tpool];
+                } else {
+                    tx = calloc(1, sizeof *tx);
+                    pl.n_text_made++;
                 }
+                pl.text_bytes -= tx->cap;
+                pthread_mutex_unlock(&pl.mu);
+                textbuf_fit(tx, at + 64);
+                pthread_mutex_lock(&pl.mu);
+                pl.text_bytes += tx->cap;
+                pthread_mutex_unlock(&pl.mu);
                 t0 = now_s();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
                 for (int i = r0; i < r1; i++) {
@@ -1170,6 +1232,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pthread_cond_broadcast(&pl.cv);
     pthread_mutex_unlock(&pl.mu);
     for (int i = 0; i < n_workers; i++) pthread_join(ws[i].th, NULL);
+    if (warming) pthread_join(warm, NULL);
     printf("\n");
     free(sc.accepted);
     const double t_sketched = now_s();
@@ -1207,7 +1270,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     for (int i = 0; i < pl.n_pool; i++) kssd_batch_destroy(pl.pool[i]);
     free(pl.pool);
     for (int i = 0; i < pl.n_tpool; i++) {
-        if (pl.tpool[i]->p) kssd_gpu_host_free(pl.tpool[i]->p);
+        textbuf_release(pl.tpool[i]);
         free(pl.tpool[i]);
     }
     free(pl.tpool);

@@ -782,29 +782,16 @@ int kssd_batch_fill_text(kssd_batch *b, uint32_t genome, int kind, const unsigne
 
 int kssd_slurp(const char *path, unsigned char **buf, size_t *len)
 {
-    gzFile g = gzopen(path, "rb");
-    if (!g) return KSSD_HOST_ERR_IO;
-    gzbuffer(g, 1 << 20);
-    size_t cap = 1 << 22, n = 0;
-    unsigned char *p = malloc(cap);
-    if (!p) { gzclose(g); return KSSD_HOST_ERR_NOMEM; }
-    for (;;) {
-        if (cap - n < (1u << 20)) {
-            cap += cap / 2;
-            unsigned char *q = realloc(p, cap);
-            if (!q) { free(p); gzclose(g); return KSSD_HOST_ERR_NOMEM; }
-            p = q;
-        }
-        size_t room = cap - n;
-        int r = gzread(g, p + n, (unsigned)(room > (1u << 30) ? (1u << 30) : room));
-        if (r < 0) { free(p); gzclose(g); return KSSD_HOST_ERR_IO; }
-        if (r == 0) break;
-        n += (size_t)r;
+    size_t cap = 0;
+    *buf = NULL;
+    const int rc = kssd_slurp_reuse(path, buf, &cap, len);
+    if (rc != KSSD_HOST_OK) {
+        free(*buf);
+        *buf = NULL;
+    } else if (!*buf) {
+        *buf = malloc(1); /* (an empty file: the callers free what they get) */
     }
-    gzclose(g);
-    *buf = p;
-    *len = n;
-    return KSSD_HOST_OK;
+    return rc;
 }
 
 /* the same into a buffer the caller keeps from file to file (grown when needed): no allocation, no page faults of fresh
@@ -816,6 +803,30 @@ int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t 
     unsigned char magic[2];
     ssize_t got = pread(fd, magic, 2, 0);
     *len = 0;
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && !getenv("KSSD_ZLIB_GUNZIP")) {
+        /* the compressed bytes whole, then host/kssd_inflate.c (KSSD_ZLIB_GUNZIP=1: zlib's gzread below, the decoder of rounds 1 - 4) */
+        struct stat zst;
+        if (fstat(fd, &zst) != 0) { close(fd); return KSSD_HOST_ERR_IO; }
+        size_t zcap = (size_t)zst.st_size + 4096, zn = 0;
+        unsigned char *z = malloc(zcap);
+        if (!z) { close(fd); return KSSD_HOST_ERR_NOMEM; }
+        for (;;) {
+            if (zcap - zn < 4096) {
+                unsigned char *q = realloc(z, zcap + zcap / 2);
+                if (!q) { free(z); close(fd); return KSSD_HOST_ERR_NOMEM; }
+                z = q;
+                zcap += zcap / 2;
+            }
+            const ssize_t r = read(fd, z + zn, zcap - zn);
+            if (r < 0) { free(z); close(fd); return KSSD_HOST_ERR_IO; }
+            if (r == 0) break;
+            zn += (size_t)r;
+        }
+        close(fd);
+        const int rc = kssd_gunzip_mem(z, zn, buf, cap, len);
+        free(z);
+        return rc;
+    }
     if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
         gzFile g = gzdopen(fd, "rb");
         if (!g) { close(fd); return KSSD_HOST_ERR_IO; }

@@ -95,6 +95,13 @@ int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t 
  * memory of the caller's choice -- e.g. a page-locked buffer the device tokeniser reads from */
 int kssd_file_probe(const char *path, int *is_gz, uint64_t *size);
 int kssd_read_into(const char *path, unsigned char *dst, size_t cap, size_t *len);
+/* gzip members in memory -> their bytes (what `zcat -fc` writes for the file, iseq2comem.c:187,196-208): *out / *cap as
+ * kssd_slurp_reuse keeps them (grown with realloc), *len the bytes.  Every member's CRC-32 and length are checked.
+ * KSSD_HOST_ERR_IO for a stream that is not gzip or is corrupt.  host/kssd_inflate.c: a table-driven inflate (up to three
+ * literals per lookup) -- sequence text is what zlib's byte loop is slowest on.  kssd_crc32: zlib's crc32(), by carry-less
+ * multiplication where the CPU has it. */
+int kssd_gunzip_mem(const unsigned char *in, size_t in_len, unsigned char **out, size_t *cap, size_t *len);
+uint32_t kssd_crc32(uint32_t crc, const unsigned char *p, size_t len);
 
 /* ---- derived constants (seq2co_global_var_initial iseq2comem.c:54-77, get_hashsz command_dist.c:217-236) */
 typedef struct kssd_derived {

@@ -1,0 +1,615 @@
+/* kssd_inflate.c -- gzip members in memory -> their bytes (RFC 1951 / 1952), written for the inputs of `kssd dist`.
+ *
+ * The reference reads every input through popen("zcat -fc <file>") (iseq2comem.c:187,196-208): one zcat process per file, a pipe, 64 KiB
+ * freads.  Round 1 - 4 of this build used zlib's gzread instead, and a directory of .fasta.gz genomes -- the form the reference's own
+ * test data comes in -- then spends 75 % of the command inside zlib's byte-at-a-time inflate on the host threads (0.3 GB/s of text
+ * per thread).  Sequence text is the worst case for that loop and the best case for a table-driven one: four or five symbols with
+ * codes of two or three bits, hardly any match.  This decoder reads the stream through a 64-bit bit buffer that is refilled
+ * eight bytes at a time, and its first-level table (11 bits) answers up to THREE literals per lookup; lengths and distances take
+ * one lookup each (second-level tables for the few codes longer than the first level).  The check value of a member (CRC-32) is
+ * computed with carry-less multiplications where the CPU has them (zlib 1.2.11's table loop runs at 1 GB/s: slower than the decoder).
+ * Own code throughout; what is reused are the published formats and the published folding constants of the CRC-32 polynomial. */
+#include "kssd_host.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h> /* crc32() as the fallback check */
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+/* ---- table entries ------------------------------------------------------------------------------------------------------------
+ * bits 0-3   code bits this entry consumes (first level: the whole code, or all codes of a literal group; second level: the bits
+ *            behind the first level's)
+ * bits 4-7   kind
+ * bits 8-31  payload: up to three literal bytes | base (16 bits) + extra-bit count (4 bits, at bit 24) | second-level table:
+ *            first entry (16 bits) + its index bits (4 bits, at bit 24) */
+enum { K_LIT1 = 0, K_LIT2 = 1, K_LIT3 = 2, K_BASE = 3, K_EOB = 4, K_SUB = 5, K_BAD = 6 };
+#define ENTRY(nbits, kind, payload) ((uint32_t)(nbits) | ((uint32_t)(kind) << 4) | ((uint32_t)(payload) << 8))
+#define E_NBITS(e) ((e) & 15u)
+#define E_KIND(e) (((e) >> 4) & 15u)
+#define E_BASE(e) (((e) >> 8) & 0xFFFFu)
+#define E_EXTRA(e) (((e) >> 24) & 15u)
+
+#define LIT_BITS 11
+#define DST_BITS 8
+#define LIT_ROOM ((1 << LIT_BITS) + (1 << 15)) /* first level + every second level a set of codes can ask for */
+#define DST_ROOM ((1 << DST_BITS) + (1 << 12))
+
+typedef struct {
+    uint32_t lit[LIT_ROOM];
+    uint32_t lit_one[1 << LIT_BITS];   /* the first level without literal groups: what the careful path (one symbol at a time) looks up */
+    uint32_t dst[DST_ROOM];
+    uint32_t fixed_lit[1 << LIT_BITS]; /* the fixed codes (at most 9 bits: no second level) */
+    uint32_t fixed_lit_one[1 << LIT_BITS];
+    uint32_t fixed_dst[1 << DST_BITS];
+    int fixed_ready;
+} inflate_tabs;
+
+static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t dst_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t dst_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+static uint32_t rev_bits(uint32_t v, int n)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < n; i++) r |= ((v >> i) & 1u) << (n - 1 - i);
+    return r;
+}
+
+/* what symbol `sym` of the literal/length (dist = 0) or distance (dist = 1) alphabet decodes to, in a code of nbits bits */
+static uint32_t leaf(int dist, int sym, int nbits)
+{
+    if (dist) return sym < 30 ? ENTRY(nbits, K_BASE, dst_base[sym] | ((uint32_t)dst_extra[sym] << 16)) : ENTRY(nbits, K_BAD, 0);
+    if (sym < 256) return ENTRY(nbits, K_LIT1, sym);
+    if (sym == 256) return ENTRY(nbits, K_EOB, 0);
+    if (sym < 286) return ENTRY(nbits, K_BASE, len_base[sym - 257] | ((uint32_t)len_extra[sym - 257] << 16));
+    return ENTRY(nbits, K_BAD, 0);
+}
+
+/* canonical code lengths -> decoding tables.  -1: the lengths oversubscribe the code space (or need more room than there is) */
+static int build_tables(const uint8_t *lens, int n_sym, int dist, uint32_t *tab, int main_bits, int room, uint32_t *single /* literal/length: the first level before grouping */)
+{
+    int count[16] = {0};
+    for (int s = 0; s < n_sym; s++) count[lens[s]]++;
+    count[0] = 0;
+    int left = 1;
+    uint32_t next_code[16];
+    uint32_t code = 0;
+    for (int l = 1; l <= 15; l++) {
+        left = left * 2 - count[l];
+        if (left < 0) return -1;
+        code = (code + (uint32_t)count[l - 1]) << 1;
+        next_code[l] = code;
+    }
+    const int main_n = 1 << main_bits;
+    for (int i = 0; i < main_n; i++) tab[i] = ENTRY(0, K_BAD, 0); /* (an incomplete set: a code nobody owns is an error when it is met) */
+    uint8_t sub_bits[1 << LIT_BITS];
+    memset(sub_bits, 0, (size_t)main_n);
+    uint16_t rev[288];
+    for (int s = 0; s < n_sym; s++) {
+        const int l = lens[s];
+        if (!l) continue;
+        const uint32_t r = rev_bits(next_code[l]++, l);
+        rev[s] = (uint16_t)r;
+        if (l <= main_bits) {
+            const uint32_t e = leaf(dist, s, l);
+            for (uint32_t i = r; i < (uint32_t)main_n; i += 1u << l) tab[i] = e;
+        } else {
+            const uint32_t p = r & (uint32_t)(main_n - 1);
+            if (l - main_bits > sub_bits[p]) sub_bits[p] = (uint8_t)(l - main_bits);
+        }
+    }
+    int next = main_n;
+    for (int p = 0; p < main_n; p++) {
+        if (!sub_bits[p]) continue;
+        if (next + (1 << sub_bits[p]) > room) return -1;
+        tab[p] = ENTRY(main_bits, K_SUB, (uint32_t)next | ((uint32_t)sub_bits[p] << 16));
+        for (int i = 0; i < (1 << sub_bits[p]); i++) tab[next + i] = ENTRY(0, K_BAD, 0);
+        next += 1 << sub_bits[p];
+    }
+    for (int s = 0; s < n_sym; s++) {
+        const int l = lens[s];
+        if (l <= main_bits) continue;
+        const uint32_t p = rev[s] & (uint32_t)(main_n - 1), hi = rev[s] >> main_bits;
+        const uint32_t base = E_BASE(tab[p]), sb = E_EXTRA(tab[p]);
+        const uint32_t e = leaf(dist, s, l - main_bits);
+        for (uint32_t i = hi; i < (1u << sb); i += 1u << (l - main_bits)) tab[base + i] = e;
+    }
+    if (!dist) {
+        /* literal groups: a first-level slot whose bits hold two or three whole literal codes answers all of them at once */
+        memcpy(single, tab, (size_t)main_n * sizeof(uint32_t));
+        for (int i = 0; i < main_n; i++) {
+            const uint32_t e1 = single[i];
+            if (E_KIND(e1) != K_LIT1) continue;
+            const uint32_t n1 = E_NBITS(e1);
+            const uint32_t e2 = single[(uint32_t)i >> n1]; /* the unknown bits above read as zeros: right for every code that fits the known ones */
+            const uint32_t n2 = E_NBITS(e2);
+            if (E_KIND(e2) != K_LIT1 || n1 + n2 > (uint32_t)main_bits) continue;
+            const uint32_t e3 = single[(uint32_t)i >> (n1 + n2)];
+            const uint32_t n3 = E_NBITS(e3);
+            if (E_KIND(e3) == K_LIT1 && n1 + n2 + n3 <= (uint32_t)main_bits)
+                tab[i] = ENTRY(n1 + n2 + n3, K_LIT3, E_BASE(e1) | (E_BASE(e2) << 8) | (E_BASE(e3) << 16));
+            else
+                tab[i] = ENTRY(n1 + n2, K_LIT2, E_BASE(e1) | (E_BASE(e2) << 8));
+        }
+    }
+    return 0;
+}
+
+/* ---- the bit reader -------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const unsigned char *in, *in_end;
+    uint64_t bb; /* bits not consumed yet, the next one at bit 0 */
+    int bc;      /* how many of them are real */
+} bitr;
+
+static inline uint64_t load64(const unsigned char *p)
+{
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v; /* (x86-64, little endian: the build's only host) */
+}
+
+/* careful refill (the stream's last bytes): whole bytes while they fit */
+static inline void refill_safe(bitr *b)
+{
+    while (b->bc < 56 && b->in < b->in_end) { /* (at most 63 bits: the fast path shifts by the count) */
+        b->bb |= (uint64_t)*b->in++ << b->bc;
+        b->bc += 8;
+    }
+}
+static inline int take_bits(bitr *b, int n, uint32_t *v)
+{
+    if (b->bc < n) {
+        refill_safe(b);
+        if (b->bc < n) return -1; /* the stream ends inside a field */
+    }
+    *v = (uint32_t)(b->bb & ((1ull << n) - 1));
+    b->bb >>= n;
+    b->bc -= n;
+    return 0;
+}
+
+typedef struct {
+    unsigned char *out; /* grown with realloc */
+    size_t cap, len;
+} outbuf;
+
+static int out_room(outbuf *o, size_t more)
+{
+    if (o->len + more <= o->cap) return 0;
+    size_t nc = o->cap + o->cap / 2 + more + (1u << 20);
+    unsigned char *q = (unsigned char *)realloc(o->out, nc);
+    if (!q) return -1;
+    o->out = q;
+    o->cap = nc;
+    return 0;
+}
+
+#define FAST_OUT_MARGIN 336 /* the longest match (258) + what the copies and the literal stores may write beyond their last byte */
+
+/* one block's symbols (its tables are built): returns 0 at the end-of-block code, -1 on a corrupt stream, -2 out of memory */
+static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32_t *lit_one, const uint32_t *dst, size_t member_start)
+{
+    const uint64_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DST_BITS) - 1;
+    for (;;) {
+        /* ---- fast: at least 16 input bytes and FAST_OUT_MARGIN output bytes to spare, no check per symbol ---- */
+        if (b->in_end - b->in >= 16 && o->cap - o->len >= FAST_OUT_MARGIN) {
+            const unsigned char *in = b->in, *const in_fast = b->in_end - 16;
+            unsigned char *out = o->out + o->len, *const out_fast = o->out + o->cap - FAST_OUT_MARGIN;
+            unsigned char *const out_min = o->out + member_start;
+            uint64_t bb = b->bb;
+            int bc = b->bc;
+            int rc = 1; /* 1: ran out of margin, 0: end of block, -1: corrupt */
+#define REFILL()                        \
+    do {                                \
+        bb |= load64(in) << bc;         \
+        in += (63 - bc) >> 3;           \
+        bc |= 56;                       \
+    } while (0)
+#define PUT_GROUP()                     \
+    do {                                \
+        const uint32_t w = e >> 8;      \
+        memcpy(out, &w, 4);             \
+        out += E_KIND(e) + 1;           \
+        bb >>= E_NBITS(e);              \
+        bc -= (int)E_NBITS(e);          \
+    } while (0)
+            while (in <= in_fast && out <= out_fast) {
+                REFILL(); /* eight bytes over the top of what is left, whole bytes accepted: 56 - 63 real bits afterwards */
+                uint32_t e = lit[bb & lmask];
+                /* up to three lookups of literals (33 bits at most) before anything else is looked at */
+                if (E_KIND(e) <= K_LIT3) {
+                    PUT_GROUP();
+                    e = lit[bb & lmask];
+                    if (E_KIND(e) <= K_LIT3) {
+                        PUT_GROUP();
+                        e = lit[bb & lmask];
+                        if (E_KIND(e) <= K_LIT3) {
+                            PUT_GROUP();
+                            continue;
+                        }
+                    }
+                }
+                /* at least 23 real bits left: a length code of up to 15 bits and its 5 extra bits */
+                if (E_KIND(e) == K_SUB) {
+                    bb >>= LIT_BITS;
+                    bc -= LIT_BITS;
+                    e = lit[E_BASE(e) + (bb & ((1u << E_EXTRA(e)) - 1))];
+                }
+                bb >>= E_NBITS(e);
+                bc -= (int)E_NBITS(e);
+                if (E_KIND(e) == K_LIT1) {
+                    *out++ = (unsigned char)(e >> 8);
+                    continue;
+                }
+                if (E_KIND(e) != K_BASE) {
+                    rc = E_KIND(e) == K_EOB ? 0 : -1;
+                    break;
+                }
+                const uint32_t len = E_BASE(e) + (uint32_t)(bb & ((1u << E_EXTRA(e)) - 1));
+                bb >>= E_EXTRA(e);
+                bc -= (int)E_EXTRA(e);
+                REFILL();
+                uint32_t d = dst[bb & dmask];
+                if (E_KIND(d) == K_SUB) {
+                    bb >>= DST_BITS;
+                    bc -= DST_BITS;
+                    d = dst[E_BASE(d) + (bb & ((1u << E_EXTRA(d)) - 1))];
+                }
+                if (E_KIND(d) != K_BASE) { rc = -1; break; }
+                bb >>= E_NBITS(d);
+                bc -= (int)E_NBITS(d);
+                const uint32_t dist = E_BASE(d) + (uint32_t)(bb & ((1u << E_EXTRA(d)) - 1));
+                bb >>= E_EXTRA(d);
+                bc -= (int)E_EXTRA(d);
+                if ((size_t)(out - out_min) < dist) { rc = -1; break; } /* before the member's first byte */
+                const unsigned char *src = out - dist;
+                unsigned char *const end = out + len;
+                if (dist >= 16) { /* the common case first, without a loop: a match of up to 16 bytes is one copy */
+                    memcpy(out, src, 16);
+                    if (len > 16) {
+                        out += 16;
+                        src += 16;
+                        do {
+                            memcpy(out, src, 16);
+                            out += 16;
+                            src += 16;
+                        } while (out < end);
+                    }
+                    out = end;
+                } else if (dist >= 8) {
+                    do {
+                        memcpy(out, src, 8);
+                        out += 8;
+                        src += 8;
+                    } while (out < end);
+                    out = end;
+                } else if (dist == 1) {
+                    memset(out, *src, len);
+                    out = end;
+                } else {
+                    do { *out++ = *src++; } while (out < end);
+                }
+            }
+#undef REFILL
+#undef PUT_GROUP
+            /* the bit buffer may hold bytes beyond what the symbols used: give whole unused bytes back (bc counts real bits only) */
+            b->in = in;
+            b->bb = bb;
+            b->bc = bc;
+            o->len = (size_t)(out - o->out);
+            if (rc <= 0) return rc;
+        }
+        /* ---- careful: one symbol, every read and write checked ---- */
+        if (out_room(o, FAST_OUT_MARGIN + 8) != 0) return -2;
+        refill_safe(b);
+        uint32_t e = lit_one[b->bb & lmask]; /* (second levels are shared: they live behind the first level of `lit`) */
+        if (E_KIND(e) == K_SUB) {
+            if (b->bc < LIT_BITS) return -1;
+            b->bb >>= LIT_BITS;
+            b->bc -= LIT_BITS;
+            refill_safe(b);
+            e = lit[E_BASE(e) + (b->bb & ((1u << E_EXTRA(e)) - 1))];
+        }
+        if ((int)E_NBITS(e) > b->bc) return -1;
+        b->bb >>= E_NBITS(e);
+        b->bc -= (int)E_NBITS(e);
+        if (E_KIND(e) == K_LIT1) {
+            o->out[o->len++] = (unsigned char)(e >> 8);
+            continue;
+        }
+        if (E_KIND(e) == K_EOB) return 0;
+        if (E_KIND(e) != K_BASE) return -1;
+        uint32_t x;
+        if (take_bits(b, (int)E_EXTRA(e), &x)) return -1;
+        const uint32_t len = E_BASE(e) + x;
+        refill_safe(b);
+        uint32_t d = dst[b->bb & dmask];
+        if (E_KIND(d) == K_SUB) {
+            if (b->bc < DST_BITS) return -1;
+            b->bb >>= DST_BITS;
+            b->bc -= DST_BITS;
+            refill_safe(b);
+            d = dst[E_BASE(d) + (b->bb & ((1u << E_EXTRA(d)) - 1))];
+        }
+        if (E_KIND(d) != K_BASE || (int)E_NBITS(d) > b->bc) return -1;
+        b->bb >>= E_NBITS(d);
+        b->bc -= (int)E_NBITS(d);
+        if (take_bits(b, (int)E_EXTRA(d), &x)) return -1;
+        const uint32_t dist = E_BASE(d) + x;
+        if (o->len - member_start < dist) return -1;
+        for (uint32_t i = 0; i < len; i++, o->len++) o->out[o->len] = o->out[o->len - dist];
+    }
+}
+
+/* ---- blocks -------------------------------------------------------------------------------------------------------------------- */
+static void fixed_tables(inflate_tabs *t)
+{
+    if (t->fixed_ready) return;
+    uint8_t lens[288];
+    for (int i = 0; i < 144; i++) lens[i] = 8;
+    for (int i = 144; i < 256; i++) lens[i] = 9;
+    for (int i = 256; i < 280; i++) lens[i] = 7;
+    for (int i = 280; i < 288; i++) lens[i] = 8;
+    build_tables(lens, 288, 0, t->fixed_lit, LIT_BITS, 1 << LIT_BITS, t->fixed_lit_one);
+    for (int i = 0; i < 32; i++) lens[i] = 5;
+    build_tables(lens, 32, 1, t->fixed_dst, DST_BITS, 1 << DST_BITS, NULL);
+    t->fixed_ready = 1;
+}
+
+/* the code lengths of a dynamic block (RFC 1951 3.2.7) */
+static int read_dynamic(bitr *b, inflate_tabs *t)
+{
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint32_t hlit, hdist, hclen, v;
+    if (take_bits(b, 5, &hlit) || take_bits(b, 5, &hdist) || take_bits(b, 4, &hclen)) return -1;
+    hlit += 257;
+    hdist += 1;
+    hclen += 4;
+    if (hlit > 286 || hdist > 30) return -1;
+    uint8_t cl[19] = {0};
+    for (uint32_t i = 0; i < hclen; i++) {
+        if (take_bits(b, 3, &v)) return -1;
+        cl[order[i]] = (uint8_t)v;
+    }
+    /* the code-length code: at most 7 bits, one flat table */
+    uint16_t ct[128]; /* symbol << 4 | bits; 0 = no code */
+    {
+        int count[8] = {0};
+        for (int s = 0; s < 19; s++) count[cl[s]]++;
+        count[0] = 0;
+        uint32_t next[8], code = 0;
+        int left = 1;
+        for (int l = 1; l <= 7; l++) {
+            left = left * 2 - count[l];
+            if (left < 0) return -1;
+            code = (code + (uint32_t)count[l - 1]) << 1;
+            next[l] = code;
+        }
+        memset(ct, 0, sizeof ct);
+        for (int s = 0; s < 19; s++) {
+            const int l = cl[s];
+            if (!l) continue;
+            const uint32_t r = rev_bits(next[l]++, l);
+            for (uint32_t i = r; i < 128; i += 1u << l) ct[i] = (uint16_t)((s << 4) | l);
+        }
+    }
+    uint8_t lens[286 + 30];
+    uint32_t n = 0;
+    const uint32_t total = hlit + hdist;
+    while (n < total) {
+        refill_safe(b);
+        const uint16_t c = ct[b->bb & 127];
+        const int l = c & 15, s = c >> 4;
+        if (!l || l > b->bc) return -1;
+        b->bb >>= l;
+        b->bc -= l;
+        if (s < 16) {
+            lens[n++] = (uint8_t)s;
+            continue;
+        }
+        uint32_t rep, val = 0;
+        if (s == 16) {
+            if (n == 0 || take_bits(b, 2, &rep)) return -1;
+            rep += 3;
+            val = lens[n - 1];
+        } else if (s == 17) {
+            if (take_bits(b, 3, &rep)) return -1;
+            rep += 3;
+        } else {
+            if (take_bits(b, 7, &rep)) return -1;
+            rep += 11;
+        }
+        if (n + rep > total) return -1;
+        while (rep--) lens[n++] = (uint8_t)val;
+    }
+    if (lens[256] == 0) return -1; /* no end-of-block code */
+    if (build_tables(lens, (int)hlit, 0, t->lit, LIT_BITS, LIT_ROOM, t->lit_one)) return -1;
+    if (build_tables(lens + hlit, (int)hdist, 1, t->dst, DST_BITS, DST_ROOM, NULL)) return -1;
+    return 0;
+}
+
+/* one deflate stream (the body of a gzip member); the reader ends behind its last block, byte-aligned */
+static int inflate_stream(bitr *b, outbuf *o, inflate_tabs *t)
+{
+    const size_t member_start = o->len;
+    for (;;) {
+        uint32_t last, type;
+        if (take_bits(b, 1, &last) || take_bits(b, 2, &type)) return -1;
+        if (type == 0) { /* stored: back to a byte boundary, LEN / NLEN, the bytes */
+            b->bb >>= b->bc & 7;
+            b->bc -= b->bc & 7;
+            uint32_t len, nlen;
+            if (take_bits(b, 16, &len) || take_bits(b, 16, &nlen) || (len ^ nlen) != 0xFFFFu) return -1;
+            if (out_room(o, len)) return -2;
+            uint32_t got = 0;
+            while (got < len && b->bc >= 8) { /* (whole bytes the bit buffer holds already) */
+                o->out[o->len++] = (unsigned char)b->bb;
+                b->bb >>= 8;
+                b->bc -= 8;
+                got++;
+            }
+            if ((size_t)(b->in_end - b->in) < len - got) return -1;
+            memcpy(o->out + o->len, b->in, len - got);
+            b->in += len - got;
+            o->len += len - got;
+        } else if (type == 1) {
+            fixed_tables(t);
+            const int rc = inflate_symbols(b, o, t->fixed_lit, t->fixed_lit_one, t->fixed_dst, member_start);
+            if (rc) return rc;
+        } else if (type == 2) {
+            if (read_dynamic(b, t)) return -1;
+            const int rc = inflate_symbols(b, o, t->lit, t->lit_one, t->dst, member_start);
+            if (rc) return rc;
+        } else {
+            return -1;
+        }
+        if (last) break;
+    }
+    /* whole unread bytes go back to the input, the bits of the last byte are dropped */
+    b->bb >>= b->bc & 7;
+    b->bc -= b->bc & 7;
+    b->in -= b->bc >> 3;
+    b->bb = 0;
+    b->bc = 0;
+    return 0;
+}
+
+/* ---- CRC-32 (gzip's check value) -------------------------------------------------------------------------------------------------
+ * Folding by carry-less multiplication (V. Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ
+ * Instruction", Intel 2009): four 128-bit lanes folded 512 bits at a time, then down to 128, 64 and 32 bits; the constants are
+ * x^n mod P for the bit-reflected polynomial 0x1DB710641.  Whatever the fold does not take (the first bytes up to a multiple of
+ * 16, a buffer below 64 bytes) goes through zlib's crc32().  Checked against zlib's on random buffers by tests/test_inflate.py. */
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_fold(uint32_t crc, const unsigned char *p, size_t len /* >= 64, a multiple of 16 */)
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596, 0x0154442bd4);
+    const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009e, 0x01751997d0);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124);
+    const __m128i poly = _mm_set_epi64x(0x01f7011641, 0x01db710641);
+    __m128i x1 = _mm_loadu_si128((const __m128i *)(p + 0)), x2 = _mm_loadu_si128((const __m128i *)(p + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i *)(p + 32)), x4 = _mm_loadu_si128((const __m128i *)(p + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    p += 64;
+    len -= 64;
+    while (len >= 64) {
+        __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        __m128i a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11);
+        x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11);
+        x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, a1), _mm_loadu_si128((const __m128i *)(p + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, a2), _mm_loadu_si128((const __m128i *)(p + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, a3), _mm_loadu_si128((const __m128i *)(p + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, a4), _mm_loadu_si128((const __m128i *)(p + 48)));
+        p += 64;
+        len -= 64;
+    }
+    /* four lanes into one */
+    __m128i a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), x2);
+    a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), x3);
+    a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+    x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), x4);
+    while (len >= 16) {
+        a = _mm_clmulepi64_si128(x1, k3k4, 0x00);
+        x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k3k4, 0x11), a), _mm_loadu_si128((const __m128i *)p));
+        p += 16;
+        len -= 16;
+    }
+    /* 128 -> 64 bits */
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i x = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x);
+    /* 64 -> 32 bits */
+    x = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, mask32);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(x1, k5, 0x00), x);
+    /* Barrett reduction */
+    x = _mm_and_si128(x1, mask32);
+    x = _mm_clmulepi64_si128(x, poly, 0x10);
+    x = _mm_and_si128(x, mask32);
+    x = _mm_clmulepi64_si128(x, poly, 0x00);
+    x1 = _mm_xor_si128(x1, x);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+
+uint32_t kssd_crc32(uint32_t crc, const unsigned char *p, size_t len)
+{
+#if defined(__x86_64__)
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    if (have && len >= 64) {
+        const size_t body = len & ~(size_t)15;
+        crc = ~crc32_fold(~crc, p, body);
+        p += body;
+        len -= body;
+    }
+#endif
+    while (len) { /* (zlib takes its lengths as 32-bit numbers) */
+        const size_t n = len > (1u << 30) ? (1u << 30) : len;
+        crc = (uint32_t)crc32(crc, p, (uInt)n);
+        p += n;
+        len -= n;
+    }
+    return crc;
+}
+
+/* ---- gzip members ---------------------------------------------------------------------------------------------------------------- */
+int kssd_gunzip_mem(const unsigned char *in, size_t in_len, unsigned char **out, size_t *cap, size_t *len)
+{
+    if (!in || !out || !cap || !len) return KSSD_HOST_ERR_PARAM;
+    inflate_tabs *t = (inflate_tabs *)malloc(sizeof *t);
+    if (!t) return KSSD_HOST_ERR_NOMEM;
+    t->fixed_ready = 0;
+    outbuf o = {*out, *cap, 0};
+    /* the last member's trailer states its length modulo 2^32: room for it up front (a single member below 4 GiB: exact) */
+    if (in_len >= 18) {
+        const size_t isize = (size_t)in[in_len - 4] | ((size_t)in[in_len - 3] << 8) | ((size_t)in[in_len - 2] << 16) | ((size_t)in[in_len - 1] << 24);
+        if (isize < ((size_t)1 << 32) - 1 && out_room(&o, isize + FAST_OUT_MARGIN + 64)) { free(t); return KSSD_HOST_ERR_NOMEM; }
+    }
+    size_t at = 0;
+    int rc = KSSD_HOST_OK, members = 0;
+    while (at < in_len) {
+        /* (zcat accepts zero bytes behind the last member -- tape blocks -- and so does this) */
+        if (members && in[at] == 0) { at++; continue; }
+        if (in_len - at < 18 || in[at] != 0x1f || in[at + 1] != 0x8b || in[at + 2] != 8 || (in[at + 3] & 0xE0)) { rc = KSSD_HOST_ERR_IO; break; }
+        const int flg = in[at + 3];
+        size_t p = at + 10;
+        if (flg & 4) { /* FEXTRA */
+            if (p + 2 > in_len) { rc = KSSD_HOST_ERR_IO; break; }
+            p += 2 + ((size_t)in[p] | ((size_t)in[p + 1] << 8));
+        }
+        for (int k = 0; k < 2; k++) /* FNAME, FCOMMENT: zero-terminated */
+            if (flg & (k ? 16 : 8)) {
+                while (p < in_len && in[p]) p++;
+                p++;
+            }
+        if (flg & 2) p += 2; /* FHCRC */
+        if (p + 8 > in_len) { rc = KSSD_HOST_ERR_IO; break; }
+        bitr b = {in + p, in + in_len, 0, 0};
+        const size_t start = o.len;
+        const int r = inflate_stream(&b, &o, t);
+        if (r) { rc = r == -2 ? KSSD_HOST_ERR_NOMEM : KSSD_HOST_ERR_IO; break; }
+        if ((size_t)(b.in_end - b.in) < 8) { rc = KSSD_HOST_ERR_IO; break; }
+        const uint32_t want_crc = (uint32_t)b.in[0] | ((uint32_t)b.in[1] << 8) | ((uint32_t)b.in[2] << 16) | ((uint32_t)b.in[3] << 24);
+        const uint32_t want_len = (uint32_t)b.in[4] | ((uint32_t)b.in[5] << 8) | ((uint32_t)b.in[6] << 16) | ((uint32_t)b.in[7] << 24);
+        if ((uint32_t)(o.len - start) != want_len || kssd_crc32(0, o.out + start, o.len - start) != want_crc) { rc = KSSD_HOST_ERR_IO; break; }
+        at = (size_t)(b.in - in) + 8;
+        members++;
+    }
+    if (rc == KSSD_HOST_OK && !members) rc = KSSD_HOST_ERR_IO;
+    free(t);
+    *out = o.out; /* (the caller's buffer may have moved even when the stream turns out corrupt) */
+    *cap = o.cap;
+    *len = rc == KSSD_HOST_OK ? o.len : 0;
+    return rc;
+}
