@@ -62,7 +62,7 @@ def _run_ours(args, cwd, env_extra=None, timeout=900):
     return dt, (None if not timing else timing[0] if len(timing) == 1 else {t["kssd_timing"]: t for t in timing})
 
 
-def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_search=1024):
+def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_search=1024, e2e_search4k=4096):
     """The CPU comparators and the end-to-end leg, on the same inputs in the same run:
       port       oracle/kssd_oracle.c (our restatement) sketching the sample texts, OpenMP over genomes
       reference  oracle/_ref/kssd (the real reference, when the snapshot carries it): stage I on FASTA files in tmpfs,
@@ -237,6 +237,42 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
                     b = open(os.path.join(d, "ref_dist", fn), "rb").read()
                     assert a == b, "kssd CLI %s differs from the reference's" % fn
                 out["end_to_end"]["search"]["byte_identical_to_reference"] = "sharedk_ct.dat and distance.out on the reference's sketch directory"
+                out["end_to_end"]["search"]["speedup_vs_reference"] = t_srch / out["end_to_end"]["search"]["seconds"]
+                # ---- the same search where start-up no longer dominates: 4 x the sketches (the directory above under four names each),
+                # both binaries on ONE sketch directory, distance.out compared byte for byte (1.9 GB of text at 4 096 x 4 096)
+                n4 = e2e_search4k if ns >= 256 else 0
+                if n4 >= 2 * ns:
+                    import filecmp
+                    for junk in ("ref_idx", "ref_dist0", "ref_dist", "our_dist_on_ref", "our_dist0", "our_dist", "our_dist_k"):
+                        shutil.rmtree(os.path.join(d, junk), ignore_errors=True)      # (the 2 GiB mco.index and the first leg's reports)
+                    S = K.SketchSet.read(os.path.join(d, rs))
+                    times = n4 // ns
+                    sizes = np.diff(S.off)
+                    big = K.SketchSet(S.shuf_id, S.kmerlen, S.dim_rd_len, S.comp_num,
+                                      ["x%02d/%s" % (r, os.path.basename(nm)) for r in range(times) for nm in S.names],
+                                      np.concatenate([[0], np.cumsum(np.tile(sizes, times))]).astype(np.uint64), np.tile(S.ids, times))
+                    big.write(os.path.join(d, "sk4k"), K.derive(10, 6, 3).hashsize, slot_order=False)
+                    nq = times * ns
+                    dt4a, _ = _run_ours(["dist", "-p", cores, "-r", "sk4k", "-o", "our_d4k0", "sk4k"], d)
+                    shutil.rmtree(os.path.join(d, "our_d4k0"), ignore_errors=True)
+                    dt4, tm4 = _run_ours(["dist", "-p", cores, "-r", "sk4k", "-o", "our_d4k", "sk4k"], d, {"KSSD_TIMING": "1"})
+                    t0 = time.time()
+                    ko.run_ref(["dist", "-p", p_srch, "-o", "ref_idx4k", "sk4k"], cwd=d, timeout=1800)
+                    t_idx4 = time.time() - t0
+                    t0 = time.time()
+                    ko.run_ref(["dist", "-p", p_srch, "-r", "ref_idx4k", "-o", "ref_d4k", "sk4k"], cwd=d, timeout=1800)
+                    t_ref4 = time.time() - t0
+                    same = filecmp.cmp(os.path.join(d, "our_d4k", "distance.out"), os.path.join(d, "ref_d4k", "distance.out"), shallow=False)
+                    assert same, "kssd CLI distance.out differs from the reference's at %d x %d" % (nq, nq)
+                    mb = os.path.getsize(os.path.join(d, "our_d4k", "distance.out")) >> 20
+                    out["end_to_end"]["search_4096"] = {
+                        "value": nq * nq / min(dt4, dt4a), "unit": "pairs/s", "seconds": min(dt4, dt4a), "seconds_runs": [dt4a, dt4], "stages": tm4,
+                        "reference_seconds": t_ref4, "reference_stage2_seconds": t_idx4, "reference_cores": p_srch,
+                        "speedup_vs_reference": t_ref4 / min(dt4, dt4a),
+                        "byte_identical_to_reference": "distance.out (%d MB)" % mb,
+                        "what": "`kssd dist -r <sketches> -o <dir> <sketches>` at %d x %d (the %d sketches above under %d names each): wall time of the "
+                                "command incl. process start and the %d MB of distance.out, the better of two runs; the reference binary on the same "
+                                "directory, one run, its stage II (%.1f s) not counted" % (nq, nq, ns, times, mb, t_idx4)}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out
@@ -867,6 +903,7 @@ def main():
     ap.add_argument("--rank", type=int, default=0, help="--emulate-world: which rank this GPU plays")
     ap.add_argument("--e2e-files", type=int, default=1024, help="files of the end-to-end / reference leg (the CPU sample under several names)")
     ap.add_argument("--e2e-search", type=int, default=1024, help="sketches of the end-to-end search leg (all-pairs among the first N files)")
+    ap.add_argument("--e2e-search-large", type=int, default=4096, help="sketches of the second search leg, where start-up no longer dominates (0 = skip)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="fastq workload: reads of 150 bp")
     ap.add_argument("--parity-reads", type=int, default=10_000_000, help="fastq workload: reads of the oracle slice (0 = skip)")
     ap.add_argument("--exchange", choices=["torch", "c"], default=os.environ.get("KSSD_BENCH_EXCHANGE", "torch"),
@@ -1328,7 +1365,7 @@ def main():
             ol, il = m["off"], m["ids"]
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
             cores = host_cores()
-            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files, e2e_search=a.e2e_search)
+            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files, e2e_search=a.e2e_search, e2e_search4k=a.e2e_search_large)
             res["cpu_baseline"] = cb.get("reference", cb["port"])
             res["cpu_baseline_port"] = cb["port"]
             res["cpu_baseline_dist"] = cb.get("dist_reference", cb["dist_port"])

@@ -294,6 +294,10 @@ int kssd_gpu_text_wait(kssd_gpu_ctx *ctx, int64_t ticket);
  */
 void *kssd_gpu_host_alloc(size_t bytes);
 void kssd_gpu_host_free(void *p);
+/* Memory of the caller's own (malloc) page-locked in place, and released again (before it is freed): for what a command read into
+ * ordinary memory while the runtime was still starting -- copies out of unregistered memory run at a fraction of the PCIe rate. */
+int kssd_gpu_host_register(void *p, size_t bytes);
+int kssd_gpu_host_unregister(void *p);
 
 /*
  * Build the inverted index of the reference sketches on the device: replaces combco2mco

@@ -49,6 +49,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
     "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times", "kssd_gpu_dist_counts_device", "kssd_gpu_transpose_metrics_device",
+    "kssd_gpu_host_register", "kssd_gpu_host_unregister",
 ]
 
 

@@ -295,34 +295,45 @@ static void *warm_device(void *arg)
 
 /* One unit of stage-I work: a run of consecutive input files of one kind (FASTA or FASTQ), tokenised into one packed
  * batch in page-locked memory; a device worker sketches it and leaves the genomes' ids in the reference's file order. */
-typedef struct textbuf { /* the raw bytes of a job's files, every file on a 16-byte boundary: page-locked memory once the HIP runtime is up */
-    unsigned char *p; /* (before that -- the first ~0.2 s of a command -- ordinary memory: the files are read while the runtime starts) */
+typedef struct textbuf { /* the raw bytes of a job's files, every file on a 16-byte boundary, in page-locked memory by the time a device reads them */
+    unsigned char *p;
     size_t cap;
-    int pinned;
+    int kind; /* 1: hipHostMalloc; 0: malloc -- what the first buffers of a command are, read while the runtime starts -- ; 2: malloc,
+               * registered with the runtime since (by the worker that takes the job: textbuf_lock) */
 } textbuf;
 
 static void textbuf_release(textbuf *tx)
 {
     if (tx->p) {
-        if (tx->pinned) kssd_gpu_host_free(tx->p);
-        else free(tx->p);
+        if (tx->kind == 1) {
+            kssd_gpu_host_free(tx->p);
+        } else {
+            if (tx->kind == 2) kssd_gpu_host_unregister(tx->p);
+            free(tx->p);
+        }
     }
     tx->p = NULL;
     tx->cap = 0;
+    tx->kind = 0;
 }
 
-/* room for `need` bytes: page-locked when the runtime is up (DMA at PCIe speed), ordinary memory before (the copy to the device
- * then goes through the runtime's staging buffers: 19 - 28 GB/s instead of 55, profiles/r02c_pinned_probe.txt -- on the first
- * buffers of a command, whose alternative is to wait 0.1 - 0.2 s for hipInit before the first byte is read) */
-static void textbuf_fit(textbuf *tx, size_t need)
+/* room for `need` bytes: page-locked when the runtime is up, ordinary memory before -- on the first buffers of a command, whose
+ * alternative is to wait 0.1 - 0.2 s for hipInit before the first byte is read.  A buffer that is large enough is kept as it is. */
+static void textbuf_fit(textbuf *tx, size_t need, int runtime_ready)
 {
-    const int want_pinned = g_runtime_ready;
-    if (tx->p && tx->cap >= need && (tx->pinned || !want_pinned)) return;
+    if (tx->p && tx->cap >= need) return;
     textbuf_release(tx);
     tx->cap = need + need / 4 + 64;
-    tx->pinned = want_pinned;
-    tx->p = want_pinned ? kssd_gpu_host_alloc(tx->cap) : malloc(tx->cap);
-    if (!tx->p) die(ENOMEM, "out of %smemory (%zu bytes)", want_pinned ? "page-locked " : "", tx->cap);
+    tx->kind = runtime_ready ? 1 : 0;
+    tx->p = runtime_ready ? kssd_gpu_host_alloc(tx->cap) : malloc(tx->cap);
+    if (!tx->p) die(ENOMEM, "out of %smemory (%zu bytes)", runtime_ready ? "page-locked " : "", tx->cap);
+}
+
+/* before a device copies out of it: ordinary memory is registered in place (0.05 s per GB; a copy out of unregistered memory goes
+ * through the runtime's staging buffers at 7 GB/s instead of 55, profiles/r05i_*) and stays so for the rest of the command */
+static void textbuf_lock(textbuf *tx)
+{
+    if (tx->p && tx->kind == 0 && kssd_gpu_host_register(tx->p, tx->cap) == KSSD_OK) tx->kind = 2; /* (refused: the copy still works, slowly) */
 }
 
 typedef struct job {
@@ -344,7 +355,13 @@ typedef struct job {
 /* host threads a device worker uses for its own post-processing (file order of the ids): small teams, so that they do not
  * fight the tokenisers' team for the cores (each pthread has its own OpenMP pool, idle pools spin) */
 #define WORKER_OMP 4
-#define TEXT_BUFS_MAX 512 /* text buffers a command may hold at most (read-ahead while the runtime starts; the steady state: a handful) */
+/* Text buffers a command may fill while the HIP runtime is still starting (KSSD_TEXT_AHEAD; ordinary memory, registered with the
+ * runtime by the worker that takes the job).  0: the first byte is read once the runtime is up, into page-locked memory -- the default,
+ * because reading ahead did NOT pay on the measurement box (profiles/r05j_e2e_probe.txt, 1 024 x 5 Mb files in tmpfs, wall time of
+ * the command): 0 / 8 / 16 / 32 / 64 buffers ahead 0.60 / 0.61 / 0.78 / 1.18 / 1.25 s -- hipInit and the context creation run slower
+ * beside sixteen reading threads (0.22 -> 0.34 s), fresh pages cost their faults, and registered or not, gigabytes of ordinary memory
+ * take 0.1 - 0.4 s to give back at the end; all of it unregistered (profiles/r05i_*): copies at 7 GB/s, 1.05 s. */
+#define TEXT_BUFS_AHEAD 0
 
 /* A long plain input is not read into a host buffer of its size: slices of it go through a small ring of page-locked
  * buffers into the context's device text buffer -- STREAM_READERS slices are read at a time (pread, one thread each) while
@@ -791,9 +808,7 @@ typedef struct {
     kssd_batch **pool;          /* free batches */
     textbuf **tpool;            /* free text buffers */
     int n_pool, n_tpool, closed;
-    int n_text_keep;            /* text buffers of the steady state (one per worker + the ones being filled) */
-    int n_text_made;            /* text buffers in existence: the pool grows while the devices are not taking jobs yet (read-ahead) */
-    size_t text_bytes, text_budget; /* their bytes, and what the read-ahead may hold */
+    int n_text_made;            /* text buffers in existence (the pool holds the free ones) */
     const dist_opt *o;
     filelist *fl;
     uint32_t hashsize, hashlimit;
@@ -843,7 +858,7 @@ static void *worker_main(void *arg)
         if (!j) break;
         const double t0 = now_s();
         double tcall = 0;
-        textbuf *surplus = NULL;
+        if (j->tx) textbuf_lock(j->tx);
         process_job(ctx, &ring, j, pl->o, pl->fl, pl->hashsize, pl->hashlimit, &tcall, pl->res ? pl->res[w->q] : NULL, pl->res ? pl->first[w->q] : 0u);
         const double dt = now_s() - t0;
         if (j->b) kssd_batch_clear(j->b);
@@ -853,16 +868,7 @@ static void *worker_main(void *arg)
         j->lines = NULL;
         pthread_mutex_lock(&pl->mu);
         if (j->b) pl->pool[pl->n_pool++] = j->b; /* the buffer goes back to the tokeniser */
-        if (j->tx) {
-            /* read-ahead buffers of ordinary memory are not kept once the runtime is up (the steady state runs on its few page-locked ones) */
-            if (!j->tx->pinned && g_runtime_ready && pl->n_text_made > pl->n_text_keep) {
-                pl->text_bytes -= j->tx->cap;
-                pl->n_text_made--;
-                surplus = j->tx;
-            } else {
-                pl->tpool[pl->n_tpool++] = j->tx;
-            }
-        }
+        if (j->tx) pl->tpool[pl->n_tpool++] = j->tx;
         j->b = NULL;
         j->tx = NULL;
         free(j->toff);
@@ -874,10 +880,6 @@ static void *worker_main(void *arg)
         pl->t_call += tcall;
         pthread_cond_broadcast(&pl->cv);
         pthread_mutex_unlock(&pl->mu);
-        if (surplus) {
-            textbuf_release(surplus);
-            free(surplus);
-        }
     }
     const double td0 = now_s();
     for (int b = 0; b < STREAM_BUFS; b++)
@@ -994,6 +996,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pthread_t warm;
     int warm_dev = o->devs[0];
     const int warming = pthread_create(&warm, NULL, warm_device, &warm_dev) == 0; /* under the .shuf read */
+    int warm_joined = 0;
     shuf_core sc;
     load_shuf(o, &sc);
     const kssd_shuf shuf = sc.h;
@@ -1044,16 +1047,13 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         if (!pl.pool[i]) die(ENOMEM, "out of memory");
     }
     pl.n_pool = n_batches;
-    pl.tpool = calloc((size_t)TEXT_BUFS_MAX, sizeof *pl.tpool);
+    int text_ahead = TEXT_BUFS_AHEAD; /* (KSSD_TEXT_AHEAD: a tuning knob, 0 = no read-ahead: the first byte is read once the runtime is up) */
+    if (getenv("KSSD_TEXT_AHEAD")) text_ahead = atoi(getenv("KSSD_TEXT_AHEAD"));
+    if (text_ahead < 0) text_ahead = 0;
+    if (text_ahead > 256) text_ahead = 256;
+    pl.tpool = calloc((size_t)(n_batches + text_ahead), sizeof *pl.tpool);
     for (int i = 0; i < n_batches; i++) pl.tpool[i] = calloc(1, sizeof(textbuf));
-    pl.n_tpool = pl.n_text_made = pl.n_text_keep = n_batches;
-    {   /* read-ahead: what may wait in memory for the devices -- a quarter of the machine's free memory, 8 GiB at most (KSSD_READ_AHEAD, bytes) */
-        size_t budget = 8ull << 30;
-        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
-        if (pages > 0 && psz > 0 && (size_t)pages * (size_t)psz / 4 < budget) budget = (size_t)pages * (size_t)psz / 4;
-        if (getenv("KSSD_READ_AHEAD")) budget = strtoull(getenv("KSSD_READ_AHEAD"), NULL, 10);
-        pl.text_budget = budget;
-    }
+    pl.n_tpool = pl.n_text_made = n_batches;
     worker *ws = calloc((size_t)n_workers, sizeof *ws);
     for (int i = 0; i < n_workers; i++) {
         ws[i].pl = &pl;
@@ -1149,8 +1149,10 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                 }
                 /* a free text buffer -- or, while the devices lag behind the readers (the runtime is still starting: nothing is
                  * taken off the queues yet), one more: the inputs are read ahead into memory up to the budget */
+                /* a free text buffer -- or, while the runtime is still starting (nothing is taken off the queues yet), one more: up
+                 * to TEXT_BUFS_AHEAD of them are read ahead into ordinary memory; they stay the command's buffers afterwards */
                 pthread_mutex_lock(&pl.mu);
-                while (pl.n_tpool == 0 && (pl.n_text_made >= TEXT_BUFS_MAX || pl.text_bytes + at > pl.text_budget)) pthread_cond_wait(&pl.cv, &pl.mu);
+                while (pl.n_tpool == 0 && (g_runtime_ready || pl.n_text_made >= text_ahead)) pthread_cond_wait(&pl.cv, &pl.mu);
                 textbuf *tx;
                 if (pl.n_tpool) {
                     tx = pl.tpool[--pl.n_tpool];
@@ -1158,12 +1160,13 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     tx = calloc(1, sizeof *tx);
                     pl.n_text_made++;
                 }
-                pl.text_bytes -= tx->cap;
                 pthread_mutex_unlock(&pl.mu);
-                textbuf_fit(tx, at + 64);
-                pthread_mutex_lock(&pl.mu);
-                pl.text_bytes += tx->cap;
-                pthread_mutex_unlock(&pl.mu);
+                if (!tx->p && !g_runtime_ready && text_ahead == 0) { /* (no reading ahead: the buffers are page-locked ones, which takes the runtime) */
+                    if (warming) pthread_join(warm, NULL);
+                    warm_joined = 1;
+                    g_runtime_ready = 1; /* (a runtime that failed to start is reported by the workers' context creation) */
+                }
+                textbuf_fit(tx, at + 64, g_runtime_ready);
                 t0 = now_s();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
                 for (int i = r0; i < r1; i++) {
@@ -1232,7 +1235,7 @@ static void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     pthread_cond_broadcast(&pl.cv);
     pthread_mutex_unlock(&pl.mu);
     for (int i = 0; i < n_workers; i++) pthread_join(ws[i].th, NULL);
-    if (warming) pthread_join(warm, NULL);
+    if (warming && !warm_joined) pthread_join(warm, NULL);
     printf("\n");
     free(sc.accepted);
     const double t_sketched = now_s();
