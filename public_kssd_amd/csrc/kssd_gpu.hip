@@ -161,7 +161,7 @@ struct kssd_gpu_ctx {
     uint32_t *d_ref_sz;     // n_ref sketch sizes
     uint32_t *d_hkeys;      // the bucketed table: 8-byte slots (IdxSlot8) of a capped build, 16-byte ones (IdxSlot) of a counted one
     uint32_t h_log2;        // log2 of the number of buckets
-    uint32_t idx_lg_cap = 0;      // capped build in place: log2 of every bucket's slots (0: exact build, descriptors)
+    uint32_t idx_cap = 0;         // capped build in place: every bucket's slots, a multiple of 64 (0: exact build, descriptors)
     uint32_t idx_serial = 0;      // number of the build in place
     uint32_t *d_idx_flag = nullptr;  // serial of the last capped build that met a bucket fuller than its run
     bool idx_exact = false;       // builds of this context count first (a capped build of it has overflowed, or the caller asked)

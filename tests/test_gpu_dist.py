@@ -554,3 +554,50 @@ def test_rows_written_transposed_carry_the_bits_of_the_rows_kernel(shuf_l3k10):
         ctx.index_set_filter(False)
     finally:
         ctx.close()
+
+
+def test_index_of_more_than_2048_buckets_is_partitioned_in_two_levels(shuf_l3k10):
+    """5.2 M ids: 4 096 buckets of a room that is no power of two (a multiple of 64), the entries partitioned by super-bucket first and
+    by bucket inside it then (idx_scatter_tile_kernel + idx_scatter_sub_kernel); KSSD_INDEX_ONE_LEVEL=1 keeps the one-level pass of
+    rounds 1 - 4.  Counts against the oracle's posting traversal either way, with and without the negative filter, and the two
+    builds' metric planes carry the same bits."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(123)
+    roff, rids = random_sketches(rng, 4000, 1250, 1350, 1 << 28, clades=200)
+    qoff, qids = random_sketches(rng, 40, 0, 1300, 1 << 28, clades=7)
+    n = len(qids) // 2
+    qids[:n] = rng.choice(rids, size=n)
+    for i in range(len(qoff) - 1):
+        s_, e_ = int(qoff[i]), int(qoff[i + 1])
+        u = np.unique(qids[s_:e_])
+        fill = rng.choice(1 << 28, size=(e_ - s_) - len(u), replace=False).astype(np.uint32)
+        qids[s_:e_] = np.sort(np.concatenate([u, fill]))
+    want = ko.shared_counts(roff, rids, qoff, qids, threads=8)
+    assert want.sum() > 20_000
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
+        outs = []
+        for one_level, filt in ((False, False), (True, False), (False, True)):
+            if one_level:
+                os.environ["KSSD_INDEX_ONE_LEVEL"] = "1"
+            try:
+                ctx.index_set_filter(filt, 3, 11)
+                for _ in range(2):                              # (twice: the cursors are back at zero after a build)
+                    ctx.index_build_device(d[0], d[1], 4000, len(rids))
+                assert ctx.index_status() == 0
+            finally:
+                os.environ.pop("KSSD_INDEX_ONE_LEVEL", None)
+            shared = torch.full((40 * 4000,), -1, dtype=torch.int32, device=dev)
+            planes = [torch.zeros(40 * 4000, dtype=torch.float64, device=dev) for _ in range(4)]
+            ctx.dist_device(d[2], d[3], 40, 0, 40, shared, *planes)
+            torch.cuda.synchronize()
+            assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(40, 4000), want), (one_level, filt)
+            outs.append([p.cpu().numpy().view(np.int64) for p in planes])
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a, b)
+        ctx.index_set_filter(False)
+    finally:
+        ctx.close()
