@@ -7,7 +7,6 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC kssd_gpu.hip -o libkssd_gpu.so
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -153,8 +152,6 @@ struct kssd_gpu_ctx {
     size_t cap_in_packed, cap_in_mask, cap_b_ids, cap_b_pos, cap_b_off;
     uint32_t *d_big_alt;          // sort output | tile counts | 2 accumulators
     size_t cap_big_alt;
-    void *d_big_tmp;              // rocPRIM temporary storage
-    size_t cap_big_tmp;
     // inverted index (dist)
     uint32_t n_ref;
     uint64_t n_ref_ids;
@@ -324,7 +321,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
-                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt, c->d_big_tmp,
+                    c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt,
                     c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag, c->d_lb};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -603,7 +600,7 @@ extern "C" int kssd_gpu_dev_deduptimes(unsigned long long *out, uint32_t n_genom
 }
 #endif
 
-// per-genome dedup (LDS sort or, for large genomes, rocPRIM sort + run kernels), CSR offsets, gather; K = key type
+// per-genome dedup (LDS sort; large genomes: sorted by ranges of their keys, or -- keys that do not spread -- by the bitonic network of kssd_big.inc), CSR offsets, gather; K = key type
 template <typename K>
 static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, uint32_t min_occ, uint32_t big_min, uint64_t max_cap,
                          uint64_t max_big, uint64_t *d_out_off, uint32_t *d_out_ids, uint32_t *d_out_pos, uint64_t out_cap,
@@ -719,22 +716,17 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         const size_t n_tiles_max = ranges ? (size_t)(max_big / RNG_T + 2) : (size_t)((max_big + BIG_TILE - 1) / BIG_TILE);
         const size_t rng_words = ranges ? 2 * n_tiles_max + 2 + 2 * ((size_t)1 << RNG_MAX_LOG2_BINS) + 2 + (size_t)256 * ((size_t)1 << RNG_MAX_LOG2_BINS) : 0;
         // keys (sort output | partitioned keys) | item / tile counts | 8 accumulator words | RANGES: item starts, bin totals, bin starts, rows of counts
-        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, (size_t)max_big * kw + n_tiles_max + 8 + rng_words)) != KSSD_OK) return rc;
+        // (the global-memory sort works on the power of two from the largest region on: big_bitonic_sort)
+        size_t sort_room = (size_t)max_big;
         if (!ranges) {
-            size_t tmp_bytes = 0;
-            HIPCK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (K *)nullptr, (K *)nullptr, (size_t)max_big, 0u, (unsigned)(8 * sizeof(K)), s));
-            if (tmp_bytes > c->cap_big_tmp) {
-                if (c->d_big_tmp) hipFree(c->d_big_tmp);
-                c->d_big_tmp = nullptr;
-                c->cap_big_tmp = 0;
-                if (hipMalloc(&c->d_big_tmp, tmp_bytes) != hipSuccess) return KSSD_ERR_NOMEM;
-                c->cap_big_tmp = tmp_bytes;
-            }
+            sort_room = BIT_TILE;
+            while (sort_room < (size_t)max_big) sort_room <<= 1;
         }
+        if ((rc = ensure(&c->d_big_alt, &c->cap_big_alt, sort_room * kw + n_tiles_max + 8 + rng_words)) != KSSD_OK) return rc;
         for (uint32_t g : c->h_big) {
             const uint64_t r0 = c->h_reg_off[g], cap = c->h_reg_off[g + 1] - r0;
             K *region = regions + r0, *sorted = reinterpret_cast<K *>(c->d_big_alt);
-            uint32_t *tile_cnt = c->d_big_alt + (size_t)max_big * kw, *accum = tile_cnt + n_tiles_max;
+            uint32_t *tile_cnt = c->d_big_alt + sort_room * kw, *accum = tile_cnt + n_tiles_max;
             const uint32_t *cur = c->d_cursor + g;
             if (ranges) {
                 // the keys' leading field: the id, or (--byread) the position inside the genome
@@ -797,8 +789,11 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
             const uint32_t n_tiles = (uint32_t)((cap + BIG_TILE - 1) / BIG_TILE);
             hipLaunchKernelGGL((big_pad_kernel<K>), dim3(1024), dim3(256), 0, s, region, (unsigned long long)cap, cur, c->d_kept + g, accum,
                                c->d_status);
-            size_t tb = c->cap_big_tmp;
-            HIPCK(rocprim::radix_sort_keys(c->d_big_tmp, tb, region, sorted, (size_t)cap, 0u, (unsigned)(8 * sizeof(K)), s));
+            {
+                unsigned long long np2 = BIT_TILE;
+                while (np2 < cap) np2 <<= 1;
+                if ((rc = big_bitonic_sort<K>(region, (unsigned long long)cap, sorted, np2, s)) != KSSD_OK) return rc;
+            }
             hipLaunchKernelGGL((big_runs_kernel<K, false>), dim3(n_tiles), dim3(BIG_THREADS), 0, s, (const K *)sorted,
                                (unsigned long long)cap, cur, flags, min_occ, tile_cnt, accum, (K *)nullptr);
             hipLaunchKernelGGL(big_scan_kernel, dim3(1), dim3(1024), 0, s, tile_cnt, n_tiles, (const uint32_t *)accum, c->P.hashlimit,
