@@ -682,7 +682,7 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
         hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_FUSED>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
                            (const unsigned long long *)c->d_reg_off, (const uint32_t *)c->d_cursor, regions, c->d_kept,
                            flags, min_occ, big_min, c->d_status, fx, px);
-    } else {
+    } else if (c->h_big.size() + c->h_med.size() < (size_t)n_genomes) {  // (a batch of nothing but large genomes -- one read set -- has no workgroup to send)
         HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(sketch_dedup_kernel<K, DEDUP_STAGED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(dlds < 65536 ? 65536 : dlds)));
         hipLaunchKernelGGL((sketch_dedup_kernel<K, DEDUP_STAGED>), dim3(n_genomes), dim3(DEDUP_THREADS), dlds, s, c->P,
@@ -991,7 +991,9 @@ static int phase_prep(kssd_gpu_ctx *c, hipStream_t s)
         // enough workgroups per genome that a single huge one (a read set, a chromosome) is not written by one of them
         uint64_t parts = (pl.n_chunks / pl.n_genomes + 16 * 256 - 1) / (16 * 256);
         if (parts > 1024) parts = 1024;
-        hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes > 64 ? pl.n_genomes : 64, (unsigned)(parts ? parts : 1)), dim3(256), 0, s,
+        // (the grid's x is the genomes and nothing more: a read set is ONE genome, and 63 of 64 workgroups of the launch used to find
+        // that they had none -- 58 000 empty workgroups, 19 of the kernel's 25 us at configs[3]; the per-call state is zeroed in loops)
+        hipLaunchKernelGGL(chunk_gid_by_genome_kernel, dim3(pl.n_genomes, (unsigned)(parts ? parts : 1)), dim3(256), 0, s,
                            (const uint64_t *)c->d_chunk_off, pl.n_genomes, c->d_chunk_gid, c->d_cursor, c->d_cand_count, pl.n_slices,
                            reinterpret_cast<uint32_t *>(c->d_status));
         HIPCK(hipGetLastError());
