@@ -1102,8 +1102,10 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     x.n_slices = pl.n_slices;
     x.reg_off = (const unsigned long long *)c->d_reg_off; x.cursor = c->d_cursor; x.regions = c->d_regions;
     x.by_pos = (pl.flags & KSSD_SKETCH_BY_POS) ? 1u : 0u;
+    x.one_genome = pl.n_genomes == 1 ? 1u : 0u;
+    x.cand_cap_end = (unsigned long long)pl.n_chunks * KSSD_CHUNK;
 #ifdef KSSD_DEV
-    x.dev_no_atomic = getenv("KSSD_DEV_EXACT_NO_ATOMIC") ? 1u : 0u;
+    x.dev_no_atomic = getenv("KSSD_DEV_EXACT_NO_ATOMIC") ? (uint32_t)atoi(getenv("KSSD_DEV_EXACT_NO_ATOMIC")) : 0u;  // (1: no cursor atomic, 2: no exact-table read, 3: no staging, 4: nothing)
 #endif
     x.status = c->d_status;
     const dim3 grid((unsigned)((pl.cand_cap + EXACT_THREADS * EXACT_PER - 1) / (EXACT_THREADS * EXACT_PER)), pl.n_slices);
