@@ -378,21 +378,6 @@ int kssd_gpu_transpose_metrics_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff,
                                       const uint32_t *d_counts, uint64_t out_pitch, uint32_t *d_shared_t, double *d_jaccard_t,
                                       double *d_mashd_t, double *d_contain_t, double *d_aafd_t, void *stream);
 
-/*
- * The same rows with the index reads kept inside one XCD's L2 (csrc/kssd_distx.inc): a row is eight workgroups, part p of them
- * takes the row's ids whose bucket lies in the p-th eighth of the table and runs on XCD p; the parts add their counters up in an
- * accumulator row, the one that arrives last writes the outputs -- the bits of kssd_gpu_dist_device.  It reads the row's ids GROUPED
- * BY PART: d_xids (the CSR's ids, every row's in the order of their parts) and d_xoff (u32[9 x n_qry]: where a row's parts begin,
- * relative to the row's first id), which kssd_gpu_xorder_device makes for any CSR on the device (and the sketch calls can leave
- * beside their ascending ids: kssd_gpu_sketch_set_xorder_output).  KSSD_ERR_UNSUPPORTED when the index in place is not the ordinary
- * (capped) one, has fewer than eight buckets, more than 4 096 references or the negative filter: kssd_gpu_dist_device then.
- */
-int kssd_gpu_xorder_device(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32_t *d_qids, uint32_t n_qry, uint32_t *d_xids,
-                           uint32_t *d_xoff, void *stream);
-int kssd_gpu_dist_device_x(kssd_gpu_ctx *ctx, const uint64_t *d_qoff, const uint32_t *d_xids, const uint32_t *d_xoff, uint32_t n_qry,
-                           uint32_t q_begin, uint32_t q_end, uint32_t *d_shared, double *d_jaccard, double *d_mashd,
-                           double *d_contain, double *d_aafd, void *stream);
-
 /* host-level convenience: HOST CSR in, HOST matrices out (caller-allocated, Q x R; planes may be NULL) */
 int kssd_gpu_dist(kssd_gpu_ctx *ctx, const uint64_t *roff, const uint32_t *rids, uint32_t n_ref,
                   const uint64_t *qoff, const uint32_t *qids, uint32_t n_qry, uint32_t *shared,

@@ -1,4 +1,5 @@
-"""dist_rows_kernel against dist_rows_x_kernel (a row as eight parts, one per XCD) on the bench's all-pairs: 1 000 sketches of the
+"""(The kernel this measured -- dist_rows_x_kernel, csrc/kssd_distx.inc -- is in the tree of commit 95bf0b6 only: measured, not kept.)
+dist_rows_kernel against dist_rows_x_kernel (a row as eight parts, one per XCD) on the bench's all-pairs: 1 000 sketches of the
 bench generator's clade structure (here: random ids with clade sharing), index + rows, the rows kernel's own time by the dispatch events."""
 import os, sys
 import numpy as np

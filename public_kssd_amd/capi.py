@@ -49,7 +49,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
     "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times", "kssd_gpu_dist_counts_device", "kssd_gpu_transpose_metrics_device",
-    "kssd_gpu_host_register", "kssd_gpu_host_unregister", "kssd_gpu_xorder_device", "kssd_gpu_dist_device_x",
+    "kssd_gpu_host_register", "kssd_gpu_host_unregister",
 ]
 
 
@@ -187,8 +187,6 @@ def gpu_lib():
         L.kssd_gpu_dist.argtypes = [vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_transposed.argtypes = [vp, vp, vp, u32, u32, u32, vp, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_counts_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp]
-        L.kssd_gpu_xorder_device.argtypes = [vp, vp, vp, u32, vp, vp, vp]
-        L.kssd_gpu_dist_device_x.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_transpose_metrics_device.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_dist_device_long.argtypes = [vp, vp, vp, u32, u32, u32, u64, vp, vp, vp, vp, vp, vp]
         L.kssd_gpu_tokenise_fasta_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
@@ -856,19 +854,6 @@ class GpuCtx:
         r * out_pitch + (q - q_begin) of every output; d_work: u32[(q_end - q_begin) x n_ref] scratch"""
         _gck(gpu_lib().kssd_gpu_dist_device_transposed(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, q_begin, q_end, _ptr(d_work), out_pitch,
                                                        _ptr(d_shared_t), _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream))
-
-    def xorder_device(self, d_qoff, d_qids, n_qry, d_xids, d_xoff, stream=None):
-        """every row's ids grouped by the eighth of the table their bucket lies in (d_xids) and where the parts begin (d_xoff, 9 per row)"""
-        _gck(gpu_lib().kssd_gpu_xorder_device(self.h, _ptr(d_qoff), _ptr(d_qids), n_qry, _ptr(d_xids), _ptr(d_xoff), stream))
-
-    def dist_device_x(self, d_qoff, d_xids, d_xoff, n_qry, q_begin, q_end, d_shared, d_j=None, d_m=None, d_c=None, d_a=None, stream=None):
-        """kssd_gpu_dist_device_x: rows as eight parts, one per XCD; returns False when the index in place wants dist_device instead"""
-        rc = gpu_lib().kssd_gpu_dist_device_x(self.h, _ptr(d_qoff), _ptr(d_xids), _ptr(d_xoff), n_qry, q_begin, q_end, _ptr(d_shared),
-                                              _ptr(d_j), _ptr(d_m), _ptr(d_c), _ptr(d_a), stream)
-        if rc == ERR_UNSUPPORTED:
-            return False
-        _gck(rc)
-        return True
 
     def dist_counts_device(self, d_qoff, d_qids, n_qry, q_begin, q_end, d_counts, stream=None):
         """shared counts of rows [q_begin, q_end), row-major by query (rows behind the negative filter are walked flat)"""

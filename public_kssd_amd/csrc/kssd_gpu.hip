@@ -198,8 +198,6 @@ struct kssd_gpu_ctx {
     uint32_t nofilt_lo, nofilt_hi;
     uint32_t *d_arrive;     // long query rows: arrival counters of the workgroups that share a row
     size_t cap_arrive;
-    uint32_t *d_xacc = nullptr;  // dist_rows_x_kernel: accumulator rows + arrival counters (zero between launches)
-    size_t cap_xacc = 0;
     uint32_t *d_sel_cnt, *d_sel_out;  // report selection (kssd_gpu_dist_select): per-row counts / starts, candidate pairs
     size_t cap_sel_cnt, cap_sel_out;
     size_t cap_hash;
@@ -324,7 +322,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag, c->d_lb, c->d_xacc};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag, c->d_lb};
     for (void *p : ptrs)
         if (p) hipFree(p);
     free(c->tok_args_saved);
@@ -1569,6 +1567,5 @@ extern "C" int kssd_gpu_text_wait(kssd_gpu_ctx *c, int64_t ticket)
 // set operations on sketches (kssd set) live in kssd_set.inc
 // ---------------------------------------------------------------------------------------------------
 #include "kssd_set.inc"
-#include "kssd_distx.inc"
 #include "kssd_xchg.inc"
 #include "kssd_resident.inc"

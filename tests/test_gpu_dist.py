@@ -602,65 +602,3 @@ def test_index_of_more_than_2048_buckets_is_partitioned_in_two_levels(shuf_l3k10
     finally:
         ctx.close()
 
-
-def test_rows_as_eight_parts_one_per_xcd_carry_the_bits_of_the_rows_kernel(shuf_l3k10):
-    """kssd_gpu_dist_device_x: a row is eight workgroups, part p of them takes the row's ids whose bucket lies in the p-th eighth of
-    the table (kssd_gpu_xorder_device groups them), the parts' counters meet in an accumulator row and the part that arrives last
-    writes the outputs.  Counts against the oracle, the planes' bits against kssd_gpu_dist_device, over several launches on one
-    context (the accumulator is clean again after each), sub-ranges of the rows, empty sketches, an index with few buckets refused."""
-    import torch
-    dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(2024)
-    ctx = K.GpuCtx(shuf_l3k10, 0)
-    try:
-        for n_ref, n_qry, lo, hi in ((300, 257, 900, 1300), (64, 40, 0, 700), (1000, 1000, 1100, 1300)):
-            roff, rids = random_sketches(rng, n_ref, lo, hi, 1 << 28, clades=max(2, n_ref // 20))
-            if n_qry == n_ref:
-                qoff, qids = roff, rids                                           # all-pairs: the queries are the references
-            else:
-                qoff, qids = random_sketches(rng, n_qry, 0, hi, 1 << 28, clades=5)
-                qids[: len(qids) // 2] = rng.choice(rids, size=len(qids) // 2)
-                for i in range(n_qry):
-                    s_, e_ = int(qoff[i]), int(qoff[i + 1])
-                    u = np.unique(qids[s_:e_])
-                    fill = rng.choice(1 << 28, size=(e_ - s_) - len(u), replace=False).astype(np.uint32)
-                    qids[s_:e_] = np.sort(np.concatenate([u, fill]))
-            want = ko.shared_counts(roff, rids, qoff, qids, threads=8)
-            d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
-            ctx.index_build_device(d[0], d[1], n_ref, len(rids))
-            xids = torch.zeros(len(qids) + 4, dtype=torch.int32, device=dev)
-            xoff = torch.zeros(9 * n_qry, dtype=torch.int32, device=dev)
-            ctx.xorder_device(d[2], d[3], n_qry, xids, xoff)
-            torch.cuda.synchronize()
-            xo = xoff.cpu().numpy().reshape(n_qry, 9)
-            xi = xids.cpu().numpy().view(np.uint32)
-            mix = lambda v: ((v.astype(np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(29)
-            for i in range(0, n_qry, max(1, n_qry // 17)):                        # the grouping itself: a permutation of the row, parts in order, ascending inside
-                s_, e_ = int(qoff[i]), int(qoff[i + 1])
-                row = xi[s_:e_]
-                assert xo[i, 0] == 0 and xo[i, 8] == e_ - s_ and np.array_equal(np.sort(row), qids[s_:e_])
-                for p in range(8):
-                    part = row[xo[i, p]:xo[i, p + 1]]
-                    assert (mix(part) == p).all() and (np.diff(part.astype(np.int64)) > 0).all()
-            shared = torch.zeros(n_qry * n_ref, dtype=torch.int32, device=dev)
-            planes = [torch.zeros(n_qry * n_ref, dtype=torch.float64, device=dev) for _ in range(4)]
-            ctx.dist_device(d[2], d[3], n_qry, 0, n_qry, shared, *planes)
-            torch.cuda.synchronize()
-            ref_planes = [p.cpu().numpy().view(np.int64).reshape(n_qry, n_ref) for p in planes]
-            assert np.array_equal(shared.cpu().numpy().view(np.uint32).reshape(n_qry, n_ref), want)
-            if n_ref < 300:     # (a handful of buckets: the index has fewer than eight -- or not: either the call says so or it computes)
-                pass
-            for rep, (q0, q1) in enumerate(((0, n_qry), (0, n_qry), (n_qry // 3, n_qry - 2))):
-                rows = q1 - q0
-                sx = torch.full((rows * n_ref,), 9, dtype=torch.int32, device=dev)
-                px = [torch.full((rows * n_ref,), 9.0, dtype=torch.float64, device=dev) for _ in range(4)]
-                ok = ctx.dist_device_x(d[2], xids, xoff, n_qry, q0, q1, sx, *px)
-                torch.cuda.synchronize()
-                if not ok:
-                    assert n_ref <= 64                                            # (too few buckets for eight parts)
-                    break
-                assert np.array_equal(sx.cpu().numpy().view(np.uint32).reshape(rows, n_ref), want[q0:q1]), (n_ref, rep)
-                for p, w in zip(px, ref_planes):
-                    assert np.array_equal(p.cpu().numpy().view(np.int64).reshape(rows, n_ref), w[q0:q1]), (n_ref, rep)
-    finally:
-        ctx.close()
