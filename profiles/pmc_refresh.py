@@ -23,7 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-RX = "sketch_scan_kernel|sketch_dedup_kernel|sketch_gather_kernel|idx_|dist_rows_kernel"
+RX = "sketch_scan_kernel|sketch_dedup_kernel|sketch_gather_kernel|idx_|dist_rows_kernel|dist_metrics"
 
 
 def one_pass(tag, counter, out_dir):
