@@ -782,43 +782,76 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     double t_read = 0, t_tok = 0;
     uint64_t n_bytes = 0;
     int done = 0, n_jobs = 0;
-    /* the text buffers of a wave's files are kept from wave to wave (no fresh memory per file) */
-    unsigned char **txt = calloc((size_t)threads, sizeof *txt);
-    size_t *txt_cap = calloc((size_t)threads, sizeof *txt_cap);
-    size_t *len = calloc((size_t)threads, sizeof *len);
-    int *trc = calloc((size_t)threads, sizeof *trc);
+    /* A wave = `threads` consecutive inputs, read (and unpacked) one per host thread.  Its buffers are kept and reused (no fresh
+     * memory per file).  While the HIP runtime is still starting -- 0.2 s in which nothing can be handed to a device, and nothing
+     * page-locked be had -- the waves of gzip'ed inputs are unpacked AHEAD into further sets of buffers (KSSD_GZ_AHEAD sets, 8): their
+     * bytes go through a scratch buffer into the job's text anyway, and sixteen threads inflate ~1 GB in that time; plain inputs are
+     * only measured there (reading them ahead into ordinary memory did not pay: TEXT_BUFS_AHEAD). */
+    typedef struct {
+        unsigned char **txt;
+        size_t *txt_cap, *len;
+        int *trc, *direct; /* direct: plain file for the device tokeniser, read straight into the job's text buffer (2: streamed by the worker) */
+        int i0, nw;
+    } wave_buf;
+    int gz_ahead = 8;
+    if (getenv("KSSD_GZ_AHEAD")) gz_ahead = atoi(getenv("KSSD_GZ_AHEAD"));
+    if (gz_ahead < 0) gz_ahead = 0;
+    if (gz_ahead > 64) gz_ahead = 64;
+    wave_buf *waves = calloc((size_t)gz_ahead + 1, sizeof *waves); /* a ring: waves read and not yet turned into jobs */
+    for (int w = 0; w <= gz_ahead; w++) {
+        waves[w].txt = calloc((size_t)threads, sizeof(unsigned char *));
+        waves[w].txt_cap = calloc((size_t)threads, sizeof(size_t));
+        waves[w].len = calloc((size_t)threads, sizeof(size_t));
+        waves[w].trc = calloc((size_t)threads, sizeof(int));
+        waves[w].direct = calloc((size_t)threads, sizeof(int));
+    }
+    int w_head = 0, w_count = 0, next_read = 0;
     uint64_t *lines = calloc((size_t)threads, sizeof *lines);
-    int *direct = calloc((size_t)threads, sizeof *direct); /* plain file for the device tokeniser: read straight into the job's text buffer */
     /* FASTQ text is tokenised on the device: fastq2co's framing with its quality rule (-Q) or, under -A, the framing of
      * mt_shortreads2koc (kssd_gpu_set_fastq_quality / _reads in worker_main); inputs only the reference's own fgets()
      * sequence reproduces come back (KSSD_ERR_UNSUPPORTED) and go through the host tokeniser */
     const int fq_dev = (o->abundance || (o->kmerqlty >= 0 && o->kmerqlty <= 127)) && !getenv("KSSD_HOST_FASTQ");
     stream_env();
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
-        const int i1 = i0 + threads < fl->n ? i0 + threads : fl->n, nw = i1 - i0;
-        double t0 = now_s();
-        /* read + gunzip, one file each.  gzip'ed files (and FASTQ files the host tokenises) go into the wave's scratch
-         * buffers; a plain file the device tokenises is only measured here and read straight into page-locked memory below */
+        /* read the next wave -- and, as long as the runtime is not up, the waves behind it */
+        while (next_read < fl->n && (w_count == 0 || (!g_runtime_ready && w_count <= gz_ahead))) {
+            wave_buf *wb = &waves[(w_head + w_count) % (gz_ahead + 1)];
+            wb->i0 = next_read;
+            wb->nw = (next_read + threads < fl->n ? next_read + threads : fl->n) - next_read;
+            double t0 = now_s();
+            /* read + gunzip, one file each.  gzip'ed files (and FASTQ files the host tokenises) go into the wave's scratch
+             * buffers; a plain file the device tokenises is only measured here and read straight into page-locked memory below */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-        for (int i = 0; i < nw; i++) {
-            const char *path = fl->path[i0 + i];
-            int gz = 0;
-            uint64_t sz = 0;
-            direct[i] = 0;
-            trc[i] = kssd_file_probe(path, &gz, &sz);
-            if (trc[i]) continue;
-            const int dev_tok = fq_dev || !has_fmt(path, fq_fmt); /* the device tokenises it */
-            if (!gz && dev_tok) {
-                direct[i] = 1;
-                len[i] = (size_t)sz;
-            } else if (gz && dev_tok && sz >= STREAM_MIN_GZ) {
-                direct[i] = 2; /* inflated by the device worker, slice by slice, on its way to the device */
-                len[i] = (size_t)sz;
-            } else {
-                trc[i] = kssd_slurp_reuse(path, &txt[i], &txt_cap[i], &len[i]);
+            for (int i = 0; i < wb->nw; i++) {
+                const char *path = fl->path[wb->i0 + i];
+                int gz = 0;
+                uint64_t sz = 0;
+                wb->direct[i] = 0;
+                wb->trc[i] = kssd_file_probe(path, &gz, &sz);
+                if (wb->trc[i]) continue;
+                const int dev_tok = fq_dev || !has_fmt(path, fq_fmt); /* the device tokenises it */
+                if (!gz && dev_tok) {
+                    wb->direct[i] = 1;
+                    wb->len[i] = (size_t)sz;
+                } else if (gz && dev_tok && sz >= STREAM_MIN_GZ) {
+                    wb->direct[i] = 2; /* inflated by the device worker, slice by slice, on its way to the device */
+                    wb->len[i] = (size_t)sz;
+                } else {
+                    wb->trc[i] = kssd_slurp_reuse(path, &wb->txt[i], &wb->txt_cap[i], &wb->len[i]);
+                }
             }
+            t_read += now_s() - t0;
+            next_read += wb->nw;
+            w_count++;
         }
-        t_read += now_s() - t0;
+        wave_buf *wb = &waves[w_head];
+        w_head = (w_head + 1) % (gz_ahead + 1);
+        w_count--;
+        const int nw = wb->nw;
+        unsigned char **txt = wb->txt;
+        size_t *len = wb->len;
+        int *trc = wb->trc, *direct = wb->direct;
+        double t0;
         for (int i = 0; i < nw; i++)
             if (trc[i]) die(EIO, "%s: %s", fl->path[i0 + i], kssd_host_strerror(trc[i]));
         /* runs of one kind that fit a device batch */
@@ -937,12 +970,15 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
             r0 = r1;
         }
     }
-    free(direct);
-    for (int i = 0; i < threads; i++) free(txt[i]);
-    free(txt);
-    free(txt_cap);
-    free(len);
-    free(trc);
+    for (int w = 0; w <= gz_ahead; w++) {
+        for (int i = 0; i < threads; i++) free(waves[w].txt[i]);
+        free(waves[w].txt);
+        free(waves[w].txt_cap);
+        free(waves[w].len);
+        free(waves[w].trc);
+        free(waves[w].direct);
+    }
+    free(waves);
     free(lines);
     pthread_mutex_lock(&pl.mu);
     pl.closed = 1;
