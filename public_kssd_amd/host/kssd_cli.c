@@ -381,6 +381,19 @@ static int cmd_dist(int argc, char **argv)
 int main(int argc, char **argv)
 {
     setvbuf(stdout, NULL, _IOLBF, 0);
+    struct timespec t_main;
+    clock_gettime(CLOCK_REALTIME, &t_main);
+    /* The host threads of this command wait for one another every few milliseconds (a wave of files, a job's genomes), and libgomp's
+     * threads wait by spinning unless told otherwise BEFORE the library is loaded: 16 readers + the device workers' teams then count as
+     * 20-odd running CPUs whatever they do, and under a CPU quota (a container's cpu.max) the whole command is stopped for the rest of
+     * every accounting period -- measured on the GPU box (16-CPU quota): 0.4-0.9 thread-seconds throttled per run, 4.6 s of CPU for 1.7 s
+     * of work (profiles/r05v_throttle_probe.txt).  The wait policy can only come from the environment the process starts with, so the
+     * command starts itself again with it set -- once, first thing, before anything has touched a device (KSSD_NO_REEXEC=1: not). */
+    if (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT") && !getenv("KSSD_NO_REEXEC")) {
+        setenv("OMP_WAIT_POLICY", "passive", 1);
+        setenv("KSSD_NO_REEXEC", "1", 1);
+        execv("/proc/self/exe", argv); /* (no /proc, no permission: go on as we are) */
+    }
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
         printf("%s\n\nUsage: kssd <subcommand> [OPTION...] [arguments ...]\nSupported subcommands are:\n\n"
                "  shuffle\tshuffle/sampling k-mer substring space.\n\n  dist   \tsequences sketching and distance estimation.\n\n"
@@ -398,6 +411,12 @@ int main(int argc, char **argv)
     else die(EINVAL, "%s is not a valid subcommand (this build implements: shuffle, dist, set, reverse)", argv[1]);
     /* every file is closed, every context destroyed: leave without the GPU runtime's exit handlers (tens of milliseconds
      * of a command that takes 0.2 s; KSSD_SLOW_EXIT=1 runs them) */
+    if (getenv("KSSD_TIMING")) { /* wall-clock stamps of main()'s two ends: what a caller's clock sees before and after them is the loader's and the kernel's */
+        struct timespec t_end;
+        clock_gettime(CLOCK_REALTIME, &t_end);
+        fprintf(stderr, "{\"kssd_timing\": \"process\", \"unix_main\": %.6f, \"unix_exit\": %.6f}\n", (double)t_main.tv_sec + 1e-9 * (double)t_main.tv_nsec,
+                (double)t_end.tv_sec + 1e-9 * (double)t_end.tv_nsec);
+    }
     fflush(NULL);
     if (!getenv("KSSD_SLOW_EXIT")) _exit(rc);
     return rc;

@@ -21,17 +21,24 @@
 #endif
 
 /* ---- table entries ------------------------------------------------------------------------------------------------------------
- * bits 0-3   code bits this entry consumes (first level: the whole code, or all codes of a literal group; second level: the bits
- *            behind the first level's)
- * bits 4-7   kind
- * bits 8-31  payload: up to three literal bytes | base (16 bits) + extra-bit count (4 bits, at bit 24) | second-level table:
- *            first entry (16 bits) + its index bits (4 bits, at bit 24) */
-enum { K_LIT1 = 0, K_LIT2 = 1, K_LIT3 = 2, K_BASE = 3, K_EOB = 4, K_SUB = 5, K_BAD = 6 };
-#define ENTRY(nbits, kind, payload) ((uint32_t)(nbits) | ((uint32_t)(kind) << 4) | ((uint32_t)(payload) << 8))
-#define E_NBITS(e) ((e) & 15u)
-#define E_KIND(e) (((e) >> 4) & 15u)
-#define E_BASE(e) (((e) >> 8) & 0xFFFFu)
-#define E_EXTRA(e) (((e) >> 24) & 15u)
+ * bits 0-5   ALL the bits this entry consumes, in one shift (the x86 shift takes its count from the low six bits of the entry as it
+ *            is): a literal group's codes; a length's or distance's code AND the extra bits behind it; behind a first-level pointer,
+ *            the second-level part of the code (+ extra bits); for the pointer itself, the first level's bits
+ * bits 6-7   0 / 1 / 2: one / two / three literal bytes in bits 8-31;  3: something else, namely
+ * bits 8-11      the code's own bits (K_BASE: the extra bits are what bits 0-5 hold beyond them; K_SUB: the second level's index bits)
+ * bits 12-14     K_BASE (a length or distance: base in bits 16-31), K_SUB (second-level table: first entry in bits 16-31), K_EOB, K_BAD */
+enum { K_BASE = 0, K_SUB = 1, K_EOB = 2, K_BAD = 3 };
+#define ENTRY_LITS(nbits, count, bytes) ((uint32_t)(nbits) | ((uint32_t)((count) - 1) << 6) | ((uint32_t)(bytes) << 8))
+#define ENTRY_OTHER(total, kind, code_bits, base) ((uint32_t)(total) | 0xC0u | ((uint32_t)(code_bits) << 8) | ((uint32_t)(kind) << 12) | ((uint32_t)(base) << 16))
+#define E_TOTAL(e) ((e) & 63u)
+#define E_IS_LIT(e) (((e) & 0xC0u) != 0xC0u)
+#define E_LIT_COUNT(e) ((((e) >> 6) & 3u) + 1u) /* (of a literal entry) */
+#define E_LITS(e) ((e) >> 8)
+#define E_KIND(e) (((e) >> 12) & 7u)            /* (of any other entry) */
+#define E_CODE(e) (((e) >> 8) & 15u)
+#define E_BASE(e) ((e) >> 16)
+/* a length's / distance's value: base + the extra bits, which sit behind the code in the low E_TOTAL bits of the bit buffer */
+#define E_VALUE(e, bb) (E_BASE(e) + (((uint32_t)(bb) & ((1u << E_TOTAL(e)) - 1u)) >> E_CODE(e)))
 
 #define LIT_BITS 11
 #define DST_BITS 8
@@ -63,11 +70,11 @@ static uint32_t rev_bits(uint32_t v, int n)
 /* what symbol `sym` of the literal/length (dist = 0) or distance (dist = 1) alphabet decodes to, in a code of nbits bits */
 static uint32_t leaf(int dist, int sym, int nbits)
 {
-    if (dist) return sym < 30 ? ENTRY(nbits, K_BASE, dst_base[sym] | ((uint32_t)dst_extra[sym] << 16)) : ENTRY(nbits, K_BAD, 0);
-    if (sym < 256) return ENTRY(nbits, K_LIT1, sym);
-    if (sym == 256) return ENTRY(nbits, K_EOB, 0);
-    if (sym < 286) return ENTRY(nbits, K_BASE, len_base[sym - 257] | ((uint32_t)len_extra[sym - 257] << 16));
-    return ENTRY(nbits, K_BAD, 0);
+    if (dist) return sym < 30 ? ENTRY_OTHER(nbits + dst_extra[sym], K_BASE, nbits, dst_base[sym]) : ENTRY_OTHER(nbits, K_BAD, 0, 0);
+    if (sym < 256) return ENTRY_LITS(nbits, 1, sym);
+    if (sym == 256) return ENTRY_OTHER(nbits, K_EOB, 0, 0);
+    if (sym < 286) return ENTRY_OTHER(nbits + len_extra[sym - 257], K_BASE, nbits, len_base[sym - 257]);
+    return ENTRY_OTHER(nbits, K_BAD, 0, 0);
 }
 
 /* canonical code lengths -> decoding tables.  -1: the lengths oversubscribe the code space (or need more room than there is) */
@@ -86,7 +93,7 @@ static int build_tables(const uint8_t *lens, int n_sym, int dist, uint32_t *tab,
         next_code[l] = code;
     }
     const int main_n = 1 << main_bits;
-    for (int i = 0; i < main_n; i++) tab[i] = ENTRY(0, K_BAD, 0); /* (an incomplete set: a code nobody owns is an error when it is met) */
+    for (int i = 0; i < main_n; i++) tab[i] = ENTRY_OTHER(0, K_BAD, 0, 0); /* (an incomplete set: a code nobody owns is an error when it is met) */
     uint8_t sub_bits[1 << LIT_BITS];
     memset(sub_bits, 0, (size_t)main_n);
     uint16_t rev[288];
@@ -107,15 +114,15 @@ static int build_tables(const uint8_t *lens, int n_sym, int dist, uint32_t *tab,
     for (int p = 0; p < main_n; p++) {
         if (!sub_bits[p]) continue;
         if (next + (1 << sub_bits[p]) > room) return -1;
-        tab[p] = ENTRY(main_bits, K_SUB, (uint32_t)next | ((uint32_t)sub_bits[p] << 16));
-        for (int i = 0; i < (1 << sub_bits[p]); i++) tab[next + i] = ENTRY(0, K_BAD, 0);
+        tab[p] = ENTRY_OTHER(main_bits, K_SUB, sub_bits[p], next);
+        for (int i = 0; i < (1 << sub_bits[p]); i++) tab[next + i] = ENTRY_OTHER(0, K_BAD, 0, 0);
         next += 1 << sub_bits[p];
     }
     for (int s = 0; s < n_sym; s++) {
         const int l = lens[s];
         if (l <= main_bits) continue;
         const uint32_t p = rev[s] & (uint32_t)(main_n - 1), hi = rev[s] >> main_bits;
-        const uint32_t base = E_BASE(tab[p]), sb = E_EXTRA(tab[p]);
+        const uint32_t base = E_BASE(tab[p]), sb = E_CODE(tab[p]);
         const uint32_t e = leaf(dist, s, l - main_bits);
         for (uint32_t i = hi; i < (1u << sb); i += 1u << (l - main_bits)) tab[base + i] = e;
     }
@@ -124,17 +131,17 @@ static int build_tables(const uint8_t *lens, int n_sym, int dist, uint32_t *tab,
         memcpy(single, tab, (size_t)main_n * sizeof(uint32_t));
         for (int i = 0; i < main_n; i++) {
             const uint32_t e1 = single[i];
-            if (E_KIND(e1) != K_LIT1) continue;
-            const uint32_t n1 = E_NBITS(e1);
+            if (!E_IS_LIT(e1)) continue;
+            const uint32_t n1 = E_TOTAL(e1);
             const uint32_t e2 = single[(uint32_t)i >> n1]; /* the unknown bits above read as zeros: right for every code that fits the known ones */
-            const uint32_t n2 = E_NBITS(e2);
-            if (E_KIND(e2) != K_LIT1 || n1 + n2 > (uint32_t)main_bits) continue;
+            const uint32_t n2 = E_TOTAL(e2);
+            if (!E_IS_LIT(e2) || n1 + n2 > (uint32_t)main_bits) continue;
             const uint32_t e3 = single[(uint32_t)i >> (n1 + n2)];
-            const uint32_t n3 = E_NBITS(e3);
-            if (E_KIND(e3) == K_LIT1 && n1 + n2 + n3 <= (uint32_t)main_bits)
-                tab[i] = ENTRY(n1 + n2 + n3, K_LIT3, E_BASE(e1) | (E_BASE(e2) << 8) | (E_BASE(e3) << 16));
+            const uint32_t n3 = E_TOTAL(e3);
+            if (E_IS_LIT(e3) && n1 + n2 + n3 <= (uint32_t)main_bits)
+                tab[i] = ENTRY_LITS(n1 + n2 + n3, 3, E_LITS(e1) | (E_LITS(e2) << 8) | (E_LITS(e3) << 16));
             else
-                tab[i] = ENTRY(n1 + n2, K_LIT2, E_BASE(e1) | (E_BASE(e2) << 8));
+                tab[i] = ENTRY_LITS(n1 + n2, 2, E_LITS(e1) | (E_LITS(e2) << 8));
         }
     }
     return 0;
@@ -192,7 +199,13 @@ static int out_room(outbuf *o, size_t more)
 
 #define FAST_OUT_MARGIN 336 /* the longest match (258) + what the copies and the literal stores may write beyond their last byte */
 
-/* one block's symbols (its tables are built): returns 0 at the end-of-block code, -1 on a corrupt stream, -2 out of memory */
+/* one block's symbols (its tables are built): returns 0 at the end-of-block code, -1 on a corrupt stream, -2 out of memory.
+ *
+ * Sequence text deflates into MATCHES, not literals: zlib -1 turns a bacterial genome into 1.3 M matches of four bases on average
+ * and a few dozen literals, -6 into 0.7 M matches of seven and 0.2 M literals.  What a match costs is the chain of dependent
+ * steps from one table entry to the next: refill -> look up -> shift.  So a match is ONE refill (56 bits hold the longest length
+ * and distance: 15 + 5 + 15 + 13), each entry is ONE shift (its count covers the extra bits too, the value is picked off the side),
+ * and the copy hangs off the chain (nothing it produces is needed to decode on). */
 static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32_t *lit_one, const uint32_t *dst, size_t member_start)
 {
     const uint64_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DST_BITS) - 1;
@@ -211,62 +224,61 @@ static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32
         in += (63 - bc) >> 3;           \
         bc |= 56;                       \
     } while (0)
+#define CONSUME(e)                      \
+    do {                                \
+        bb >>= E_TOTAL(e);              \
+        bc -= (int)E_TOTAL(e);          \
+    } while (0)
 #define PUT_GROUP()                     \
     do {                                \
-        const uint32_t w = e >> 8;      \
+        const uint32_t w = E_LITS(e);   \
         memcpy(out, &w, 4);             \
-        out += E_KIND(e) + 1;           \
-        bb >>= E_NBITS(e);              \
-        bc -= (int)E_NBITS(e);          \
+        out += E_LIT_COUNT(e);          \
+        CONSUME(e);                     \
     } while (0)
             while (in <= in_fast && out <= out_fast) {
                 REFILL(); /* eight bytes over the top of what is left, whole bytes accepted: 56 - 63 real bits afterwards */
                 uint32_t e = lit[bb & lmask];
-                /* up to three lookups of literals (33 bits at most) before anything else is looked at */
-                if (E_KIND(e) <= K_LIT3) {
+                int behind_literals = 0;
+                if (E_IS_LIT(e)) {
+                    /* up to three lookups of literals (33 bits at most) before anything else is looked at */
                     PUT_GROUP();
                     e = lit[bb & lmask];
-                    if (E_KIND(e) <= K_LIT3) {
+                    if (E_IS_LIT(e)) {
                         PUT_GROUP();
                         e = lit[bb & lmask];
-                        if (E_KIND(e) <= K_LIT3) {
+                        if (E_IS_LIT(e)) {
                             PUT_GROUP();
                             continue;
                         }
                     }
+                    behind_literals = 1; /* up to 22 bits are gone: a length (20) still fits, the distance behind it (28) may not */
                 }
-                /* at least 23 real bits left: a length code of up to 15 bits and its 5 extra bits */
                 if (E_KIND(e) == K_SUB) {
-                    bb >>= LIT_BITS;
-                    bc -= LIT_BITS;
-                    e = lit[E_BASE(e) + (bb & ((1u << E_EXTRA(e)) - 1))];
-                }
-                bb >>= E_NBITS(e);
-                bc -= (int)E_NBITS(e);
-                if (E_KIND(e) == K_LIT1) {
-                    *out++ = (unsigned char)(e >> 8);
-                    continue;
+                    CONSUME(e);
+                    e = lit[E_BASE(e) + (bb & ((1u << E_CODE(e)) - 1))];
+                    if (E_IS_LIT(e)) { /* (a literal with a long code) */
+                        *out++ = (unsigned char)E_LITS(e);
+                        CONSUME(e);
+                        continue;
+                    }
                 }
                 if (E_KIND(e) != K_BASE) {
+                    CONSUME(e);
                     rc = E_KIND(e) == K_EOB ? 0 : -1;
                     break;
                 }
-                const uint32_t len = E_BASE(e) + (uint32_t)(bb & ((1u << E_EXTRA(e)) - 1));
-                bb >>= E_EXTRA(e);
-                bc -= (int)E_EXTRA(e);
-                REFILL();
+                const uint32_t len = E_VALUE(e, bb);
+                CONSUME(e);
+                if (behind_literals) REFILL();
                 uint32_t d = dst[bb & dmask];
                 if (E_KIND(d) == K_SUB) {
-                    bb >>= DST_BITS;
-                    bc -= DST_BITS;
-                    d = dst[E_BASE(d) + (bb & ((1u << E_EXTRA(d)) - 1))];
+                    CONSUME(d);
+                    d = dst[E_BASE(d) + (bb & ((1u << E_CODE(d)) - 1))];
                 }
-                if (E_KIND(d) != K_BASE) { rc = -1; break; }
-                bb >>= E_NBITS(d);
-                bc -= (int)E_NBITS(d);
-                const uint32_t dist = E_BASE(d) + (uint32_t)(bb & ((1u << E_EXTRA(d)) - 1));
-                bb >>= E_EXTRA(d);
-                bc -= (int)E_EXTRA(d);
+                if (E_KIND(d) != K_BASE) { rc = -1; break; } /* (the distance tables hold no literal entries: every entry has a kind) */
+                const uint32_t dist = E_VALUE(d, bb);
+                CONSUME(d);
                 if ((size_t)(out - out_min) < dist) { rc = -1; break; } /* before the member's first byte */
                 const unsigned char *src = out - dist;
                 unsigned char *const end = out + len;
@@ -297,6 +309,7 @@ static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32
                 }
             }
 #undef REFILL
+#undef CONSUME
 #undef PUT_GROUP
             /* the bit buffer may hold bytes beyond what the symbols used: give whole unused bytes back (bc counts real bits only) */
             b->in = in;
@@ -307,27 +320,27 @@ static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32
         }
         /* ---- careful: one symbol, every read and write checked ---- */
         if (out_room(o, FAST_OUT_MARGIN + 8) != 0) return -2;
-        refill_safe(b);
+        refill_safe(b); /* 56 bits and more unless the stream ends: whatever one entry consumes */
         uint32_t e = lit_one[b->bb & lmask]; /* (second levels are shared: they live behind the first level of `lit`) */
-        if (E_KIND(e) == K_SUB) {
+        if (!E_IS_LIT(e) && E_KIND(e) == K_SUB) {
             if (b->bc < LIT_BITS) return -1;
             b->bb >>= LIT_BITS;
             b->bc -= LIT_BITS;
             refill_safe(b);
-            e = lit[E_BASE(e) + (b->bb & ((1u << E_EXTRA(e)) - 1))];
+            e = lit[E_BASE(e) + (b->bb & ((1u << E_CODE(e)) - 1))];
         }
-        if ((int)E_NBITS(e) > b->bc) return -1;
-        b->bb >>= E_NBITS(e);
-        b->bc -= (int)E_NBITS(e);
-        if (E_KIND(e) == K_LIT1) {
-            o->out[o->len++] = (unsigned char)(e >> 8);
+        if ((int)E_TOTAL(e) > b->bc) return -1; /* the stream ends inside a code or its extra bits */
+        if (E_IS_LIT(e)) {
+            o->out[o->len++] = (unsigned char)E_LITS(e);
+            b->bb >>= E_TOTAL(e);
+            b->bc -= (int)E_TOTAL(e);
             continue;
         }
+        const uint32_t len = E_VALUE(e, b->bb);
+        b->bb >>= E_TOTAL(e);
+        b->bc -= (int)E_TOTAL(e);
         if (E_KIND(e) == K_EOB) return 0;
         if (E_KIND(e) != K_BASE) return -1;
-        uint32_t x;
-        if (take_bits(b, (int)E_EXTRA(e), &x)) return -1;
-        const uint32_t len = E_BASE(e) + x;
         refill_safe(b);
         uint32_t d = dst[b->bb & dmask];
         if (E_KIND(d) == K_SUB) {
@@ -335,13 +348,12 @@ static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32
             b->bb >>= DST_BITS;
             b->bc -= DST_BITS;
             refill_safe(b);
-            d = dst[E_BASE(d) + (b->bb & ((1u << E_EXTRA(d)) - 1))];
+            d = dst[E_BASE(d) + (b->bb & ((1u << E_CODE(d)) - 1))];
         }
-        if (E_KIND(d) != K_BASE || (int)E_NBITS(d) > b->bc) return -1;
-        b->bb >>= E_NBITS(d);
-        b->bc -= (int)E_NBITS(d);
-        if (take_bits(b, (int)E_EXTRA(d), &x)) return -1;
-        const uint32_t dist = E_BASE(d) + x;
+        if (E_KIND(d) != K_BASE || (int)E_TOTAL(d) > b->bc) return -1;
+        const uint32_t dist = E_VALUE(d, b->bb);
+        b->bb >>= E_TOTAL(d);
+        b->bc -= (int)E_TOTAL(d);
         if (o->len - member_start < dist) return -1;
         for (uint32_t i = 0; i < len; i++, o->len++) o->out[o->len] = o->out[o->len - dist];
     }
