@@ -364,7 +364,6 @@ extern "C" int kssd_gpu_warm_up(int device)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KSSD_ERR_NO_DEVICE;
     HIPCK(hipSetDevice(device));
-    if (getenv("KSSD_DEV_SYNC_FLAGS")) hipSetDeviceFlags((unsigned)atoi(getenv("KSSD_DEV_SYNC_FLAGS")));
     HIPCK(hipFree(nullptr));  // the device's context
     hipLaunchKernelGGL(warm_up_kernel, dim3(1), dim3(64), 0, 0, (uint32_t *)nullptr);  // the library's code object onto the device
     HIPCK(hipGetLastError());

@@ -780,6 +780,7 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     /* a device batch: at most ~0.5 Gbases (so that several are in flight and the transfers hide under the kernels) */
     const uint64_t max_chunks = 1ull << 17;
     double t_read = 0, t_tok = 0;
+    double t_unpack_thr = 0, t_copy_thr = 0, t_wait_text = 0; /* summed over the host threads: inside the readers / unpackers, inside the copies into the job's text; the main thread waiting for a free text buffer */
     uint64_t n_bytes = 0;
     int done = 0, n_jobs = 0;
     /* A wave = `threads` consecutive inputs, read (and unpacked) one per host thread.  Its buffers are kept and reused (no fresh
@@ -795,7 +796,7 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     } wave_buf;
     int gz_ahead = 8;
     if (getenv("KSSD_GZ_AHEAD")) gz_ahead = atoi(getenv("KSSD_GZ_AHEAD"));
-    if (gz_ahead < 0) gz_ahead = 0;
+    if (gz_ahead < 1) gz_ahead = 1; /* (two waves are read together) */
     if (gz_ahead > 64) gz_ahead = 64;
     wave_buf *waves = calloc((size_t)gz_ahead + 1, sizeof *waves); /* a ring: waves read and not yet turned into jobs */
     for (int w = 0; w <= gz_ahead; w++) {
@@ -813,36 +814,62 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     const int fq_dev = (o->abundance || (o->kmerqlty >= 0 && o->kmerqlty <= 127)) && !getenv("KSSD_HOST_FASTQ");
     stream_env();
     for (int i0 = 0; i0 < fl->n; i0 += threads) {
-        /* read the next wave -- and, as long as the runtime is not up, the waves behind it */
+        /* read the next wave -- and, as long as the runtime is not up, the waves behind it.  Two waves go through one parallel region,
+         * file i of the one and file i of the other on the same thread: two gzip'ed files are unpacked in step (kssd_slurp_reuse2) */
         while (next_read < fl->n && (w_count == 0 || (!g_runtime_ready && w_count <= gz_ahead))) {
-            wave_buf *wb = &waves[(w_head + w_count) % (gz_ahead + 1)];
-            wb->i0 = next_read;
-            wb->nw = (next_read + threads < fl->n ? next_read + threads : fl->n) - next_read;
+            wave_buf *wv[2] = {NULL, NULL};
+            int n_wv = 0;
+            for (; n_wv < 2 && next_read < fl->n && w_count <= gz_ahead; n_wv++) {
+                wave_buf *wb = wv[n_wv] = &waves[(w_head + w_count) % (gz_ahead + 1)];
+                wb->i0 = next_read;
+                wb->nw = (next_read + threads < fl->n ? next_read + threads : fl->n) - next_read;
+                next_read += wb->nw;
+                w_count++;
+            }
             double t0 = now_s();
-            /* read + gunzip, one file each.  gzip'ed files (and FASTQ files the host tokenises) go into the wave's scratch
-             * buffers; a plain file the device tokenises is only measured here and read straight into page-locked memory below */
+            /* read + gunzip.  gzip'ed files (and FASTQ files the host tokenises) go into the wave's scratch buffers; a plain file
+             * the device tokenises is only measured here and read straight into page-locked memory below */
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-            for (int i = 0; i < wb->nw; i++) {
-                const char *path = fl->path[wb->i0 + i];
-                int gz = 0;
-                uint64_t sz = 0;
-                wb->direct[i] = 0;
-                wb->trc[i] = kssd_file_probe(path, &gz, &sz);
-                if (wb->trc[i]) continue;
-                const int dev_tok = fq_dev || !has_fmt(path, fq_fmt); /* the device tokenises it */
-                if (!gz && dev_tok) {
-                    wb->direct[i] = 1;
-                    wb->len[i] = (size_t)sz;
-                } else if (gz && dev_tok && sz >= STREAM_MIN_GZ) {
-                    wb->direct[i] = 2; /* inflated by the device worker, slice by slice, on its way to the device */
-                    wb->len[i] = (size_t)sz;
-                } else {
-                    wb->trc[i] = kssd_slurp_reuse(path, &wb->txt[i], &wb->txt_cap[i], &wb->len[i]);
+            for (int i = 0; i < wv[0]->nw; i++) {
+                const double ti0 = now_s();
+                int slurp[2] = {0, 0};
+                for (int v = 0; v < n_wv; v++) {
+                    wave_buf *wb = wv[v];
+                    if (i >= wb->nw) continue;
+                    const char *path = fl->path[wb->i0 + i];
+                    int gz = 0;
+                    uint64_t sz = 0;
+                    wb->direct[i] = 0;
+                    wb->trc[i] = kssd_file_probe(path, &gz, &sz);
+                    if (wb->trc[i]) continue;
+                    const int dev_tok = fq_dev || !has_fmt(path, fq_fmt); /* the device tokenises it */
+                    if (!gz && dev_tok) {
+                        wb->direct[i] = 1;
+                        wb->len[i] = (size_t)sz;
+                    } else if (gz && dev_tok && sz >= STREAM_MIN_GZ) {
+                        wb->direct[i] = 2; /* inflated by the device worker, slice by slice, on its way to the device */
+                        wb->len[i] = (size_t)sz;
+                    } else {
+                        slurp[v] = 1;
+                    }
                 }
+                if (slurp[0] && slurp[1]) {
+                    const char *const path[2] = {fl->path[wv[0]->i0 + i], fl->path[wv[1]->i0 + i]};
+                    unsigned char **buf[2] = {&wv[0]->txt[i], &wv[1]->txt[i]};
+                    size_t *cap[2] = {&wv[0]->txt_cap[i], &wv[1]->txt_cap[i]}, *len[2] = {&wv[0]->len[i], &wv[1]->len[i]};
+                    int rc[2];
+                    kssd_slurp_reuse2(path, buf, cap, len, rc);
+                    wv[0]->trc[i] = rc[0];
+                    wv[1]->trc[i] = rc[1];
+                } else {
+                    for (int v = 0; v < 2; v++)
+                        if (slurp[v]) wv[v]->trc[i] = kssd_slurp_reuse(fl->path[wv[v]->i0 + i], &wv[v]->txt[i], &wv[v]->txt_cap[i], &wv[v]->len[i]);
+                }
+                const double dti = now_s() - ti0;
+#pragma omp atomic
+                t_unpack_thr += dti;
             }
             t_read += now_s() - t0;
-            next_read += wb->nw;
-            w_count++;
         }
         wave_buf *wb = &waves[w_head];
         w_head = (w_head + 1) % (gz_ahead + 1);
@@ -898,6 +925,7 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                  * taken off the queues yet), one more: the inputs are read ahead into memory up to the budget */
                 /* a free text buffer -- or, while the runtime is still starting (nothing is taken off the queues yet), one more: up
                  * to TEXT_BUFS_AHEAD of them are read ahead into ordinary memory; they stay the command's buffers afterwards */
+                const double tw0 = now_s();
                 pthread_mutex_lock(&pl.mu);
                 while (pl.n_tpool == 0 && (g_runtime_ready || pl.n_text_made >= text_ahead)) pthread_cond_wait(&pl.cv, &pl.mu);
                 textbuf *tx;
@@ -914,9 +942,11 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     g_runtime_ready = 1; /* (a runtime that failed to start is reported by the workers' context creation) */
                 }
                 textbuf_fit(tx, at + 64, g_runtime_ready);
+                t_wait_text += now_s() - tw0; /* (a free buffer, the runtime's start, page-locked memory for a new one) */
                 t0 = now_s();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
                 for (int i = r0; i < r1; i++) {
+                    const double ti0 = now_s();
                     unsigned char *dst = tx->p + j->toff[i - r0];
                     if (direct[i] == 1) {
                         size_t got = 0;
@@ -925,6 +955,9 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     } else {
                         memcpy(dst, txt[i], len[i]);
                     }
+                    const double dti = now_s() - ti0;
+#pragma omp atomic
+                    t_copy_thr += dti;
                 }
                 t_read += now_s() - t0;
                 for (int i = r0; i < r1; i++) {
@@ -1094,9 +1127,9 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     free(s.sub);
     if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
         fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
-                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_tokenise\": %.6f, "
+                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_unpack_threads_summed\": %.6f, \"s_copy_threads_summed\": %.6f, \"s_wait_text_buffer\": %.6f, \"s_tokenise\": %.6f, "
                         "\"s_workers_summed\": %.6f, \"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
-                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_shuf, sc.from_cache, t_read, t_tok,
+                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_shuf, sc.from_cache, t_read, t_unpack_thr, t_copy_thr, t_wait_text, t_tok,
                 pl.t_gpu, pl.t_call, t_written - t_sketched);
 }
 

@@ -794,6 +794,37 @@ int kssd_slurp(const char *path, unsigned char **buf, size_t *len)
     return rc;
 }
 
+/* an open file's bytes from where it stands to its end (st_size is a hint), in a buffer the THREAD keeps from file to file: a
+ * compressed genome is 1 - 2 MB, which malloc() serves by mmap -- a thousand files are a thousand mappings, half a million page
+ * faults and as many trips through the process's one address-space lock, taken by sixteen threads at once.  `slot` 0 / 1: the two
+ * files of a pair.  The buffers live as long as the thread. */
+static __thread unsigned char *t_zbuf[2];
+static __thread size_t t_zcap[2];
+static int read_fd_whole(int fd, int slot, unsigned char **out, size_t *n_out)
+{
+    struct stat zst;
+    if (fstat(fd, &zst) != 0) return KSSD_HOST_ERR_IO;
+    size_t zn = 0;
+    for (;;) {
+        const size_t want = zn + ((size_t)zst.st_size > zn ? (size_t)zst.st_size - zn : 0) + 4096;
+        if (t_zcap[slot] < want) {
+            const size_t nc = want + want / 4;
+            unsigned char *q = realloc(t_zbuf[slot], nc);
+            if (!q) return KSSD_HOST_ERR_NOMEM;
+            t_zbuf[slot] = q;
+            t_zcap[slot] = nc;
+        }
+        const ssize_t r = read(fd, t_zbuf[slot] + zn, t_zcap[slot] - zn);
+        if (r < 0) return KSSD_HOST_ERR_IO;
+        if (r == 0) break;
+        zn += (size_t)r;
+        zst.st_size = 0; /* (whatever comes beyond the hint: 4 KiB at a time, the buffer grows by a quarter) */
+    }
+    *out = t_zbuf[slot];
+    *n_out = zn;
+    return KSSD_HOST_OK;
+}
+
 /* the same into a buffer the caller keeps from file to file (grown when needed): no allocation, no page faults of fresh
  * memory per file.  Plain files are read straight with read(2); gzip'ed ones (magic 1f 8b) go through zlib. */
 int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t *len)
@@ -805,26 +836,11 @@ int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t 
     *len = 0;
     if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b && !getenv("KSSD_ZLIB_GUNZIP")) {
         /* the compressed bytes whole, then host/kssd_inflate.c (KSSD_ZLIB_GUNZIP=1: zlib's gzread below, the decoder of rounds 1 - 4) */
-        struct stat zst;
-        if (fstat(fd, &zst) != 0) { close(fd); return KSSD_HOST_ERR_IO; }
-        size_t zcap = (size_t)zst.st_size + 4096, zn = 0;
-        unsigned char *z = malloc(zcap);
-        if (!z) { close(fd); return KSSD_HOST_ERR_NOMEM; }
-        for (;;) {
-            if (zcap - zn < 4096) {
-                unsigned char *q = realloc(z, zcap + zcap / 2);
-                if (!q) { free(z); close(fd); return KSSD_HOST_ERR_NOMEM; }
-                z = q;
-                zcap += zcap / 2;
-            }
-            const ssize_t r = read(fd, z + zn, zcap - zn);
-            if (r < 0) { free(z); close(fd); return KSSD_HOST_ERR_IO; }
-            if (r == 0) break;
-            zn += (size_t)r;
-        }
+        unsigned char *z = NULL;
+        size_t zn = 0;
+        int rc = read_fd_whole(fd, 0, &z, &zn);
         close(fd);
-        const int rc = kssd_gunzip_mem(z, zn, buf, cap, len);
-        free(z);
+        if (rc == KSSD_HOST_OK) rc = kssd_gunzip_mem(z, zn, buf, cap, len);
         return rc;
     }
     if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
@@ -870,6 +886,27 @@ int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t 
     close(fd);
     *len = n;
     return KSSD_HOST_OK;
+}
+
+/* two files by one thread: gzip'ed ones are unpacked in step (kssd_gunzip_mem2: the two decoders' lookups overlap); anything else
+ * -- a plain file, KSSD_ZLIB_GUNZIP=1, a file that cannot be opened -- goes through kssd_slurp_reuse, one after the other */
+void kssd_slurp_reuse2(const char *const path[2], unsigned char **buf[2], size_t *cap[2], size_t *len[2], int rc[2])
+{
+    unsigned char *z[2] = {NULL, NULL};
+    size_t zn[2] = {0, 0};
+    int gz = !getenv("KSSD_ZLIB_GUNZIP") && !getenv("KSSD_GZ_ONE_AT_A_TIME"); /* (the second: measurements) */
+    for (int f = 0; f < 2 && gz; f++) {
+        const int fd = open(path[f], O_RDONLY);
+        unsigned char magic[2];
+        if (fd < 0 || pread(fd, magic, 2, 0) != 2 || magic[0] != 0x1f || magic[1] != 0x8b || read_fd_whole(fd, f, &z[f], &zn[f]) != KSSD_HOST_OK) gz = 0;
+        if (fd >= 0) close(fd);
+    }
+    if (gz) {
+        const unsigned char *const in[2] = {z[0], z[1]};
+        kssd_gunzip_mem2(in, zn, buf, cap, len, rc);
+    } else {
+        for (int f = 0; f < 2; f++) rc[f] = kssd_slurp_reuse(path[f], buf[f], cap[f], len[f]);
+    }
 }
 
 /* is the file gzip'ed (magic 1f 8b), and how many bytes does it hold on disk */

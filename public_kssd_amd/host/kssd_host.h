@@ -91,6 +91,8 @@ int kssd_slurp(const char *path, unsigned char **buf, size_t *len);
 /* the same into a malloc'd buffer the caller keeps from file to file: *buf / *cap are grown (realloc) when the file
  * does not fit, *len receives the bytes read; the caller frees *buf in the end */
 int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t *len);
+/* two files by one thread; gzip'ed ones are unpacked in step (kssd_gunzip_mem2).  rc[f]: kssd_slurp_reuse's for file f */
+void kssd_slurp_reuse2(const char *const path[2], unsigned char **buf[2], size_t *cap[2], size_t *len[2], int rc[2]);
 /* is the file gzip'ed (magic 1f 8b), and its size on disk; kssd_read_into copies a plain file's bytes (at most cap) into
  * memory of the caller's choice -- e.g. a page-locked buffer the device tokeniser reads from */
 int kssd_file_probe(const char *path, int *is_gz, uint64_t *size);
@@ -101,6 +103,9 @@ int kssd_read_into(const char *path, unsigned char *dst, size_t cap, size_t *len
  * literals per lookup) -- sequence text is what zlib's byte loop is slowest on.  kssd_crc32: zlib's crc32(), by carry-less
  * multiplication where the CPU has it. */
 int kssd_gunzip_mem(const unsigned char *in, size_t in_len, unsigned char **out, size_t *cap, size_t *len);
+/* two files by one thread, their symbol loops in step (two independent chains of table lookups fill the core where one leaves it
+ * half idle); rc[f] is what kssd_gunzip_mem returns for file f */
+void kssd_gunzip_mem2(const unsigned char *const in[2], const size_t in_len[2], unsigned char **out[2], size_t *cap[2], size_t *len[2], int rc[2]);
 uint32_t kssd_crc32(uint32_t crc, const unsigned char *p, size_t len);
 
 /* ---- derived constants (seq2co_global_var_initial iseq2comem.c:54-77, get_hashsz command_dist.c:217-236) */

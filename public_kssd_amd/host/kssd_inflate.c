@@ -21,24 +21,35 @@
 #endif
 
 /* ---- table entries ------------------------------------------------------------------------------------------------------------
- * bits 0-5   ALL the bits this entry consumes, in one shift (the x86 shift takes its count from the low six bits of the entry as it
- *            is): a literal group's codes; a length's or distance's code AND the extra bits behind it; behind a first-level pointer,
- *            the second-level part of the code (+ extra bits); for the pointer itself, the first level's bits
- * bits 6-7   0 / 1 / 2: one / two / three literal bytes in bits 8-31;  3: something else, namely
- * bits 8-11      the code's own bits (K_BASE: the extra bits are what bits 0-5 hold beyond them; K_SUB: the second level's index bits)
- * bits 12-14     K_BASE (a length or distance: base in bits 16-31), K_SUB (second-level table: first entry in bits 16-31), K_EOB, K_BAD */
-enum { K_BASE = 0, K_SUB = 1, K_EOB = 2, K_BAD = 3 };
-#define ENTRY_LITS(nbits, count, bytes) ((uint32_t)(nbits) | ((uint32_t)((count) - 1) << 6) | ((uint32_t)(bytes) << 8))
-#define ENTRY_OTHER(total, kind, code_bits, base) ((uint32_t)(total) | 0xC0u | ((uint32_t)(code_bits) << 8) | ((uint32_t)(kind) << 12) | ((uint32_t)(base) << 16))
-#define E_TOTAL(e) ((e) & 63u)
-#define E_IS_LIT(e) (((e) & 0xC0u) != 0xC0u)
-#define E_LIT_COUNT(e) ((((e) >> 6) & 3u) + 1u) /* (of a literal entry) */
-#define E_LITS(e) ((e) >> 8)
-#define E_KIND(e) (((e) >> 12) & 7u)            /* (of any other entry) */
+ * Laid out for the instructions the symbol loop spends on an entry (two files in step run at the core's instruction rate):
+ * bits 0-7   ALL the bits the entry consumes, a byte of its own: the bit buffer is shifted by the entry as it is (the shift takes its
+ *            count from the low six bits), the bit count subtracts the entry as it is (only its low byte is ever looked at), and the
+ *            mask of a length's or distance's extra bits takes its width from it -- a literal's code(s); a length's or distance's code
+ *            AND the extra bits behind it; behind a first-level pointer the second-level part of the code (+ extra bits); for the
+ *            pointer itself, the first level's bits
+ * bits 8-11  a length / distance: the code's own bits (its extra bits are what bits 0-7 count beyond them); a pointer: the second
+ *            level's index bits
+ * bit 12     F_LIT: one literal byte in bits 16-23 -- bit 13, F_LIT2: and a second one in bits 24-31
+ * bit 14     F_SUB: pointer to a second-level table, its first entry in bits 16-31
+ * bit 15     F_EXC: the end-of-block code (bits 16-31 = 1) or a code nobody owns (0)
+ * none of bits 12-15: a length or distance, its base in bits 16-31 */
+#define F_LIT 0x1000u
+#define F_LIT2 0x2000u
+#define F_SUB 0x4000u
+#define F_EXC 0x8000u
+#define ENTRY_LIT1(nbits, b0) ((uint32_t)(nbits) | F_LIT | ((uint32_t)(b0) << 16))
+#define ENTRY_LIT2(nbits, b0, b1) ((uint32_t)(nbits) | F_LIT | F_LIT2 | ((uint32_t)(b0) << 16) | ((uint32_t)(b1) << 24))
+#define ENTRY_BASE(total, code_bits, base) ((uint32_t)(total) | ((uint32_t)(code_bits) << 8) | ((uint32_t)(base) << 16))
+#define ENTRY_SUB(main_bits, index_bits, first) ((uint32_t)(main_bits) | ((uint32_t)(index_bits) << 8) | F_SUB | ((uint32_t)(first) << 16))
+#define ENTRY_EOB(nbits) ((uint32_t)(nbits) | F_EXC | (1u << 16))
+#define ENTRY_BAD F_EXC
+#define E_TOTAL(e) ((e) & 255u)
 #define E_CODE(e) (((e) >> 8) & 15u)
-#define E_BASE(e) ((e) >> 16)
-/* a length's / distance's value: base + the extra bits, which sit behind the code in the low E_TOTAL bits of the bit buffer */
-#define E_VALUE(e, bb) (E_BASE(e) + (((uint32_t)(bb) & ((1u << E_TOTAL(e)) - 1u)) >> E_CODE(e)))
+#define E_PAYLOAD(e) ((e) >> 16)
+#define E_IS_BASE(e) (((e) & 0xF000u) == 0)
+/* a length's / distance's value: base + the extra bits, which sit behind the code in the low E_TOTAL bits of the bit buffer (the
+ * shift by `(e >> 8) & 63` is the shift by E_CODE: bits 12 and 13 of such an entry are clear) */
+#define E_VALUE(e, bb) (E_PAYLOAD(e) + (uint32_t)(((bb) & (((uint64_t)1 << E_TOTAL(e)) - 1)) >> (((e) >> 8) & 63u)))
 
 #define LIT_BITS 11
 #define DST_BITS 8
@@ -70,11 +81,11 @@ static uint32_t rev_bits(uint32_t v, int n)
 /* what symbol `sym` of the literal/length (dist = 0) or distance (dist = 1) alphabet decodes to, in a code of nbits bits */
 static uint32_t leaf(int dist, int sym, int nbits)
 {
-    if (dist) return sym < 30 ? ENTRY_OTHER(nbits + dst_extra[sym], K_BASE, nbits, dst_base[sym]) : ENTRY_OTHER(nbits, K_BAD, 0, 0);
-    if (sym < 256) return ENTRY_LITS(nbits, 1, sym);
-    if (sym == 256) return ENTRY_OTHER(nbits, K_EOB, 0, 0);
-    if (sym < 286) return ENTRY_OTHER(nbits + len_extra[sym - 257], K_BASE, nbits, len_base[sym - 257]);
-    return ENTRY_OTHER(nbits, K_BAD, 0, 0);
+    if (dist) return sym < 30 ? ENTRY_BASE(nbits + dst_extra[sym], nbits, dst_base[sym]) : ENTRY_BAD;
+    if (sym < 256) return ENTRY_LIT1(nbits, sym);
+    if (sym == 256) return ENTRY_EOB(nbits);
+    if (sym < 286) return ENTRY_BASE(nbits + len_extra[sym - 257], nbits, len_base[sym - 257]);
+    return ENTRY_BAD;
 }
 
 /* canonical code lengths -> decoding tables.  -1: the lengths oversubscribe the code space (or need more room than there is) */
@@ -93,7 +104,7 @@ static int build_tables(const uint8_t *lens, int n_sym, int dist, uint32_t *tab,
         next_code[l] = code;
     }
     const int main_n = 1 << main_bits;
-    for (int i = 0; i < main_n; i++) tab[i] = ENTRY_OTHER(0, K_BAD, 0, 0); /* (an incomplete set: a code nobody owns is an error when it is met) */
+    for (int i = 0; i < main_n; i++) tab[i] = ENTRY_BAD; /* (an incomplete set: a code nobody owns is an error when it is met) */
     uint8_t sub_bits[1 << LIT_BITS];
     memset(sub_bits, 0, (size_t)main_n);
     uint16_t rev[288];
@@ -114,34 +125,28 @@ static int build_tables(const uint8_t *lens, int n_sym, int dist, uint32_t *tab,
     for (int p = 0; p < main_n; p++) {
         if (!sub_bits[p]) continue;
         if (next + (1 << sub_bits[p]) > room) return -1;
-        tab[p] = ENTRY_OTHER(main_bits, K_SUB, sub_bits[p], next);
-        for (int i = 0; i < (1 << sub_bits[p]); i++) tab[next + i] = ENTRY_OTHER(0, K_BAD, 0, 0);
+        tab[p] = ENTRY_SUB(main_bits, sub_bits[p], next);
+        for (int i = 0; i < (1 << sub_bits[p]); i++) tab[next + i] = ENTRY_BAD;
         next += 1 << sub_bits[p];
     }
     for (int s = 0; s < n_sym; s++) {
         const int l = lens[s];
         if (l <= main_bits) continue;
         const uint32_t p = rev[s] & (uint32_t)(main_n - 1), hi = rev[s] >> main_bits;
-        const uint32_t base = E_BASE(tab[p]), sb = E_CODE(tab[p]);
+        const uint32_t base = E_PAYLOAD(tab[p]), sb = E_CODE(tab[p]);
         const uint32_t e = leaf(dist, s, l - main_bits);
         for (uint32_t i = hi; i < (1u << sb); i += 1u << (l - main_bits)) tab[base + i] = e;
     }
     if (!dist) {
-        /* literal groups: a first-level slot whose bits hold two or three whole literal codes answers all of them at once */
+        /* literal pairs: a first-level slot whose bits hold two whole literal codes answers both at once */
         memcpy(single, tab, (size_t)main_n * sizeof(uint32_t));
         for (int i = 0; i < main_n; i++) {
             const uint32_t e1 = single[i];
-            if (!E_IS_LIT(e1)) continue;
+            if (!(e1 & F_LIT)) continue;
             const uint32_t n1 = E_TOTAL(e1);
             const uint32_t e2 = single[(uint32_t)i >> n1]; /* the unknown bits above read as zeros: right for every code that fits the known ones */
             const uint32_t n2 = E_TOTAL(e2);
-            if (!E_IS_LIT(e2) || n1 + n2 > (uint32_t)main_bits) continue;
-            const uint32_t e3 = single[(uint32_t)i >> (n1 + n2)];
-            const uint32_t n3 = E_TOTAL(e3);
-            if (E_IS_LIT(e3) && n1 + n2 + n3 <= (uint32_t)main_bits)
-                tab[i] = ENTRY_LITS(n1 + n2 + n3, 3, E_LITS(e1) | (E_LITS(e2) << 8) | (E_LITS(e3) << 16));
-            else
-                tab[i] = ENTRY_LITS(n1 + n2, 2, E_LITS(e1) | (E_LITS(e2) << 8));
+            if ((e2 & F_LIT) && n1 + n2 <= (uint32_t)main_bits) tab[i] = ENTRY_LIT2(n1 + n2, E_PAYLOAD(e1) & 255u, E_PAYLOAD(e2) & 255u);
         }
     }
     return 0;
@@ -206,151 +211,175 @@ static int out_room(outbuf *o, size_t more)
  * steps from one table entry to the next: refill -> look up -> shift.  So a match is ONE refill (56 bits hold the longest length
  * and distance: 15 + 5 + 15 + 13), each entry is ONE shift (its count covers the extra bits too, the value is picked off the side),
  * and the copy hangs off the chain (nothing it produces is needed to decode on). */
-static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32_t *lit_one, const uint32_t *dst, size_t member_start)
+/* the symbol loops are built twice, with and without BMI2 (shifts and masks by a register's count in one instruction, no detour
+ * through %cl), and the loader picks by the CPU */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define HOT_CLONES __attribute__((target_clones("bmi2", "default")))
+#else
+#define HOT_CLONES
+#endif
+
+/* one turn of the fast loop on the stream whose locals end in S: literals (up to three lookups of up to two each) or a match.
+ * `break` leaves the turn; the end-of-block code and a corrupt stream set rc##S and leave the loop (label `stop`).  bc##S: only its
+ * low byte is the bit count (whole entries are subtracted from it). */
+#define REFILL(S)                                       \
+    do {                                                \
+        bb##S |= load64(in##S) << (bc##S & 63);         \
+        in##S += 7 - ((bc##S >> 3) & 7);                \
+        bc##S |= 56;                                    \
+    } while (0)
+#define CONSUME(S, e)                                   \
+    do {                                                \
+        bb##S >>= (e) & 63;                             \
+        bc##S -= (e);                                   \
+    } while (0)
+#define PUT_GROUP(S)                                    \
+    do {                                                \
+        const uint16_t w = (uint16_t)E_PAYLOAD(e);      \
+        memcpy(out##S, &w, 2);                          \
+        out##S += 1 + ((e >> 13) & 1);                  \
+        CONSUME(S, e);                                  \
+    } while (0)
+#define STEP(S)                                                                                                                     \
+    do {                                                                                                                            \
+        REFILL(S); /* eight bytes over the top of what is left, whole bytes accepted: 56 - 63 real bits afterwards */               \
+        uint32_t e = lit##S[bb##S & lmask];                                                                                         \
+        int behind_literals = 0;                                                                                                    \
+        if (e & F_LIT) {                                                                                                            \
+            PUT_GROUP(S);                                                                                                           \
+            e = lit##S[bb##S & lmask];                                                                                              \
+            if (e & F_LIT) {                                                                                                        \
+                PUT_GROUP(S);                                                                                                       \
+                e = lit##S[bb##S & lmask];                                                                                          \
+                if (e & F_LIT) {                                                                                                    \
+                    PUT_GROUP(S);                                                                                                   \
+                    break;                                                                                                          \
+                }                                                                                                                   \
+            }                                                                                                                       \
+            behind_literals = 1; /* up to 22 bits are gone: a length (20) still fits, the distance behind it (28) may not */        \
+        }                                                                                                                           \
+        if (__builtin_expect(!E_IS_BASE(e), 0)) { /* (no literal here: a pointer, the end of the block, nobody's code) */           \
+            if (e & F_SUB) {                                                                                                        \
+                CONSUME(S, e);                                                                                                      \
+                e = lit##S[E_PAYLOAD(e) + (bb##S & ((1u << E_CODE(e)) - 1))];                                                       \
+                if (e & F_LIT) { /* (a literal with a long code) */                                                                 \
+                    *out##S++ = (unsigned char)E_PAYLOAD(e);                                                                        \
+                    CONSUME(S, e);                                                                                                  \
+                    break;                                                                                                          \
+                }                                                                                                                   \
+            }                                                                                                                       \
+            if (e & F_EXC) {                                                                                                        \
+                CONSUME(S, e);                                                                                                      \
+                rc##S = E_PAYLOAD(e) ? 0 : -1;                                                                                      \
+                goto stop;                                                                                                          \
+            }                                                                                                                       \
+        }                                                                                                                           \
+        const uint32_t len = E_VALUE(e, bb##S);                                                                                     \
+        CONSUME(S, e);                                                                                                              \
+        if (behind_literals) REFILL(S);                                                                                             \
+        uint32_t d = dst##S[bb##S & dmask];                                                                                         \
+        if (__builtin_expect(!E_IS_BASE(d), 0)) {                                                                                   \
+            if (d & F_SUB) {                                                                                                        \
+                CONSUME(S, d);                                                                                                      \
+                d = dst##S[E_PAYLOAD(d) + (bb##S & ((1u << E_CODE(d)) - 1))];                                                       \
+            }                                                                                                                       \
+            if (!E_IS_BASE(d)) { rc##S = -1; goto stop; } /* (the distance tables hold no literals and no end of block) */          \
+        }                                                                                                                           \
+        const uint32_t dist = E_VALUE(d, bb##S);                                                                                    \
+        CONSUME(S, d);                                                                                                              \
+        if (__builtin_expect((size_t)(out##S - out_min##S) < dist, 0)) { rc##S = -1; goto stop; } /* before the member's first byte */ \
+        const unsigned char *src = out##S - dist;                                                                                   \
+        unsigned char *const end = out##S + len;                                                                                    \
+        if (__builtin_expect(dist >= 16, 1)) { /* the common case first, without a loop: a match of up to 16 bytes is one copy */    \
+            memcpy(out##S, src, 16);                                                                                                \
+            if (__builtin_expect(len > 16, 0)) {                                                                                    \
+                out##S += 16;                                                                                                       \
+                src += 16;                                                                                                          \
+                do {                                                                                                                \
+                    memcpy(out##S, src, 16);                                                                                        \
+                    out##S += 16;                                                                                                   \
+                    src += 16;                                                                                                      \
+                } while (out##S < end);                                                                                             \
+            }                                                                                                                       \
+        } else if (dist >= 8) {                                                                                                     \
+            do {                                                                                                                    \
+                memcpy(out##S, src, 8);                                                                                             \
+                out##S += 8;                                                                                                        \
+                src += 8;                                                                                                           \
+            } while (out##S < end);                                                                                                 \
+        } else if (dist == 1) {                                                                                                     \
+            memset(out##S, *src, len);                                                                                              \
+        } else {                                                                                                                    \
+            do { *out##S++ = *src++; } while (out##S < end);                                                                        \
+        }                                                                                                                           \
+        out##S = end;                                                                                                               \
+    } while (0)
+/* the locals of a stream inside a fast loop, and their way back into the stream's reader and output */
+#define FAST_LOCALS(S, b, o, lit_, dst_, member_start)                                                                               \
+    const unsigned char *in##S = (b)->in, *const in_fast##S = (b)->in_end - 16;                                                     \
+    unsigned char *out##S = (o)->out + (o)->len, *const out_fast##S = (o)->out + (o)->cap - FAST_OUT_MARGIN;                        \
+    unsigned char *const out_min##S = (o)->out + (member_start);                                                                    \
+    const uint32_t *const lit##S = (lit_), *const dst##S = (dst_);                                                                  \
+    uint64_t bb##S = (b)->bb;                                                                                                       \
+    uint32_t bc##S = (uint32_t)(b)->bc
+#define FAST_STORE(S, b, o) /* (the bit buffer may hold bytes beyond what the symbols used: bc counts the real bits only) */       \
+    do {                                                                                                                            \
+        (b)->in = in##S;                                                                                                            \
+        (b)->bb = bb##S;                                                                                                            \
+        (b)->bc = (int)(bc##S & 255u);                                                                                                      \
+        (o)->len = (size_t)(out##S - (o)->out);                                                                                     \
+    } while (0)
+#define FAST_FITS(b, o) ((b)->in_end - (b)->in >= 16 && (o)->cap - (o)->len >= FAST_OUT_MARGIN)
+
+HOT_CLONES static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32_t *lit_one, const uint32_t *dst, size_t member_start)
 {
     const uint64_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DST_BITS) - 1;
     for (;;) {
         /* ---- fast: at least 16 input bytes and FAST_OUT_MARGIN output bytes to spare, no check per symbol ---- */
-        if (b->in_end - b->in >= 16 && o->cap - o->len >= FAST_OUT_MARGIN) {
-            const unsigned char *in = b->in, *const in_fast = b->in_end - 16;
-            unsigned char *out = o->out + o->len, *const out_fast = o->out + o->cap - FAST_OUT_MARGIN;
-            unsigned char *const out_min = o->out + member_start;
-            uint64_t bb = b->bb;
-            int bc = b->bc;
-            int rc = 1; /* 1: ran out of margin, 0: end of block, -1: corrupt */
-#define REFILL()                        \
-    do {                                \
-        bb |= load64(in) << bc;         \
-        in += (63 - bc) >> 3;           \
-        bc |= 56;                       \
-    } while (0)
-#define CONSUME(e)                      \
-    do {                                \
-        bb >>= E_TOTAL(e);              \
-        bc -= (int)E_TOTAL(e);          \
-    } while (0)
-#define PUT_GROUP()                     \
-    do {                                \
-        const uint32_t w = E_LITS(e);   \
-        memcpy(out, &w, 4);             \
-        out += E_LIT_COUNT(e);          \
-        CONSUME(e);                     \
-    } while (0)
-            while (in <= in_fast && out <= out_fast) {
-                REFILL(); /* eight bytes over the top of what is left, whole bytes accepted: 56 - 63 real bits afterwards */
-                uint32_t e = lit[bb & lmask];
-                int behind_literals = 0;
-                if (E_IS_LIT(e)) {
-                    /* up to three lookups of literals (33 bits at most) before anything else is looked at */
-                    PUT_GROUP();
-                    e = lit[bb & lmask];
-                    if (E_IS_LIT(e)) {
-                        PUT_GROUP();
-                        e = lit[bb & lmask];
-                        if (E_IS_LIT(e)) {
-                            PUT_GROUP();
-                            continue;
-                        }
-                    }
-                    behind_literals = 1; /* up to 22 bits are gone: a length (20) still fits, the distance behind it (28) may not */
-                }
-                if (E_KIND(e) == K_SUB) {
-                    CONSUME(e);
-                    e = lit[E_BASE(e) + (bb & ((1u << E_CODE(e)) - 1))];
-                    if (E_IS_LIT(e)) { /* (a literal with a long code) */
-                        *out++ = (unsigned char)E_LITS(e);
-                        CONSUME(e);
-                        continue;
-                    }
-                }
-                if (E_KIND(e) != K_BASE) {
-                    CONSUME(e);
-                    rc = E_KIND(e) == K_EOB ? 0 : -1;
-                    break;
-                }
-                const uint32_t len = E_VALUE(e, bb);
-                CONSUME(e);
-                if (behind_literals) REFILL();
-                uint32_t d = dst[bb & dmask];
-                if (E_KIND(d) == K_SUB) {
-                    CONSUME(d);
-                    d = dst[E_BASE(d) + (bb & ((1u << E_CODE(d)) - 1))];
-                }
-                if (E_KIND(d) != K_BASE) { rc = -1; break; } /* (the distance tables hold no literal entries: every entry has a kind) */
-                const uint32_t dist = E_VALUE(d, bb);
-                CONSUME(d);
-                if ((size_t)(out - out_min) < dist) { rc = -1; break; } /* before the member's first byte */
-                const unsigned char *src = out - dist;
-                unsigned char *const end = out + len;
-                if (dist >= 16) { /* the common case first, without a loop: a match of up to 16 bytes is one copy */
-                    memcpy(out, src, 16);
-                    if (len > 16) {
-                        out += 16;
-                        src += 16;
-                        do {
-                            memcpy(out, src, 16);
-                            out += 16;
-                            src += 16;
-                        } while (out < end);
-                    }
-                    out = end;
-                } else if (dist >= 8) {
-                    do {
-                        memcpy(out, src, 8);
-                        out += 8;
-                        src += 8;
-                    } while (out < end);
-                    out = end;
-                } else if (dist == 1) {
-                    memset(out, *src, len);
-                    out = end;
-                } else {
-                    do { *out++ = *src++; } while (out < end);
-                }
-            }
-#undef REFILL
-#undef CONSUME
-#undef PUT_GROUP
-            /* the bit buffer may hold bytes beyond what the symbols used: give whole unused bytes back (bc counts real bits only) */
-            b->in = in;
-            b->bb = bb;
-            b->bc = bc;
-            o->len = (size_t)(out - o->out);
-            if (rc <= 0) return rc;
+        if (FAST_FITS(b, o)) {
+            FAST_LOCALS(A, b, o, lit, dst, member_start);
+            int rcA = 1; /* 1: ran out of margin, 0: end of block, -1: corrupt */
+            while (inA <= in_fastA && outA <= out_fastA) STEP(A);
+        stop:
+            FAST_STORE(A, b, o);
+            if (rcA <= 0) return rcA;
         }
         /* ---- careful: one symbol, every read and write checked ---- */
         if (out_room(o, FAST_OUT_MARGIN + 8) != 0) return -2;
         refill_safe(b); /* 56 bits and more unless the stream ends: whatever one entry consumes */
         uint32_t e = lit_one[b->bb & lmask]; /* (second levels are shared: they live behind the first level of `lit`) */
-        if (!E_IS_LIT(e) && E_KIND(e) == K_SUB) {
+        if (e & F_SUB) {
             if (b->bc < LIT_BITS) return -1;
             b->bb >>= LIT_BITS;
             b->bc -= LIT_BITS;
             refill_safe(b);
-            e = lit[E_BASE(e) + (b->bb & ((1u << E_CODE(e)) - 1))];
+            e = lit[E_PAYLOAD(e) + (b->bb & ((1u << E_CODE(e)) - 1))];
         }
         if ((int)E_TOTAL(e) > b->bc) return -1; /* the stream ends inside a code or its extra bits */
-        if (E_IS_LIT(e)) {
-            o->out[o->len++] = (unsigned char)E_LITS(e);
+        if (e & F_LIT) {
+            o->out[o->len++] = (unsigned char)E_PAYLOAD(e);
             b->bb >>= E_TOTAL(e);
             b->bc -= (int)E_TOTAL(e);
             continue;
         }
+        if (e & F_EXC) {
+            b->bb >>= E_TOTAL(e);
+            b->bc -= (int)E_TOTAL(e);
+            return E_PAYLOAD(e) ? 0 : -1;
+        }
         const uint32_t len = E_VALUE(e, b->bb);
         b->bb >>= E_TOTAL(e);
         b->bc -= (int)E_TOTAL(e);
-        if (E_KIND(e) == K_EOB) return 0;
-        if (E_KIND(e) != K_BASE) return -1;
         refill_safe(b);
         uint32_t d = dst[b->bb & dmask];
-        if (E_KIND(d) == K_SUB) {
+        if (d & F_SUB) {
             if (b->bc < DST_BITS) return -1;
             b->bb >>= DST_BITS;
             b->bc -= DST_BITS;
             refill_safe(b);
-            d = dst[E_BASE(d) + (b->bb & ((1u << E_CODE(d)) - 1))];
+            d = dst[E_PAYLOAD(d) + (b->bb & ((1u << E_CODE(d)) - 1))];
         }
-        if (E_KIND(d) != K_BASE || (int)E_TOTAL(d) > b->bc) return -1;
+        if (!E_IS_BASE(d) || (int)E_TOTAL(d) > b->bc) return -1;
         const uint32_t dist = E_VALUE(d, b->bb);
         b->bb >>= E_TOTAL(d);
         b->bc -= (int)E_TOTAL(d);
@@ -358,6 +387,40 @@ static int inflate_symbols(bitr *b, outbuf *o, const uint32_t *lit, const uint32
         for (uint32_t i = 0; i < len; i++, o->len++) o->out[o->len] = o->out[o->len - dist];
     }
 }
+
+/* The same fast loop over TWO streams, a turn of each in turn.  A stream's turns form one chain of dependent steps (the next table
+ * index is in the bits behind this entry's), some 25 cycles a match at half the instructions the core could retire in them; a
+ * second, independent chain fills the other half.  Runs while BOTH streams have their margins, and stops when either leaves its
+ * block: rc 0 = end of block, -1 = corrupt, 1 = out of margin (its caller goes on through inflate_symbols), 2 = only the other one stopped. */
+HOT_CLONES static void inflate_symbols2(bitr *b0, outbuf *o0, const uint32_t *lit0, const uint32_t *dst0, size_t member_start0, int *rc0,
+                             bitr *b1, outbuf *o1, const uint32_t *lit1, const uint32_t *dst1, size_t member_start1, int *rc1)
+{
+    const uint64_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DST_BITS) - 1;
+    *rc0 = FAST_FITS(b0, o0) ? 2 : 1;
+    *rc1 = FAST_FITS(b1, o1) ? 2 : 1;
+    if (*rc0 == 1 || *rc1 == 1) return;
+    FAST_LOCALS(A, b0, o0, lit0, dst0, member_start0);
+    FAST_LOCALS(B, b1, o1, lit1, dst1, member_start1);
+    int rcA = 2, rcB = 2;
+    while (inA <= in_fastA && outA <= out_fastA && inB <= in_fastB && outB <= out_fastB) {
+        STEP(A);
+        STEP(B);
+    }
+    if (inA > in_fastA || outA > out_fastA) rcA = 1;
+    if (inB > in_fastB || outB > out_fastB) rcB = 1;
+stop:
+    FAST_STORE(A, b0, o0);
+    FAST_STORE(B, b1, o1);
+    *rc0 = rcA;
+    *rc1 = rcB;
+}
+#undef REFILL
+#undef CONSUME
+#undef PUT_GROUP
+#undef STEP
+#undef FAST_LOCALS
+#undef FAST_STORE
+#undef FAST_FITS
 
 /* ---- blocks -------------------------------------------------------------------------------------------------------------------- */
 static void fixed_tables(inflate_tabs *t)
@@ -446,52 +509,6 @@ static int read_dynamic(bitr *b, inflate_tabs *t)
     return 0;
 }
 
-/* one deflate stream (the body of a gzip member); the reader ends behind its last block, byte-aligned */
-static int inflate_stream(bitr *b, outbuf *o, inflate_tabs *t)
-{
-    const size_t member_start = o->len;
-    for (;;) {
-        uint32_t last, type;
-        if (take_bits(b, 1, &last) || take_bits(b, 2, &type)) return -1;
-        if (type == 0) { /* stored: back to a byte boundary, LEN / NLEN, the bytes */
-            b->bb >>= b->bc & 7;
-            b->bc -= b->bc & 7;
-            uint32_t len, nlen;
-            if (take_bits(b, 16, &len) || take_bits(b, 16, &nlen) || (len ^ nlen) != 0xFFFFu) return -1;
-            if (out_room(o, len)) return -2;
-            uint32_t got = 0;
-            while (got < len && b->bc >= 8) { /* (whole bytes the bit buffer holds already) */
-                o->out[o->len++] = (unsigned char)b->bb;
-                b->bb >>= 8;
-                b->bc -= 8;
-                got++;
-            }
-            if ((size_t)(b->in_end - b->in) < len - got) return -1;
-            memcpy(o->out + o->len, b->in, len - got);
-            b->in += len - got;
-            o->len += len - got;
-        } else if (type == 1) {
-            fixed_tables(t);
-            const int rc = inflate_symbols(b, o, t->fixed_lit, t->fixed_lit_one, t->fixed_dst, member_start);
-            if (rc) return rc;
-        } else if (type == 2) {
-            if (read_dynamic(b, t)) return -1;
-            const int rc = inflate_symbols(b, o, t->lit, t->lit_one, t->dst, member_start);
-            if (rc) return rc;
-        } else {
-            return -1;
-        }
-        if (last) break;
-    }
-    /* whole unread bytes go back to the input, the bits of the last byte are dropped */
-    b->bb >>= b->bc & 7;
-    b->bc -= b->bc & 7;
-    b->in -= b->bc >> 3;
-    b->bb = 0;
-    b->bc = 0;
-    return 0;
-}
-
 /* ---- CRC-32 (gzip's check value) -------------------------------------------------------------------------------------------------
  * Folding by carry-less multiplication (V. Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ
  * Instruction", Intel 2009): four 128-bit lanes folded 512 bits at a time, then down to 128, 64 and 32 bits; the constants are
@@ -575,53 +592,217 @@ uint32_t kssd_crc32(uint32_t crc, const unsigned char *p, size_t len)
     return crc;
 }
 
+/* ---- one file's state: gzip members > deflate blocks > symbols -------------------------------------------------------------------
+ * A state machine rather than nested loops, so that two files can be decoded in step (kssd_gunzip_mem2): z_advance() runs a file
+ * up to the next Huffman block's symbols (member headers, block headers, stored blocks, code lengths -- none of it hot), the symbol
+ * loops take it to the block's end, z_block_end() closes the block and, behind a member's last, checks its CRC-32 and length. */
+enum { ZS_MEMBER, ZS_BLOCK, ZS_SYMBOLS, ZS_DONE, ZS_FAILED };
+typedef struct {
+    const unsigned char *src; /* the file's bytes */
+    size_t src_len, at;       /* ... and where its next member starts */
+    int members;
+    bitr b;
+    outbuf o;
+    inflate_tabs *t;
+    const uint32_t *lit, *lit_one, *dst; /* ZS_SYMBOLS: the block's tables */
+    size_t member_start;
+    int last, state, rc; /* last: the block is the member's last; rc: the KSSD_HOST_ERR_* of a ZS_FAILED file */
+} zstate;
+
+static void z_fail(zstate *z, int rc)
+{
+    z->state = ZS_FAILED;
+    z->rc = rc;
+}
+
+static __thread inflate_tabs *t_tabs[2];
+static int z_init(zstate *z, int slot, const unsigned char *in, size_t in_len, unsigned char *out, size_t cap)
+{
+    memset(z, 0, sizeof *z);
+    z->src = in;
+    z->src_len = in_len;
+    z->o.out = out;
+    z->o.cap = cap;
+    z->state = ZS_MEMBER;
+    z->rc = KSSD_HOST_OK;
+    z->t = t_tabs[slot]; /* (the thread's own, kept from file to file: 0.2 MB that malloc() would map and unmap every time) */
+    if (!z->t) {
+        z->t = t_tabs[slot] = (inflate_tabs *)malloc(sizeof *z->t);
+        if (!z->t) { z_fail(z, KSSD_HOST_ERR_NOMEM); return -1; }
+        z->t->fixed_ready = 0;
+    }
+    /* the last member's trailer states its length modulo 2^32: room for it up front (a single member below 4 GiB: exact) */
+    if (in_len >= 18) {
+        const size_t isize = (size_t)in[in_len - 4] | ((size_t)in[in_len - 3] << 8) | ((size_t)in[in_len - 2] << 16) | ((size_t)in[in_len - 1] << 24);
+        if (isize < ((size_t)1 << 32) - 1 && out_room(&z->o, isize + FAST_OUT_MARGIN + 64)) { z_fail(z, KSSD_HOST_ERR_NOMEM); return -1; }
+    }
+    return 0;
+}
+
+/* behind a member's last block: whole unread bytes go back to the input, the bits of the last byte are dropped; CRC-32, ISIZE */
+static void z_member_end(zstate *z)
+{
+    bitr *b = &z->b;
+    b->bb >>= b->bc & 7;
+    b->bc -= b->bc & 7;
+    b->in -= b->bc >> 3;
+    b->bb = 0;
+    b->bc = 0;
+    if ((size_t)(b->in_end - b->in) < 8) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+    const uint32_t want_crc = (uint32_t)b->in[0] | ((uint32_t)b->in[1] << 8) | ((uint32_t)b->in[2] << 16) | ((uint32_t)b->in[3] << 24);
+    const uint32_t want_len = (uint32_t)b->in[4] | ((uint32_t)b->in[5] << 8) | ((uint32_t)b->in[6] << 16) | ((uint32_t)b->in[7] << 24);
+    const size_t start = z->member_start;
+    if ((uint32_t)(z->o.len - start) != want_len || kssd_crc32(0, z->o.out + start, z->o.len - start) != want_crc) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+    z->at = (size_t)(b->in - z->src) + 8;
+    z->members++;
+    z->state = ZS_MEMBER;
+}
+
+static void z_block_end(zstate *z)
+{
+    if (z->last) z_member_end(z);
+    else z->state = ZS_BLOCK;
+}
+
+/* up to the symbols of the next Huffman block (ZS_SYMBOLS), the end of the file (ZS_DONE) or a failure */
+static void z_advance(zstate *z)
+{
+    for (;;) {
+        if (z->state == ZS_MEMBER) {
+            const unsigned char *in = z->src;
+            const size_t in_len = z->src_len;
+            size_t at = z->at;
+            while (z->members && at < in_len && in[at] == 0) at++; /* (zcat accepts zero bytes behind the last member -- tape blocks -- and so does this) */
+            if (at >= in_len) {
+                if (!z->members) z_fail(z, KSSD_HOST_ERR_IO);
+                else z->state = ZS_DONE;
+                return;
+            }
+            if (in_len - at < 18 || in[at] != 0x1f || in[at + 1] != 0x8b || in[at + 2] != 8 || (in[at + 3] & 0xE0)) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+            const int flg = in[at + 3];
+            size_t p = at + 10;
+            if (flg & 4) { /* FEXTRA */
+                if (p + 2 > in_len) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+                p += 2 + ((size_t)in[p] | ((size_t)in[p + 1] << 8));
+            }
+            for (int k = 0; k < 2; k++) /* FNAME, FCOMMENT: zero-terminated */
+                if (flg & (k ? 16 : 8)) {
+                    while (p < in_len && in[p]) p++;
+                    p++;
+                }
+            if (flg & 2) p += 2; /* FHCRC */
+            if (p + 8 > in_len) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+            z->b.in = in + p;
+            z->b.in_end = in + in_len;
+            z->b.bb = 0;
+            z->b.bc = 0;
+            z->member_start = z->o.len;
+            z->state = ZS_BLOCK;
+        } else if (z->state == ZS_BLOCK) {
+            bitr *b = &z->b;
+            outbuf *o = &z->o;
+            uint32_t last, type;
+            if (take_bits(b, 1, &last) || take_bits(b, 2, &type)) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+            z->last = (int)last;
+            if (type == 0) { /* stored: back to a byte boundary, LEN / NLEN, the bytes */
+                b->bb >>= b->bc & 7;
+                b->bc -= b->bc & 7;
+                uint32_t len, nlen;
+                if (take_bits(b, 16, &len) || take_bits(b, 16, &nlen) || (len ^ nlen) != 0xFFFFu) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+                if (out_room(o, len)) { z_fail(z, KSSD_HOST_ERR_NOMEM); return; }
+                uint32_t got = 0;
+                while (got < len && b->bc >= 8) { /* (whole bytes the bit buffer holds already) */
+                    o->out[o->len++] = (unsigned char)b->bb;
+                    b->bb >>= 8;
+                    b->bc -= 8;
+                    got++;
+                }
+                if ((size_t)(b->in_end - b->in) < len - got) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+                memcpy(o->out + o->len, b->in, len - got);
+                b->in += len - got;
+                o->len += len - got;
+                z_block_end(z);
+                if (z->state == ZS_FAILED) return;
+            } else if (type == 1) {
+                fixed_tables(z->t);
+                z->lit = z->t->fixed_lit;
+                z->lit_one = z->t->fixed_lit_one;
+                z->dst = z->t->fixed_dst;
+                z->state = ZS_SYMBOLS;
+                return;
+            } else if (type == 2) {
+                if (read_dynamic(b, z->t)) { z_fail(z, KSSD_HOST_ERR_IO); return; }
+                z->lit = z->t->lit;
+                z->lit_one = z->t->lit_one;
+                z->dst = z->t->dst;
+                z->state = ZS_SYMBOLS;
+                return;
+            } else {
+                z_fail(z, KSSD_HOST_ERR_IO);
+                return;
+            }
+        } else {
+            return;
+        }
+    }
+}
+
+/* a file to its end, on its own */
+static void z_run(zstate *z)
+{
+    for (;;) {
+        z_advance(z);
+        if (z->state != ZS_SYMBOLS) return;
+        const int r = inflate_symbols(&z->b, &z->o, z->lit, z->lit_one, z->dst, z->member_start);
+        if (r) { z_fail(z, r == -2 ? KSSD_HOST_ERR_NOMEM : KSSD_HOST_ERR_IO); return; }
+        z_block_end(z);
+    }
+}
+
+static int z_finish(zstate *z, unsigned char **out, size_t *cap, size_t *len)
+{
+    *out = z->o.out; /* (the caller's buffer may have moved even when the stream turns out corrupt) */
+    *cap = z->o.cap;
+    *len = z->state == ZS_DONE ? z->o.len : 0;
+    return z->state == ZS_DONE ? KSSD_HOST_OK : z->rc != KSSD_HOST_OK ? z->rc : KSSD_HOST_ERR_IO;
+}
+
 /* ---- gzip members ---------------------------------------------------------------------------------------------------------------- */
 int kssd_gunzip_mem(const unsigned char *in, size_t in_len, unsigned char **out, size_t *cap, size_t *len)
 {
     if (!in || !out || !cap || !len) return KSSD_HOST_ERR_PARAM;
-    inflate_tabs *t = (inflate_tabs *)malloc(sizeof *t);
-    if (!t) return KSSD_HOST_ERR_NOMEM;
-    t->fixed_ready = 0;
-    outbuf o = {*out, *cap, 0};
-    /* the last member's trailer states its length modulo 2^32: room for it up front (a single member below 4 GiB: exact) */
-    if (in_len >= 18) {
-        const size_t isize = (size_t)in[in_len - 4] | ((size_t)in[in_len - 3] << 8) | ((size_t)in[in_len - 2] << 16) | ((size_t)in[in_len - 1] << 24);
-        if (isize < ((size_t)1 << 32) - 1 && out_room(&o, isize + FAST_OUT_MARGIN + 64)) { free(t); return KSSD_HOST_ERR_NOMEM; }
-    }
-    size_t at = 0;
-    int rc = KSSD_HOST_OK, members = 0;
-    while (at < in_len) {
-        /* (zcat accepts zero bytes behind the last member -- tape blocks -- and so does this) */
-        if (members && in[at] == 0) { at++; continue; }
-        if (in_len - at < 18 || in[at] != 0x1f || in[at + 1] != 0x8b || in[at + 2] != 8 || (in[at + 3] & 0xE0)) { rc = KSSD_HOST_ERR_IO; break; }
-        const int flg = in[at + 3];
-        size_t p = at + 10;
-        if (flg & 4) { /* FEXTRA */
-            if (p + 2 > in_len) { rc = KSSD_HOST_ERR_IO; break; }
-            p += 2 + ((size_t)in[p] | ((size_t)in[p + 1] << 8));
+    zstate z;
+    if (z_init(&z, 0, in, in_len, *out, *cap) == 0) z_run(&z);
+    return z_finish(&z, out, cap, len);
+}
+
+/* two files at once, their Huffman blocks decoded in step by one thread (inflate_symbols2); whatever one file has beyond the other
+ * -- and whatever is no symbol loop -- runs on its own.  rc[f]: what kssd_gunzip_mem would have returned for file f. */
+void kssd_gunzip_mem2(const unsigned char *const in[2], const size_t in_len[2], unsigned char **out[2], size_t *cap[2], size_t *len[2], int rc[2])
+{
+    zstate z[2];
+    for (int f = 0; f < 2; f++) {
+        if (!in[f] || !out[f] || !cap[f] || !len[f]) { /* (nothing is decoded when a file's arguments are missing) */
+            rc[0] = rc[1] = KSSD_HOST_ERR_PARAM;
+            return;
         }
-        for (int k = 0; k < 2; k++) /* FNAME, FCOMMENT: zero-terminated */
-            if (flg & (k ? 16 : 8)) {
-                while (p < in_len && in[p]) p++;
-                p++;
-            }
-        if (flg & 2) p += 2; /* FHCRC */
-        if (p + 8 > in_len) { rc = KSSD_HOST_ERR_IO; break; }
-        bitr b = {in + p, in + in_len, 0, 0};
-        const size_t start = o.len;
-        const int r = inflate_stream(&b, &o, t);
-        if (r) { rc = r == -2 ? KSSD_HOST_ERR_NOMEM : KSSD_HOST_ERR_IO; break; }
-        if ((size_t)(b.in_end - b.in) < 8) { rc = KSSD_HOST_ERR_IO; break; }
-        const uint32_t want_crc = (uint32_t)b.in[0] | ((uint32_t)b.in[1] << 8) | ((uint32_t)b.in[2] << 16) | ((uint32_t)b.in[3] << 24);
-        const uint32_t want_len = (uint32_t)b.in[4] | ((uint32_t)b.in[5] << 8) | ((uint32_t)b.in[6] << 16) | ((uint32_t)b.in[7] << 24);
-        if ((uint32_t)(o.len - start) != want_len || kssd_crc32(0, o.out + start, o.len - start) != want_crc) { rc = KSSD_HOST_ERR_IO; break; }
-        at = (size_t)(b.in - in) + 8;
-        members++;
     }
-    if (rc == KSSD_HOST_OK && !members) rc = KSSD_HOST_ERR_IO;
-    free(t);
-    *out = o.out; /* (the caller's buffer may have moved even when the stream turns out corrupt) */
-    *cap = o.cap;
-    *len = rc == KSSD_HOST_OK ? o.len : 0;
-    return rc;
+    for (int f = 0; f < 2; f++)
+        if (z_init(&z[f], f, in[f], in_len[f], *out[f], *cap[f]) == 0) z_advance(&z[f]);
+    while (z[0].state == ZS_SYMBOLS && z[1].state == ZS_SYMBOLS) {
+        int r[2];
+        inflate_symbols2(&z[0].b, &z[0].o, z[0].lit, z[0].dst, z[0].member_start, &r[0], &z[1].b, &z[1].o, z[1].lit, z[1].dst, z[1].member_start, &r[1]);
+        for (int f = 0; f < 2; f++) {
+            if (r[f] == 2) continue;                          /* (only the other one stopped) */
+            if (r[f] == 1)                                    /* out of its margins: to the block's end through the careful loop */
+                r[f] = inflate_symbols(&z[f].b, &z[f].o, z[f].lit, z[f].lit_one, z[f].dst, z[f].member_start);
+            if (r[f]) { z_fail(&z[f], r[f] == -2 ? KSSD_HOST_ERR_NOMEM : KSSD_HOST_ERR_IO); continue; }
+            z_block_end(&z[f]);
+            z_advance(&z[f]);
+        }
+    }
+    for (int f = 0; f < 2; f++) {
+        if (z[f].state == ZS_SYMBOLS || z[f].state == ZS_BLOCK || z[f].state == ZS_MEMBER) z_run(&z[f]);
+        rc[f] = z_finish(&z[f], out[f], cap[f], len[f]);
+    }
 }

@@ -21,6 +21,11 @@ def _lib():
     L.kssd_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
     L.kssd_crc32.restype = C.c_uint32
     L.kssd_host_free.argtypes = [C.c_void_p]
+    P2 = C.POINTER(C.c_void_p) * 2
+    L.kssd_gunzip_mem2.argtypes = [C.c_char_p * 2, C.c_size_t * 2, P2, C.POINTER(C.c_size_t) * 2, C.POINTER(C.c_size_t) * 2, C.c_int * 2]
+    L.kssd_gunzip_mem2.restype = None
+    L.kssd_slurp_reuse2.argtypes = [C.c_char_p * 2, P2, C.POINTER(C.c_size_t) * 2, C.POINTER(C.c_size_t) * 2, C.c_int * 2]
+    L.kssd_slurp_reuse2.restype = None
     return L
 
 
@@ -32,6 +37,28 @@ def gunzip(z):
     if out.value:
         L.kssd_host_free(out)
     return rc, data
+
+
+def _pair_call(fn, first):
+    """fn = kssd_gunzip_mem2 / kssd_slurp_reuse2: the leading arguments, then out / cap / len / rc for two files"""
+    L = _lib()
+    out = [C.c_void_p(), C.c_void_p()]
+    cap = [C.c_size_t(0), C.c_size_t(0)]
+    n = [C.c_size_t(0), C.c_size_t(0)]
+    rc = (C.c_int * 2)(-99, -99)
+    fn(*first, (C.POINTER(C.c_void_p) * 2)(C.pointer(out[0]), C.pointer(out[1])), (C.POINTER(C.c_size_t) * 2)(C.pointer(cap[0]), C.pointer(cap[1])),
+       (C.POINTER(C.c_size_t) * 2)(C.pointer(n[0]), C.pointer(n[1])), rc)
+    res = []
+    for f in range(2):
+        res.append((rc[f], C.string_at(out[f], n[f].value) if (rc[f] == 0 and n[f].value) else b""))
+        if out[f].value:
+            L.kssd_host_free(out[f])
+    return res
+
+
+def gunzip2(z0, z1):
+    L = _lib()
+    return _pair_call(L.kssd_gunzip_mem2, ((C.c_char_p * 2)(z0, z1), (C.c_size_t * 2)(len(z0), len(z1))))
 
 
 def dna(rng, n, width=70, alphabet=b"ACGT"):
@@ -127,6 +154,48 @@ def test_members_headers_and_trailing_zeros():
     assert gzip.decompress(z2) == c
     rc, out = gunzip(z2)
     assert rc == 0 and out == c
+
+
+def test_two_files_in_step_equal_one_at_a_time(tmp_path):
+    """kssd_gunzip_mem2 / kssd_slurp_reuse2: every pairing of files of different lengths, levels, block structures and defects gives
+    each file what it gets alone -- the bytes or the refusal"""
+    rng = np.random.default_rng(21)
+    noise = rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes()
+    big = dna(rng, 1_500_000)
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    flushed = b"".join(co.compress(dna(rng, int(rng.integers(1, 3000)))) + co.flush(zlib.Z_FULL_FLUSH if i % 3 else zlib.Z_SYNC_FLUSH) for i in range(40)) + co.flush()
+    fixed = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    good = gzip.compress(big, 6)
+    bad_crc = bytearray(gzip.compress(dna(rng, 50_000), 6)); bad_crc[-6] ^= 1
+    bad_mid = bytearray(good); bad_mid[len(good) // 2] ^= 0x55
+    corpus = [gzip.compress(b"", 6), gzip.compress(b"A", 1), gzip.compress(dna(rng, 5000), 1), gzip.compress(big, 1), good,
+              gzip.compress(dna(rng, 300_000, alphabet=b"ACGTacgtNNNNRYKM"), 9), gzip.compress(noise, 6), flushed,
+              fixed.compress(dna(rng, 20_000)) + fixed.flush(), gzip.compress(dna(rng, 10_000), 1) + gzip.compress(b"", 9) + gzip.compress(dna(rng, 70_000), 6) + b"\0" * 100,
+              gzip.compress((b"AC" * 7 + b"GGT") * 9000, 9), bytes(bad_crc), bytes(bad_mid), good[: len(good) // 3], b"not gzip at all", b""]
+    alone = [gunzip(z) for z in corpus]
+    for i, (rc, out) in enumerate(alone):
+        if i < 11:
+            assert rc == 0 and out == gzip.decompress(corpus[i]), i
+        else:
+            assert rc != 0, i
+    for i in range(len(corpus)):
+        for j in range(len(corpus)):
+            r = gunzip2(corpus[i], corpus[j])
+            assert (r[0][0] == 0) == (alone[i][0] == 0) and r[0][1] == alone[i][1], (i, j)
+            assert (r[1][0] == 0) == (alone[j][0] == 0) and r[1][1] == alone[j][1], (i, j)
+    # the file-level pair: gzip'ed with gzip'ed in step, anything else one after the other, a missing file refused on its own
+    L = _lib()
+    paths = {}
+    for name, data in (("a.fa.gz", corpus[3]), ("b.fa.gz", corpus[5]), ("plain.fa", big[:100_000]), ("bad.fa.gz", bytes(bad_mid))):
+        paths[name] = str(tmp_path / name).encode()
+        open(paths[name], "wb").write(data)
+    paths["missing"] = str(tmp_path / "missing.fa.gz").encode()
+    want = {"a.fa.gz": alone[3], "b.fa.gz": alone[5], "plain.fa": (0, big[:100_000]), "bad.fa.gz": (1, b""), "missing": (1, b"")}
+    for x in paths:
+        for y in paths:
+            r = _pair_call(L.kssd_slurp_reuse2, ((C.c_char_p * 2)(paths[x], paths[y]),))
+            for f, name in enumerate((x, y)):
+                assert (r[f][0] == 0) == (want[name][0] == 0) and r[f][1] == want[name][1], (x, y, f)
 
 
 def test_corrupt_and_truncated_streams_are_refused_not_followed():
