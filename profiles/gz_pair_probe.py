@@ -36,11 +36,11 @@ try:
         t1 = time.time(); c1 = cpu_stat()
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         tm = [json.loads(l) for l in r.stderr.decode().splitlines() if '"stage1"' in l][0]
-        return round(t1 - t0, 3), {k: c1[k] - c0[k] for k in c1 if k in ("usage_usec", "nr_throttled", "throttled_usec")}, {k: round(v, 3) for k, v in tm.items() if k in ("s_total", "s_context_create_max", "s_read_gunzip", "s_device_calls_summed", "s_unpack_threads_summed", "s_copy_threads_summed", "s_wait_text_buffer")}
+        return round(t1 - t0, 3), {k: c1[k] - c0[k] for k in c1 if k in ("usage_usec", "user_usec", "system_usec", "nr_throttled")}, {k: round(v, 3) for k, v in tm.items() if k in ("s_total", "s_context_create_max", "s_read_gunzip", "s_device_calls_summed", "s_unpack_threads_summed", "s_copy_threads_summed", "s_wait_text_buffer")}
     run("fa", {})
     for src in ("fa", "gz"):
-        for env, p in (({}, 16),):
-            res = [run(src, env, p) for _ in range(6)]
+        for env, p in (({}, 16), ({"KSSD_GZ_AHEAD": "24"}, 16), ({"KSSD_GZ_AHEAD": "48"}, 16), ({"KSSD_GZ_AHEAD": "16"}, 16)) if src == "gz" else (({}, 16),):
+            res = [run(src, env, p) for _ in range(4)]
             for r in res: print(src, env, "-p", p, *r, flush=True)
             print(src, env, "best %.3f s -> %.0f genomes/s, median %.3f s" % (min(r[0] for r in res), 1024 / min(r[0] for r in res), sorted(r[0] for r in res)[3]), flush=True)
     subprocess.run("gcc -O2 -o /tmp/inflate_bench profiles/src/inflate_bench.c -Lpublic_kssd_amd -lkssd_host -Wl,-rpath,%s/public_kssd_amd && /tmp/inflate_bench %s/gz/r00_g0000.fasta.gz 30 && /tmp/inflate_bench %s/gz/r00_g0001.fasta.gz 30" % (ROOT, d, d), shell=True, cwd=ROOT)
