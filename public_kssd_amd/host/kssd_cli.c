@@ -378,6 +378,16 @@ static int cmd_dist(int argc, char **argv)
     return 0;
 }
 
+/* A preloaded library or a profiler's tool library may have started the GPU runtime before main(): such a process must not be
+ * replaced by another (the rule of the GPU hosts this runs on), so it keeps the environment it came with. */
+extern char **environ;
+static int tooling_preloaded(void)
+{
+    for (char **e = environ; e && *e; e++)
+        if (!strncmp(*e, "LD_PRELOAD=", 11) ? (*e)[11] != 0 : (!strncmp(*e, "ROCP", 4) || !strncmp(*e, "HSA_TOOLS", 9) || !strncmp(*e, "ROCPROFILER", 11))) return 1;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     setvbuf(stdout, NULL, _IOLBF, 0);
@@ -389,7 +399,7 @@ int main(int argc, char **argv)
      * every accounting period -- measured on the GPU box (16-CPU quota): 0.4-0.9 thread-seconds throttled per run, 4.6 s of CPU for 1.7 s
      * of work (profiles/r05v_throttle_probe.txt).  The wait policy can only come from the environment the process starts with, so the
      * command starts itself again with it set -- once, first thing, before anything has touched a device (KSSD_NO_REEXEC=1: not). */
-    if (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT") && !getenv("KSSD_NO_REEXEC")) {
+    if (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT") && !getenv("KSSD_NO_REEXEC") && !tooling_preloaded()) {
         setenv("OMP_WAIT_POLICY", "passive", 1);
         setenv("KSSD_NO_REEXEC", "1", 1);
         execv("/proc/self/exe", argv); /* (no /proc, no permission: go on as we are) */
