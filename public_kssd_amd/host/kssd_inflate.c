@@ -631,10 +631,13 @@ static int z_init(zstate *z, int slot, const unsigned char *in, size_t in_len, u
         if (!z->t) { z_fail(z, KSSD_HOST_ERR_NOMEM); return -1; }
         z->t->fixed_ready = 0;
     }
-    /* the last member's trailer states its length modulo 2^32: room for it up front (a single member below 4 GiB: exact) */
+    /* the last member's trailer states its length modulo 2^32: room for it up front (a single member below 4 GiB: exact) -- as far as
+     * the file's own size makes it plausible (sequence text packs 3 - 5 : 1; a damaged trailer must not reserve gigabytes per thread;
+     * text that packs better than 16 : 1 grows its buffer on the way) */
     if (in_len >= 18) {
-        const size_t isize = (size_t)in[in_len - 4] | ((size_t)in[in_len - 3] << 8) | ((size_t)in[in_len - 2] << 16) | ((size_t)in[in_len - 1] << 24);
-        if (isize < ((size_t)1 << 32) - 1 && out_room(&z->o, isize + FAST_OUT_MARGIN + 64)) { z_fail(z, KSSD_HOST_ERR_NOMEM); return -1; }
+        size_t isize = (size_t)in[in_len - 4] | ((size_t)in[in_len - 3] << 8) | ((size_t)in[in_len - 2] << 16) | ((size_t)in[in_len - 1] << 24);
+        if (isize > in_len * 16 + ((size_t)1 << 20)) isize = in_len * 16 + ((size_t)1 << 20);
+        if (out_room(&z->o, isize + FAST_OUT_MARGIN + 64)) { z_fail(z, KSSD_HOST_ERR_NOMEM); return -1; }
     }
     return 0;
 }
