@@ -323,3 +323,49 @@ def test_quality_floor_and_abundance_inputs_through_the_device_tokeniser(tmp_pat
         wi, wc = sk.fastq_koc(afiles[name])
         lo, hi = int(idx[g]), int(idx[g + 1])
         assert np.array_equal(got[lo:hi], wi) and np.array_equal(cnt[lo:hi], wc), name
+
+
+def test_waves_of_gzipped_files_give_the_files_of_the_plain_inputs(tmp_path):
+    """host/kssd_cli_stage1.c: gzip'ed inputs are unpacked two waves at a time, file i of the one in step with file i of the other
+    (kssd_slurp_reuse2), and ahead of the runtime's start.  Several waves at -p 4 -- whole, short and mixed ones, a file of two members,
+    an empty member, a plain file between them -- must leave the combco.* of the same inputs plain: by default, one file at a time, with
+    zlib, with one set of wave buffers ahead.  A damaged file is named."""
+    import gzip
+    d = str(tmp_path)
+    rng = np.random.default_rng(17)
+    run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
+    os.mkdir(os.path.join(d, "gz")); os.mkdir(os.path.join(d, "fa"))
+    def fasta(n, name):
+        a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)]
+        rows = (n + 69) // 70
+        buf = np.full((rows, 71), 10, np.uint8); flat = np.full(rows * 70, ord("A"), np.uint8); flat[:n] = a; buf[:, :70] = flat.reshape(rows, 70)
+        return b">" + name.encode() + b" x\n" + buf.tobytes()
+    for i in range(21):      # five waves of four files + one: whole waves, the last one short
+        t = fasta(int(rng.integers(20_000, 120_000)), "g%02d" % i)
+        if i in (6, 17):     # two members
+            z = gzip.compress(t[: len(t) // 3], 1) + gzip.compress(t[len(t) // 3:], 6)
+        elif i == 9:         # an empty member behind the text
+            z = gzip.compress(t, 6) + gzip.compress(b"", 6)
+        else:
+            z = gzip.compress(t, 1 if i % 2 else 6)
+        if i == 14:          # a plain file in the middle of a wave
+            open(os.path.join(d, "gz", "s%02d.fasta" % i), "wb").write(t)
+        else:
+            open(os.path.join(d, "gz", "s%02d.fasta.gz" % i), "wb").write(z)
+        open(os.path.join(d, "fa", "s%02d.fasta" % i), "wb").write(t)
+    def sets(sub):
+        return {os.path.basename(nm).replace(".gz", ""): ids for nm, ids in ko.sketch_sets_by_name(os.path.join(d, sub)).items()}
+    run(["dist", "-p", 4, "-L", "L3K10.shuf", "-o", "o_fa", "fa"], d)
+    want = sets("o_fa")
+    assert len(want) == 21 and all(len(v) > 0 for v in want.values())
+    for tag, env in (("pairs", {}), ("single", {"KSSD_GZ_ONE_AT_A_TIME": "1"}), ("zlib", {"KSSD_ZLIB_GUNZIP": "1"}), ("ahead1", {"KSSD_GZ_AHEAD": "1"}),
+                     ("as_we_are", {"KSSD_NO_REEXEC": "1"})):
+        run(["dist", "-p", 4, "-L", "L3K10.shuf", "-o", "o_" + tag, "gz"], d, env=env)
+        got = sets("o_" + tag)
+        assert sorted(got) == sorted(want), tag
+        for nm in want:
+            assert np.array_equal(got[nm], want[nm]), (tag, nm)
+    bad = bytearray(open(os.path.join(d, "gz", "s03.fasta.gz"), "rb").read()); bad[len(bad) // 2] ^= 0x40
+    open(os.path.join(d, "gz", "s03.fasta.gz"), "wb").write(bytes(bad))
+    r = subprocess.run([BIN, "dist", "-p", "4", "-L", "L3K10.shuf", "-o", "o_bad", "gz"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode != 0 and b"s03.fasta.gz" in r.stdout, r.stdout.decode()[-500:]
