@@ -1,17 +1,17 @@
 #!/bin/bash
-# round 5, closing pass on the committed kernel sources: GPU suite, the driver's command, its kernel trace, the PMC passes, the line again
+# round 5, second closing pass (after the host-side work of the second half) on the committed kernel sources: GPU suite, the driver's command, its kernel trace, the PMC passes, the line again
 # (now with the traffic stamped), configs[2] / [3] / [4] for the record, one GPU as a rank of eight
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/r05Z; mkdir -p $o
+o=gpurun_out/r05ZZ; mkdir -p $o
 timeout 1800 python -m pytest tests -m gpu -q > $o/tests_gpu.log 2>&1; echo "gpu rc=$?" >> $o/tests_gpu.log
 tail -4 $o/tests_gpu.log
 timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $o/bench.json 2> $o/bench.err; echo "bench rc=$?"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $o/prof.json 2> $o/prof.err
 f=$(find $o/prof -name '*kernel_stats.csv' | head -1); cp "$f" $o/kernel_stats.csv; rm -rf $o/prof
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 1500 python3 profiles/pmc_refresh.py r05Z > $o/pmc_refresh.txt 2>&1; echo "pmc rc=$?"
+timeout 1500 python3 profiles/pmc_refresh.py r05ZZ > $o/pmc_refresh.txt 2>&1; echo "pmc rc=$?"
 cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json 2>/dev/null; cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
-rm -rf gpurun_out/pmc_r05Z_FETCH_SIZE gpurun_out/pmc_r05Z_WRITE_SIZE
+rm -rf gpurun_out/pmc_r05ZZ_FETCH_SIZE gpurun_out/pmc_r05ZZ_WRITE_SIZE
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $o/bench_after_refresh.json 2> $o/bench_after_refresh.err
 timeout 900 python3 bench.py --emulate-world 8 --rank 3 --steps 20 --warmup 5 --cpu-sample 0 > $o/bench_emu8_rank3.json 2> $o/bench_emu8_rank3.err
 timeout 1500 python3 bench.py --genomes 10000 --clades 500 --cpu-sample 0 --steps 10 --warmup 2 > $o/bench_config3.json 2> $o/bench_config3.err; echo "config2 rc=$?"
