@@ -378,13 +378,17 @@ static int cmd_dist(int argc, char **argv)
     return 0;
 }
 
-/* A preloaded library or a profiler's tool library may have started the GPU runtime before main(): such a process must not be
- * replaced by another (the rule of the GPU hosts this runs on), so it keeps the environment it came with. */
+/* A profiler's tool library may have started the GPU runtime before main(): such a process must not be replaced by another (the
+ * rule of the GPU hosts this runs on), so it keeps the environment it came with.  Told by the profilers' own variables and by
+ * their libraries' names in LD_PRELOAD (another preloaded library -- a sanitizer, a guard -- starts nothing). */
 extern char **environ;
 static int tooling_preloaded(void)
 {
-    for (char **e = environ; e && *e; e++)
-        if (!strncmp(*e, "LD_PRELOAD=", 11) ? (*e)[11] != 0 : (!strncmp(*e, "ROCP", 4) || !strncmp(*e, "HSA_TOOLS", 9) || !strncmp(*e, "ROCPROFILER", 11))) return 1;
+    for (char **e = environ; e && *e; e++) {
+        if (!strncmp(*e, "ROCP", 4) || !strncmp(*e, "HSA_TOOLS", 9)) return 1;
+        if (!strncmp(*e, "LD_PRELOAD=", 11) && (strstr(*e, "rocprof") || strstr(*e, "roctracer") || strstr(*e, "rocprofiler") || strstr(*e, "omnitrace") || strstr(*e, "rocsys")))
+            return 1;
+    }
     return 0;
 }
 

@@ -941,7 +941,7 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     warm_joined = 1;
                     g_runtime_ready = 1; /* (a runtime that failed to start is reported by the workers' context creation) */
                 }
-                textbuf_fit(tx, at + 64, g_runtime_ready);
+                textbuf_fit(tx, at + 64, g_runtime_ready && !getenv("KSSD_TEXT_REGISTERED"));
                 t_wait_text += now_s() - tw0; /* (a free buffer, the runtime's start, page-locked memory for a new one) */
                 t0 = now_s();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
