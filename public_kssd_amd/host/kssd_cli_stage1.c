@@ -761,6 +761,11 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
         if (!pl.pool[i]) die(ENOMEM, "out of memory");
     }
     pl.n_pool = n_batches;
+    /* A job's text lives in ordinary memory that the worker registers with the runtime before its first copy (textbuf_lock): the
+     * sixteen readers fault it in while they fill it, and registering 100 MB takes 5 ms on the worker's thread -- hipHostMalloc
+     * takes 14 - 19 ms per buffer on the main thread, in front of the first five waves (profiles/r05v_startup_probe.txt; end to end
+     * 0.55 - 0.62 -> 0.54 - 0.56 s, profiles/r05B_text_registered_probe.txt).  KSSD_TEXT_PAGE_LOCKED=1: hipHostMalloc. */
+    const int text_page_locked = getenv("KSSD_TEXT_PAGE_LOCKED") != NULL;
     int text_ahead = TEXT_BUFS_AHEAD; /* (KSSD_TEXT_AHEAD: a tuning knob, 0 = no read-ahead: the first byte is read once the runtime is up) */
     if (getenv("KSSD_TEXT_AHEAD")) text_ahead = atoi(getenv("KSSD_TEXT_AHEAD"));
     if (text_ahead < 0) text_ahead = 0;
@@ -921,8 +926,6 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     printf("%d/%d decomposing %s\r", ++done, fl->n, fl->path[i0 + r0]);
                     goto queue_job;
                 }
-                /* a free text buffer -- or, while the devices lag behind the readers (the runtime is still starting: nothing is
-                 * taken off the queues yet), one more: the inputs are read ahead into memory up to the budget */
                 /* a free text buffer -- or, while the runtime is still starting (nothing is taken off the queues yet), one more: up
                  * to TEXT_BUFS_AHEAD of them are read ahead into ordinary memory; they stay the command's buffers afterwards */
                 const double tw0 = now_s();
@@ -936,12 +939,12 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
                     pl.n_text_made++;
                 }
                 pthread_mutex_unlock(&pl.mu);
-                if (!tx->p && !g_runtime_ready && text_ahead == 0) { /* (no reading ahead: the buffers are page-locked ones, which takes the runtime) */
+                if (!tx->p && !g_runtime_ready && text_ahead == 0 && text_page_locked) { /* (page-locked buffers take the runtime; ordinary ones are filled while it starts) */
                     if (warming) pthread_join(warm, NULL);
                     warm_joined = 1;
                     g_runtime_ready = 1; /* (a runtime that failed to start is reported by the workers' context creation) */
                 }
-                textbuf_fit(tx, at + 64, g_runtime_ready && !getenv("KSSD_TEXT_REGISTERED"));
+                textbuf_fit(tx, at + 64, g_runtime_ready && text_page_locked);
                 t_wait_text += now_s() - tw0; /* (a free buffer, the runtime's start, page-locked memory for a new one) */
                 t0 = now_s();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
