@@ -40,7 +40,7 @@ try:
     run("fa", {})
     for rep in range(3):
         for env, p in (({}, 16), ({"KSSD_GZ_VIA_SCRATCH": "1"}, 16)):
-            res = [run("gz", env, p) for _ in range(4)]
+            res = [run("gz", env, p) for _ in range(5)]
             for r in res: print("gz", env, "-p", p, *r, flush=True)
             print("gz", env, "best %.3f s -> %.0f genomes/s, median %.3f s" % (min(r[0] for r in res), 1024 / min(r[0] for r in res), sorted(r[0] for r in res)[2]), flush=True)
     subprocess.run("gcc -O2 -o /tmp/inflate_bench profiles/src/inflate_bench.c -Lpublic_kssd_amd -lkssd_host -Wl,-rpath,%s/public_kssd_amd && /tmp/inflate_bench %s/gz/r00_g0000.fasta.gz 30 && /tmp/inflate_bench %s/gz/r00_g0001.fasta.gz 30" % (ROOT, d, d), shell=True, cwd=ROOT)
