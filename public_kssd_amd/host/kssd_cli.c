@@ -398,15 +398,22 @@ int main(int argc, char **argv)
     struct timespec t_main;
     clock_gettime(CLOCK_REALTIME, &t_main);
     /* The host threads of this command wait for one another every few milliseconds (a wave of files, a job's genomes), and libgomp's
-     * threads wait by spinning unless told otherwise BEFORE the library is loaded: 16 readers + the device workers' teams then count as
+     * threads wait by spinning unless told otherwise BEFORE the library initialises: 16 readers + the device workers' teams then count as
      * 20-odd running CPUs whatever they do, and under a CPU quota (a container's cpu.max) the whole command is stopped for the rest of
      * every accounting period -- measured on the GPU box (16-CPU quota): 0.4-0.9 thread-seconds throttled per run, 4.6 s of CPU for 1.7 s
-     * of work (profiles/r05v_throttle_probe.txt).  The wait policy can only come from the environment the process starts with, so the
-     * command starts itself again with it set -- once, first thing, before anything has touched a device (KSSD_NO_REEXEC=1: not). */
-    if (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT") && !getenv("KSSD_NO_REEXEC") && !tooling_preloaded()) {
-        setenv("OMP_WAIT_POLICY", "passive", 1);
-        setenv("KSSD_NO_REEXEC", "1", 1);
-        execv("/proc/self/exe", argv); /* (no /proc, no permission: go on as we are) */
+     * of work (profiles/r05v_throttle_probe.txt).  libkssd_env.so's constructor has set the passive policy in front of libgomp's own
+     * (host/kssd_env.c) -- the thread limit it set with it is the proof.  Where the loader ran the two the other way round, the command
+     * starts itself again with the policy in its environment: once, first thing, before anything has touched a device, and never under
+     * a profiler (KSSD_NO_REEXEC=1: not at all). */
+    if (omp_get_thread_limit() != 1000003 && !getenv("KSSD_NO_REEXEC") && !tooling_preloaded()) { /* (the mark is there: nothing to do) */
+        const char *mark = getenv("OMP_THREAD_LIMIT");
+        const int late = mark && !strcmp(mark, "1000003");                              /* the constructor ran, but behind libgomp's */
+        const int absent = !late && !getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT"); /* ... or not at all (otherwise: the caller's own choice) */
+        if (late || absent) {
+            setenv("OMP_WAIT_POLICY", "passive", 0);
+            setenv("KSSD_NO_REEXEC", "1", 1);
+            execv("/proc/self/exe", argv); /* (no /proc, no permission: go on as we are) */
+        }
     }
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
         printf("%s\n\nUsage: kssd <subcommand> [OPTION...] [arguments ...]\nSupported subcommands are:\n\n"
