@@ -10,7 +10,7 @@ from test_gpu_dist import random_sketches
 shuf = K.Shuf.generate(10, 6, 3, seed=1)
 ctx = K.GpuCtx(shuf, 0)
 bad = 0
-for seed in range(300):
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):
     rng = np.random.default_rng(seed)
     nr = int(rng.integers(1, 80)); nq = int(rng.integers(1, 40))
     roff, rids = random_sketches(rng, nr, 0, 1300, 1 << 28, clades=int(rng.integers(1, 8)))

@@ -17,7 +17,7 @@ for pi, (k, s, l) in enumerate(PARAMS):
     shuf = K.Shuf.generate(k, s, l, seed=100 + pi)
     sk = ko.Sketcher(shuf.table, k, s, l)
     ctx = K.GpuCtx(shuf, 0)
-    for seed in range(12):
+    for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
         rng = np.random.default_rng(1000 * pi + seed)
         texts = []
         for g in range(int(rng.integers(1, 12))):

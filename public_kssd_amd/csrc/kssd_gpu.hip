@@ -874,12 +874,18 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
         const uint64_t pos = (h_chunk_off[g + 1] - h_chunk_off[g]) * KSSD_CHUNK;
         if (with_pos && pos >= (1ull << 32)) { c->last_launch_rc = KSSD_ERR_UNSUPPORTED; return KSSD_ERR_UNSUPPORTED; }
         uint64_t cap = (uint64_t)((double)pos * rate * c->region_factor) + 256;
-        if (cap > pos) cap = pos;  // a genome cannot emit more tuples than it has positions
+        const bool all_positions = cap > pos;
+        if (all_positions) cap = pos;  // a genome cannot emit more tuples than it has positions
+        // A region that is all of the genome's positions cannot grow any further: after an overflow (the factor has moved) such a
+        // genome must not go back to a path whose room depends on how its ids SPREAD -- a tandem repeat of 190 kb at a dense
+        // parameter set stages 38 000 occurrences of a handful of ids, all in one of sixteen parts of 16 384 keys, and every
+        // repetition asked for "2.36 x" of a region that was at its limit (profiles/r05E_fuzz_tandem_repeat.txt)
+        const bool no_parts = all_positions && c->region_factor > 2.0;
         if (cap > big_min) {
             // a genome expected to fit the LDS sort keeps that path -- unless an earlier attempt has shown that this
             // batch emits far more than the sampling rate predicts (low-complexity sequence): then the factor decides
             if (c->region_factor <= 2.0 && (uint64_t)((double)pos * rate * 1.25) + 64 <= big_min) cap = big_min;
-            else if (!(flags & KSSD_SKETCH_BY_POS) && cap <= ((uint64_t)big_min << DEDUP_MAX_PARTS_LOG2)) {
+            else if (!(flags & KSSD_SKETCH_BY_POS) && cap <= ((uint64_t)big_min << DEDUP_MAX_PARTS_LOG2) && !no_parts) {
                 // sorted in LDS in parts: ranges of the ids' top bits, narrow enough for the register sort where that is possible
                 // (~4 096 expected tuples per part) and never wider than the LDS array
                 uint32_t lg = 1;
@@ -894,7 +900,10 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
         c->h_reg_off[g] = acc;
         acc += cap;
         const bool is_med = !c->h_med.empty() && c->h_med.back().x == g;
-        if (cap <= big_min && cap > max_cap) max_cap = cap;
+        // (the per-genome workgroup's key array is 5/8 of the largest region, finish_sketch: a region that is all of its genome's
+        // positions asks for an array that holds them all -- there is no larger region to ask for behind it)
+        const uint64_t lds_cap = all_positions ? (cap * 8 + 4) / 5 : cap;
+        if (cap <= big_min && lds_cap > max_cap) max_cap = lds_cap;
         if (cap > big_min && !is_med && cap > max_big) max_big = cap;
     }
     c->h_reg_off[n_genomes] = acc;
@@ -1231,7 +1240,9 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
     }
     if (st.region_overflow) {
         double need = (double)st.max_need_q8 / 256.0;  // emitted / capacity of the worst genome
+        if (need > 4096.0) need = 4096.0;              // (no genome emits more than one tuple per position; a region that is all positions grows no further)
         c->region_factor *= (need > 1.0 ? need : 1.0) * 1.25;
+        if (c->region_factor > 1e9) c->region_factor = 1e9;
         return KSSD_ERR_OVERFLOW;
     }
     if (st.out_overflow) return KSSD_ERR_OVERFLOW;

@@ -661,3 +661,35 @@ def test_lengths_around_chunk_and_block_borders(params):
             b.close()
     finally:
         ctx.close()
+
+
+def test_tandem_repeat_whose_region_is_all_its_positions_converges():
+    """Found by profiles/fuzz_sketch.py in round 5 (profiles/r05E_fuzz_tandem_repeat.txt): at a dense parameter set (-k 8 -s 4 -l 1: every
+    16th sub-context) a tandem repeat of 190 kb stages 38 000 occurrences of a handful of ids.  Its region grows to ALL of its positions
+    and can grow no further, the parts of the LDS sort split ids by their top bits -- all in one part -- and every repeated call asked
+    for more of a region that was at its limit; an empty genome in the same batch reported the fullest region there can be (`cap - 1`
+    wrapped around for a region of no room), which the host multiplied into its growth factor.  Such a genome now leaves the parts path
+    after the first overflow, an empty region is 0 % full, and the call converges: ids as the oracle's."""
+    k, s, l = 8, 4, 1
+    shuf = K.Shuf.generate(k, s, l, seed=105)
+    sk = ko.Sketcher(shuf.table, k, s, l)
+    rng = np.random.default_rng(5048)
+    for unit_len, n, with_empty in ((46, 193_203, True), (46, 193_203, False), (7, 60_000, True)):
+        unit = rng.integers(0, 4, unit_len, dtype=np.uint8)
+        texts = [fasta_text(np.tile(rng.integers(0, 4, 29, dtype=np.uint8), 16_385)[:16_385], b"g0"),
+                 fasta_text(np.tile(unit, n)[:n], b"g1")]
+        if with_empty:
+            texts += [fasta_text(np.zeros(0, np.uint8), b"g2"), fasta_text(rng.integers(0, 4, 16, dtype=np.uint8), b"g3")]
+        ctx = K.GpuCtx(shuf, 0)
+        b = K.Batch()
+        for t in texts:
+            b.add_fasta(t)
+        off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+        for g, t in enumerate(texts):
+            want = np.zeros(0, np.uint32)
+            if len(t):
+                wi, wc = sk.fasta(t, with_comps=True)
+                want = np.sort((wi.astype(np.uint64) << np.uint64(4 * max(k - l - 7, 0)) | wc.astype(np.uint64)).astype(np.uint32))
+            assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want), (unit_len, n, g)
+        b.close()
+        ctx.close()
