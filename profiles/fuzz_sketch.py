@@ -42,6 +42,15 @@ for pi, (k, s, l) in enumerate(PARAMS):
             print("params", (k, s, l), "seed", seed, "error", e)
             bad += 1
             continue
+        try:  # the same batch with first positions (8-byte keys: what the command line asks for) must list the same ids
+            off2, ids2, pos2 = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+            n_cases += 1
+            if not (np.array_equal(off2, off) and np.array_equal(ids2, ids)):
+                bad += 1
+                print("params", (k, s, l), "seed", seed, "first-position call differs", flush=True)
+        except K.KssdError as e:
+            print("params", (k, s, l), "seed", seed, "first-position call: error", e)
+            bad += 1
         for g, t in enumerate(texts):
             if len(t):
                 wi, wc = sk.fasta(t, with_comps=True)          # stored ids and their components: the device lists whole tuples
