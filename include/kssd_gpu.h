@@ -302,8 +302,10 @@ int kssd_gpu_host_unregister(void *p);
 /*
  * Build the inverted index of the reference sketches on the device: replaces combco2mco
  * (co2mco.c:25-77).  CSR input, DEVICE pointers (as kssd_gpu_sketch_device writes them; any id order is
- * accepted).  max_ref_ids is only an upper bound of d_roff[n_ref] (it sizes the hash), so no host
- * synchronisation is needed between sketching and indexing.  The index lives in ctx until the next call.
+ * accepted).  max_ref_ids is only an upper bound of d_roff[n_ref] -- the TOTAL number of reference ids; it sizes the
+ * index's arrays -- so no host synchronisation is needed between sketching and indexing.  A bound that turns out too
+ * small is not followed behind those arrays: the index then holds the first max_ref_ids entries and
+ * kssd_gpu_index_status returns KSSD_ERR_PARAM.  The index lives in ctx until the next call.
  */
 int kssd_gpu_index_build_device(kssd_gpu_ctx *ctx, const uint64_t *d_roff, const uint32_t *d_rids,
                                 uint32_t n_ref, uint64_t max_ref_ids, void *stream);

@@ -827,12 +827,16 @@ class GpuCtx:
         index in place is whole when the call returns.  check=False: nothing is synchronised (a timed loop); the caller then polls
         index_status() itself -- the rows of an index that is not whole come back as 0xFFFFFFFF counts, never as stale data."""
         _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
-        if check and self.index_status(stream) == ERR_OVERFLOW:
-            _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
-            _gck(self.index_status(stream))
+        if check:
+            st = self.index_status(stream)
+            if st == ERR_OVERFLOW:
+                _gck(gpu_lib().kssd_gpu_index_build_device(self.h, _ptr(d_roff), _ptr(d_rids), n_ref, max_ref_ids, stream))
+                st = self.index_status(stream)
+            _gck(st)  # (ERR_PARAM: max_ref_ids -- the TOTAL of the references' ids -- was no upper bound of d_roff[n_ref])
 
     def index_status(self, stream=None):
-        """synchronises the stream; 0, or ERR_OVERFLOW when the (capped) build in place met a bucket fuller than its run: build again"""
+        """synchronises the stream; 0, ERR_OVERFLOW when the (capped) build in place met a bucket fuller than its run: build again --
+        or ERR_PARAM when the build's max_ref_ids was smaller than d_roff[n_ref] (the index then holds the first max_ref_ids entries)"""
         return gpu_lib().kssd_gpu_index_status(self.h, stream)
 
     def index_set_exact(self, exact=True):

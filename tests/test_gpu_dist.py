@@ -602,3 +602,33 @@ def test_index_of_more_than_2048_buckets_is_partitioned_in_two_levels(shuf_l3k10
     finally:
         ctx.close()
 
+
+
+def test_index_bound_that_is_too_small_is_reported_not_followed(shuf_l3k10):
+    """kssd_gpu_index_build_device sizes the index's arrays from max_ref_ids, the caller's bound on d_roff[n_ref] (the TOTAL of the
+    references' ids) -- the real total is only read on the device.  A bound that is too small (here: the largest sketch's size where the
+    total belongs: what profiles/fuzz_dist_device.py first passed, and the GPU faulted) takes the first max_ref_ids entries and nothing
+    behind the arrays; kssd_gpu_index_status says KSSD_ERR_PARAM; the same context then builds and searches with the right bound."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    roff, rids = random_sketches(rng, 812, 100, 1300, 1 << 28, clades=5)
+    qoff, qids = roff[:41].copy(), rids[: int(roff[40])].copy()
+    want = ko.shared_counts(roff, rids, qoff, qids, threads=4)
+    d = [torch.from_numpy(a).to(dev) for a in (roff.astype(np.int64), rids.view(np.int32), qoff.astype(np.int64), qids.view(np.int32))]
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        for exact in (False, True):
+            ctx.index_set_exact(exact)
+            for bound in (int(np.diff(roff).max()), len(rids) // 2, len(rids) - 1):
+                ctx.index_build_device(d[0], d[1], 812, bound, check=False)
+                assert ctx.index_status() == K.capi.ERR_PARAM, (exact, bound)
+                with pytest.raises(K.KssdError):
+                    ctx.index_build_device(d[0], d[1], 812, bound)
+            ctx.index_build_device(d[0], d[1], 812, len(rids))
+            shared = torch.zeros((40, 812), dtype=torch.int32, device=dev)
+            ctx.dist_device(d[2], d[3], 40, 0, 40, shared)
+            torch.cuda.synchronize()
+            assert np.array_equal(shared.cpu().numpy().view(np.uint32), want)
+    finally:
+        ctx.close()
