@@ -914,7 +914,10 @@ def main():
             rc, total, bad = ctx.sketch_status(stream)
             irc = ctx.index_status(stream)        # (a capped index build that overflowed: the next one counts first)
             if rc == 0 and irc == 0:
-                st["idx_bound"] = min(cap, int(total) + 1024)
+                # the index's bound per rank: what the FULLEST rank holds (the full-index partition builds over all ranks' ids with
+                # W x this -- with this rank's own count a fuller neighbour made the bound too small; kssd_gpu_index_status says so
+                # since the build stopped following a bound that is too small)
+                st["idx_bound"] = min(cap, max(int(total), most if emu else 0) + 1024)
                 break
             if rc not in (0, K.capi.ERR_OVERFLOW) or irc not in (0, K.capi.ERR_OVERFLOW):
                 raise SystemExit("sketch / index failed: rc=%d, %d" % (rc, irc))
@@ -928,6 +931,7 @@ def main():
             need = torch.tensor([st["idx_bound"]], dtype=torch.int64, device=dev)
             dist.all_reduce(need, op=dist.ReduceOp.MAX)
             st["unit"] = min(cap, (int(need.item()) + 4096 + 1023) // 1024 * 1024)
+            st["idx_bound"] = min(cap, int(need.item()))   # (the fullest rank's count + 1 024, for every rank)
             new_search()
             index_build()
             rows()
