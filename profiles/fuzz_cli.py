@@ -1,0 +1,116 @@
+"""development tool (GPU box): `kssd dist` of this build against the REFERENCE BINARY (oracle/_ref/kssd) on random directories of input
+files -- FASTA with several records, lower case, N runs, IUPAC codes, blank lines, CRLF, a last line without a newline, empty and tiny
+files, gzip'ed ones (one and several members), FASTQ under -n 1..3 / -Q -- at three parameter sets.  Compared: every file's sketch in
+the FILE order of combco.* (the reference's hash-slot order), cofiles.stat's header and sizes, and `dist -r` of the reference's own
+sketches through both binaries (distance.out as a set of lines).  python3 profiles/fuzz_cli.py [cases] [first seed]"""
+import gzip, os, shutil, subprocess, sys, tempfile
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in ("", "tests", "oracle"):
+    sys.path.insert(0, os.path.join(R, d))
+import numpy as np
+import kssd_oracle as ko
+BIN = os.path.join(R, "public_kssd_amd", "kssd")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+assert ko.have_ref(), "oracle/_ref/kssd is not in the snapshot"
+PARAMS = [(10, 6, 3), (8, 5, 2), (9, 6, 3)]
+
+def fasta(rng, name):
+    recs = int(rng.choice([1, 1, 1, 2, 5]))
+    out = []
+    for r in range(recs):
+        n = int(rng.choice([0, 1, 19, 20, 21, 300, 4095, 4096, 4097, 20_000, int(rng.integers(100, 150_000))]))
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        kind = int(rng.integers(0, 7))
+        if kind == 1 and n: s[rng.integers(0, n, max(1, n // 300))] = ord("N")
+        if kind == 2 and n > 50:
+            a = int(rng.integers(0, n - 10)); s[a:a + int(rng.integers(1, 3000))] = ord("N")
+        if kind == 3 and n: s = np.frombuffer(bytes(s).lower(), np.uint8).copy()
+        if kind == 4 and n: s[rng.integers(0, n, max(1, n // 200))] = np.frombuffer(b"RYKMSWBDHVn", np.uint8)[rng.integers(0, 11, max(1, n // 200))]
+        if kind == 5 and n > 100: s = np.tile(s[: int(rng.integers(1, 40))], n)[:n]
+        width = int(rng.choice([60, 70, 80, 1000, 10**9]))
+        lines = [bytes(s[i:i + width]) for i in range(0, n, width)] or [b""]
+        if rng.random() < 0.1: lines.insert(int(rng.integers(0, len(lines) + 1)), b"")
+        out.append(b">" + name.encode() + b"_r%d some description\n" % r + b"\n".join(lines))
+    t = b"\n".join(out)
+    if rng.random() < 0.8: t += b"\n"
+    if rng.random() < 0.08: t = t.replace(b"\n", b"\r\n")
+    return t
+
+def fastq(rng, name):
+    reads = int(rng.choice([1, 3, 200, 2000]))
+    src = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)]
+    out = []
+    for r in range(reads):
+        L = int(rng.choice([30, 100, 150, 151]))
+        a = int(rng.integers(0, len(src) - L))
+        s = src[a:a + L].copy()
+        if rng.random() < 0.05: s[int(rng.integers(0, L))] = ord("N")
+        q = rng.integers(33 + 2, 33 + 41, L).astype(np.uint8)
+        out.append(b"@%s_%d\n%s\n+\n%s\n" % (name.encode(), r, bytes(s), bytes(q)))
+    return b"".join(out)
+
+bad = 0
+for case in range(n_cases):
+    rng = np.random.default_rng(910_000 + seed0 + case)
+    k, s, l = PARAMS[int(rng.integers(0, len(PARAMS)))]
+    d = tempfile.mkdtemp(prefix="kssd_fz_", dir="/dev/shm")
+    try:
+        subprocess.run([BIN, "shuffle", "-k", str(k), "-s", str(s), "-l", str(l), "-o", "p", "--seed", str(1000 + case)], cwd=d, check=True, stdout=subprocess.DEVNULL)
+        fq_mode = rng.random() < 0.25
+        os.mkdir(os.path.join(d, "in"))
+        for f in range(int(rng.integers(1, 7))):
+            name = "f%02d" % f
+            if fq_mode:
+                t, ext = fastq(rng, name), ".fastq"
+            else:
+                t, ext = fasta(rng, name), str(rng.choice([".fasta", ".fa", ".fna", ".fas"]))
+            if rng.random() < 0.3:
+                z = gzip.compress(t, int(rng.choice([1, 6, 9])))
+                if rng.random() < 0.2 and len(t) > 100:
+                    c = len(t) // 2; z = gzip.compress(t[:c], 1) + gzip.compress(t[c:], 6)
+                open(os.path.join(d, "in", name + ext + ".gz"), "wb").write(z)
+            else:
+                open(os.path.join(d, "in", name + ext), "wb").write(t)
+        opts = []
+        if fq_mode:
+            opts = ["-n", str(int(rng.integers(1, 4)))]
+            if rng.random() < 0.4: opts += ["-Q", str(int(rng.choice([0, 10, 20, 30])))]
+        elif rng.random() < 0.15:
+            opts = ["-u"]
+        args = ["dist", "-p", "4", "-L", "p.shuf"] + opts
+        r_ref = ko.run_ref(args + ["-o", "o_ref", "in"], cwd=d, check=False)
+        r_our = subprocess.run([BIN] + args + ["-o", "o_our", "in"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        tag = "case %d seed %d k%d s%d l%d %s %s" % (case, 910_000 + seed0 + case, k, s, l, "fastq" if fq_mode else "fasta", " ".join(opts))
+        if (r_ref.returncode == 0) != (r_our.returncode == 0):
+            bad += 1
+            print(tag, "EXIT CODES differ: reference", r_ref.returncode, "ours", r_our.returncode, "|", r_ref.stdout.decode(errors="replace")[-200:].replace("\n", " "), "|", r_our.stdout.decode(errors="replace")[-200:].replace("\n", " "), flush=True)
+            continue
+        if r_ref.returncode != 0:
+            continue
+        h1, n1, o1, i1 = ko.read_sketch_dir(os.path.join(d, "o_ref"))
+        h2, n2, o2, i2 = ko.read_sketch_dir(os.path.join(d, "o_our"))
+        a = {os.path.basename(nm): i1[int(o1[j]):int(o1[j + 1])] for j, nm in enumerate(n1)}
+        b = {os.path.basename(nm): i2[int(o2[j]):int(o2[j + 1])] for j, nm in enumerate(n2)}
+        ok = sorted(a) == sorted(b) and all(np.array_equal(a[x], b[x]) for x in a) and {x: h1[x] for x in h1 if x != "infile_num"} == {x: h2[x] for x in h2 if x != "infile_num"}
+        if not ok:
+            bad += 1
+            diff = [x for x in a if x not in b or not np.array_equal(a[x], b[x])]
+            print(tag, "SKETCHES differ:", diff[:4], [(len(a[x]), len(b.get(x, []))) for x in diff[:4]], flush=True)
+            shutil.copytree(d, os.path.join(R, "gpurun_out", "fuzz_cli_case_%d" % (seed0 + case)), ignore=shutil.ignore_patterns("*.shuf", "o_*"))
+            continue
+        if len(n1) >= 2 and not fq_mode and not opts:   # the search of the reference's sketches through both binaries
+            ko.run_ref(["dist", "-p", "4", "-o", "m_ref", "o_ref"], cwd=d, check=False)
+            rr = ko.run_ref(["dist", "-p", "4", "-r", "m_ref", "-o", "d_ref", "o_ref"], cwd=d, check=False)
+            ro = subprocess.run([BIN, "dist", "-p", "4", "-r", "o_ref", "-o", "d_our", "o_ref"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if rr.returncode == 0 and ro.returncode == 0:
+                la = sorted(open(os.path.join(d, "d_ref", "distance.out"), "rb").read().splitlines())
+                lb = sorted(open(os.path.join(d, "d_our", "distance.out"), "rb").read().splitlines())
+                if la != lb:
+                    bad += 1
+                    print(tag, "DISTANCE.OUT differs:", len(la), len(lb), [x for x in la if x not in lb][:2], [x for x in lb if x not in la][:2], flush=True)
+            elif (rr.returncode == 0) != (ro.returncode == 0):
+                print(tag, "search exit codes differ (not counted): reference", rr.returncode, "ours", ro.returncode, "|", rr.stdout.decode(errors="replace")[-160:].replace("\n", " "), flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+print("cases", n_cases, "bad", bad)
