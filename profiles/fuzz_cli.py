@@ -1,8 +1,9 @@
 """development tool (GPU box): `kssd dist` of this build against the REFERENCE BINARY (oracle/_ref/kssd) on random directories of input
 files -- FASTA with several records, lower case, N runs, IUPAC codes, blank lines, CRLF, a last line without a newline, empty and tiny
 files, gzip'ed ones (one and several members), FASTQ under -n 1..3 / -Q -- at three parameter sets.  Compared: every file's sketch in
-the FILE order of combco.* (the reference's hash-slot order), cofiles.stat's header and sizes, and `dist -r` of the reference's own
-sketches through both binaries (distance.out as a set of lines).  python3 profiles/fuzz_cli.py [cases] [first seed]"""
+the FILE order of combco.* (the reference's hash-slot order), cofiles.stat's header and sizes, `dist -r` of the reference's own
+sketches through both binaries (distance.out as a set of lines), and `kssd set` -u / -q / -s / -i on them (pan files byte for byte, the
+filtered sketches per name in file order).  python3 profiles/fuzz_cli.py [cases] [first seed]"""
 import gzip, os, shutil, subprocess, sys, tempfile
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for d in ("", "tests", "oracle"):
@@ -101,8 +102,15 @@ for case in range(n_cases):
             continue
         if len(n1) >= 2 and not fq_mode and not opts:   # the search of the reference's sketches through both binaries
             ko.run_ref(["dist", "-p", "4", "-o", "m_ref", "o_ref"], cwd=d, check=False)
-            rr = ko.run_ref(["dist", "-p", "4", "-r", "m_ref", "-o", "d_ref", "o_ref"], cwd=d, check=False)
-            ro = subprocess.run([BIN, "dist", "-p", "4", "-r", "o_ref", "-o", "d_our", "o_ref"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            ropt = []   # the report's options at random: metric, output fields, neighbours, distance cut-off, correction
+            if rng.random() < 0.5: ropt += ["-M", str(int(rng.integers(0, 2)))]
+            if rng.random() < 0.5: ropt += ["-O", str(int(rng.integers(0, 3)))]
+            if rng.random() < 0.3: ropt += ["-N", str(int(rng.integers(1, len(n1) + 1)))]
+            if rng.random() < 0.3: ropt += ["-D", str(float(rng.choice([0.05, 0.2, 0.5, 1.0])))]
+            if rng.random() < 0.3: ropt += ["--correction", str(int(rng.integers(0, 2)))]
+            tag += " report " + " ".join(ropt)
+            rr = ko.run_ref(["dist", "-p", "4", "-r", "m_ref"] + ropt + ["-o", "d_ref", "o_ref"], cwd=d, check=False)
+            ro = subprocess.run([BIN, "dist", "-p", "4", "-r", "o_ref"] + ropt + ["-o", "d_our", "o_ref"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
             if rr.returncode == 0 and ro.returncode == 0:
                 la = sorted(open(os.path.join(d, "d_ref", "distance.out"), "rb").read().splitlines())
                 lb = sorted(open(os.path.join(d, "d_our", "distance.out"), "rb").read().splitlines())
@@ -111,6 +119,32 @@ for case in range(n_cases):
                     print(tag, "DISTANCE.OUT differs:", len(la), len(lb), [x for x in la if x not in lb][:2], [x for x in lb if x not in la][:2], flush=True)
             elif (rr.returncode == 0) != (ro.returncode == 0):
                 print(tag, "search exit codes differ (not counted): reference", rr.returncode, "ours", ro.returncode, "|", rr.stdout.decode(errors="replace")[-160:].replace("\n", " "), flush=True)
+            # kssd set: union / uniq union of the reference's sketches, then subtract / intersect with that pan-sketch, through both binaries
+            def per_name(sub):
+                hh, nn, oo, ii = ko.read_sketch_dir(os.path.join(d, sub))
+                return {os.path.basename(x): ii[int(oo[j]):int(oo[j + 1])] for j, x in enumerate(nn)}
+            set_ok = True
+            for flag, out, fn in (("-u", "U", "pan.0"), ("-q", "Q", "uniq_pan.0")):
+                ra = ko.run_ref(["set", flag, "-o", out + "_ref", "o_ref"], cwd=d, check=False)
+                rb = subprocess.run([BIN, "set", flag, "-o", out + "_our", "o_ref"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                if ra.returncode != rb.returncode and (ra.returncode == 0 or rb.returncode == 0):
+                    set_ok = False; print(tag, "set", flag, "exit codes differ:", ra.returncode, rb.returncode, flush=True)
+                elif ra.returncode == 0 and open(os.path.join(d, out + "_ref", fn), "rb").read() != open(os.path.join(d, out + "_our", fn), "rb").read():
+                    set_ok = False; print(tag, "set", flag, fn, "differs", flush=True)
+            if set_ok and os.path.exists(os.path.join(d, "U_ref", "pan.0")):
+                for flag, out in (("-s", "S"), ("-i", "I")):
+                    for pan in ("U_ref", "Q_ref"):
+                        if not os.path.exists(os.path.join(d, pan)): continue
+                        ra = ko.run_ref(["set", flag, pan, "-o", out + pan + "_ref", "o_ref"], cwd=d, check=False)
+                        rb = subprocess.run([BIN, "set", flag, pan, "-o", out + pan + "_our", "o_ref"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                        if (ra.returncode == 0) != (rb.returncode == 0):
+                            set_ok = False; print(tag, "set", flag, pan, "exit codes differ:", ra.returncode, rb.returncode, rb.stdout.decode(errors="replace")[-150:], flush=True)
+                        elif ra.returncode == 0:
+                            x, y = per_name(out + pan + "_ref"), per_name(out + pan + "_our")
+                            if sorted(x) != sorted(y) or any(not np.array_equal(x[z], y[z]) for z in x):
+                                set_ok = False; print(tag, "set", flag, pan, "results differ", flush=True)
+            if not set_ok:
+                bad += 1
     finally:
         shutil.rmtree(d, ignore_errors=True)
 print("cases", n_cases, "bad", bad)
