@@ -74,11 +74,24 @@ for case in range(n_cases):
             else:
                 open(os.path.join(d, "in", name + ext), "wb").write(t)
         opts = []
+        byread = False
         if fq_mode:
-            opts = ["-n", str(int(rng.integers(1, 4)))]
-            if rng.random() < 0.4: opts += ["-Q", str(int(rng.choice([0, 10, 20, 30])))]
+            if rng.random() < 0.3:
+                opts = ["-A"]                                   # abundances: combco.<c>.a beside the ids
+            else:
+                opts = ["-n", str(int(rng.integers(1, 4)))]
+                if rng.random() < 0.4: opts += ["-Q", str(int(rng.choice([0, 10, 20, 30])))]
         elif rng.random() < 0.15:
             opts = ["-u"]
+        elif rng.random() < 0.12:
+            byread = True                                       # one file (every file overwrites the one before, and the two binaries order files differently)
+            keep = sorted(os.listdir(os.path.join(d, "in")))[0]
+            for f in os.listdir(os.path.join(d, "in")):
+                if f != keep: os.remove(os.path.join(d, "in", f))
+            if keep.endswith(".gz"):                            # (the reference reads --byread inputs without zcat: a documented deviation)
+                t = gzip.decompress(open(os.path.join(d, "in", keep), "rb").read())
+                os.remove(os.path.join(d, "in", keep)); open(os.path.join(d, "in", keep[:-3]), "wb").write(t)
+            opts = ["--byread"]
         args = ["dist", "-p", "4", "-L", "p.shuf"] + opts
         r_ref = ko.run_ref(args + ["-o", "o_ref", "in"], cwd=d, check=False)
         r_our = subprocess.run([BIN] + args + ["-o", "o_our", "in"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -89,11 +102,24 @@ for case in range(n_cases):
             continue
         if r_ref.returncode != 0:
             continue
+        if byread:
+            same = all(open(os.path.join(d, "o_ref", f), "rb").read() == open(os.path.join(d, "o_our", f), "rb").read() for f in ("combco.0", "combco.index.0"))
+            if not same:
+                bad += 1
+                print(tag, "BYREAD files differ", flush=True)
+            continue
         h1, n1, o1, i1 = ko.read_sketch_dir(os.path.join(d, "o_ref"))
         h2, n2, o2, i2 = ko.read_sketch_dir(os.path.join(d, "o_our"))
         a = {os.path.basename(nm): i1[int(o1[j]):int(o1[j + 1])] for j, nm in enumerate(n1)}
         b = {os.path.basename(nm): i2[int(o2[j]):int(o2[j + 1])] for j, nm in enumerate(n2)}
         ok = sorted(a) == sorted(b) and all(np.array_equal(a[x], b[x]) for x in a) and {x: h1[x] for x in h1 if x != "infile_num"} == {x: h2[x] for x in h2 if x != "infile_num"}
+        if ok and "-A" in opts and os.path.exists(os.path.join(d, "o_ref", "combco.0.a")):
+            c1 = np.fromfile(os.path.join(d, "o_ref", "combco.0.a"), np.uint16); c2 = np.fromfile(os.path.join(d, "o_our", "combco.0.a"), np.uint16)
+            ca = {os.path.basename(nm): c1[int(o1[j]):int(o1[j + 1])] for j, nm in enumerate(n1)}
+            cb = {os.path.basename(nm): c2[int(o2[j]):int(o2[j + 1])] for j, nm in enumerate(n2)}
+            if any(not np.array_equal(ca[x], cb[x]) for x in ca):
+                ok = False
+                print(tag, "ABUNDANCES differ", flush=True)
         if not ok:
             bad += 1
             diff = [x for x in a if x not in b or not np.array_equal(a[x], b[x])]
