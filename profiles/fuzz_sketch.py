@@ -18,7 +18,7 @@ for pi, (k, s, l) in enumerate(PARAMS):
     sk = ko.Sketcher(shuf.table, k, s, l)
     ctx = K.GpuCtx(shuf, 0)
     for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
-        rng = np.random.default_rng(1000 * pi + seed)
+        rng = np.random.default_rng((int(sys.argv[2]) if len(sys.argv) > 2 else 0) + 1000 * pi + seed)
         texts = []
         for g in range(int(rng.integers(1, 12))):
             kind = int(rng.integers(0, 6))

@@ -902,7 +902,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
         const bool is_med = !c->h_med.empty() && c->h_med.back().x == g;
         // (the per-genome workgroup's key array is 5/8 of the largest region, finish_sketch: a region that is all of its genome's
         // positions asks for an array that holds them all -- there is no larger region to ask for behind it)
-        const uint64_t lds_cap = all_positions ? (cap * 8 + 4) / 5 : cap;
+        const uint64_t lds_cap = all_positions ? cap * 8 / 5 : cap;  // (rounded DOWN: 5/8 of it rounded up is `cap` again, never cap + 1 -- which doubled the array of a 16 384-position genome past the LDS)
         if (cap <= big_min && lds_cap > max_cap) max_cap = lds_cap;
         if (cap > big_min && !is_med && cap > max_big) max_big = cap;
     }

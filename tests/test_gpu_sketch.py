@@ -691,5 +691,50 @@ def test_tandem_repeat_whose_region_is_all_its_positions_converges():
                 wi, wc = sk.fasta(t, with_comps=True)
                 want = np.sort((wi.astype(np.uint64) << np.uint64(4 * max(k - l - 7, 0)) | wc.astype(np.uint64)).astype(np.uint32))
             assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want), (unit_len, n, g)
+        # the same batch with first positions (8-byte keys: half as many fit the LDS sort): the same ids
+        off2, ids2, pos2 = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+        assert np.array_equal(off2, off) and np.array_equal(ids2, ids)
         b.close()
         ctx.close()
+    # the fuzzer's second find, as the fuzzer made it (profiles/fuzz_sketch.py, seed base 777 000, parameter set 5, seed 189): the
+    # first-position call failed with "hipFuncSetAttribute ... invalid argument"
+    rng2 = np.random.default_rng(777_000 + 1000 * 5 + 189)
+    texts = []
+    for g in range(int(rng2.integers(1, 12))):
+        kind = int(rng2.integers(0, 6))
+        n = int(rng2.choice([0, 1, 15, 16, 17, 2 * k - 1, 2 * k, 4095, 4096, 4097, 16383, 16384, 16385, 65536, int(rng2.integers(100, 400_000))]))
+        codes = rng2.integers(0, 4, n, dtype=np.uint8)
+        if kind == 1 and n > 100:
+            codes = np.tile(codes[: int(rng2.integers(1, 50))], n)[:n]
+        nm = np.zeros(n, dtype=bool)
+        if kind == 2 and n:
+            nm[rng2.integers(0, n, max(1, n // 500))] = True
+        if kind == 3 and n > 50:
+            a0 = int(rng2.integers(0, n - 10))
+            nm[a0:a0 + int(rng2.integers(1, 9000))] = True
+        texts.append(fasta_text(codes, b"g%d" % g, n_mask=nm if nm.any() else None))
+    ctx = K.GpuCtx(shuf, 0)
+    b = K.Batch()
+    for t in texts:
+        b.add_fasta(t)
+    off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+    off2, ids2, pos2 = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+    assert np.array_equal(off2, off) and np.array_equal(ids2, ids)
+    b.close()
+    ctx.close()
+    # a region of exactly 16 384 positions -- all of the genome's, after an overflow -- asks for an LDS array of 16 384 keys, not of
+    # the next power of two (a rounding on the way doubled it: 256 KB of 8-byte keys, more than the LDS; the fuzzer's second find)
+    ctx = K.GpuCtx(shuf, 0)
+    b = K.Batch()
+    texts = [fasta_text(np.tile(rng.integers(0, 4, 23, dtype=np.uint8), 16_384)[:16_384], b"t"), fasta_text(rng.integers(0, 4, 16_384, dtype=np.uint8), b"u")]
+    for t in texts:
+        b.add_fasta(t)
+    off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+    off2, ids2, pos2 = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+    assert np.array_equal(off2, off) and np.array_equal(ids2, ids)
+    for g, t in enumerate(texts):
+        wi, wc = sk.fasta(t, with_comps=True)
+        want = np.sort((wi.astype(np.uint64) << np.uint64(4 * max(k - l - 7, 0)) | wc.astype(np.uint64)).astype(np.uint32))
+        assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want), g
+    b.close()
+    ctx.close()
