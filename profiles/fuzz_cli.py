@@ -92,7 +92,7 @@ for case in range(n_cases):
                 t = gzip.decompress(open(os.path.join(d, "in", keep), "rb").read())
                 os.remove(os.path.join(d, "in", keep)); open(os.path.join(d, "in", keep[:-3]), "wb").write(t)
             opts = ["--byread"]
-        args = ["dist", "-p", "4", "-L", "p.shuf"] + opts
+        args = ["dist", "-p", str(int(rng.choice([1, 2, 4, 16]))), "-L", "p.shuf"] + opts
         r_ref = ko.run_ref(args + ["-o", "o_ref", "in"], cwd=d, check=False)
         r_our = subprocess.run([BIN] + args + ["-o", "o_our", "in"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         tag = "case %d seed %d k%d s%d l%d %s %s" % (case, 910_000 + seed0 + case, k, s, l, "fastq" if fq_mode else "fasta", " ".join(opts))
