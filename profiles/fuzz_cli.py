@@ -135,8 +135,16 @@ for case in range(n_cases):
             if rng.random() < 0.3: ropt += ["-D", str(float(rng.choice([0.05, 0.2, 0.5, 1.0])))]
             if rng.random() < 0.3: ropt += ["--correction", str(int(rng.integers(0, 2)))]
             tag += " report " + " ".join(ropt)
-            rr = ko.run_ref(["dist", "-p", "4", "-r", "m_ref"] + ropt + ["-o", "d_ref", "o_ref"], cwd=d, check=False)
-            ro = subprocess.run([BIN, "dist", "-p", "4", "-r", "o_ref"] + ropt + ["-o", "d_our", "o_ref"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            qdir = "o_ref"
+            if rng.random() < 0.5:   # queries that are not the references: a second directory of 1-4 files, sketched by the reference
+                os.mkdir(os.path.join(d, "in2"))
+                for f in range(int(rng.integers(1, 5))):
+                    open(os.path.join(d, "in2", "q%02d.fasta" % f), "wb").write(fasta(rng, "q%02d" % f))
+                if ko.run_ref(["dist", "-p", "2", "-L", "p.shuf", "-o", "o_ref2", "in2"], cwd=d, check=False).returncode == 0:
+                    qdir = "o_ref2"
+                    tag += " (other queries)"
+            rr = ko.run_ref(["dist", "-p", "4", "-r", "m_ref"] + ropt + ["-o", "d_ref", qdir], cwd=d, check=False)
+            ro = subprocess.run([BIN, "dist", "-p", "4", "-r", "o_ref"] + ropt + ["-o", "d_our", qdir], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
             if rr.returncode == 0 and ro.returncode == 0:
                 la = sorted(open(os.path.join(d, "d_ref", "distance.out"), "rb").read().splitlines())
                 lb = sorted(open(os.path.join(d, "d_our", "distance.out"), "rb").read().splitlines())
