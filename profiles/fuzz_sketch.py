@@ -36,6 +36,8 @@ for pi, (k, s, l) in enumerate(PARAMS):
         b = K.Batch()
         for t in texts:
             b.add_fasta(t)
+        # four seeds in ten: small limits on the LDS sort send ordinary genomes down the parts / ranges / global-memory paths
+        ctx.set_lds_sort_limit(int(rng.choice([64, 256, 1024, 4096])) if rng.random() < 0.4 else 0)
         try:
             off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
         except K.KssdError as e:
