@@ -5,6 +5,7 @@
 #define _GNU_SOURCE
 #include "kssd_host.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -800,6 +801,15 @@ int kssd_slurp(const char *path, unsigned char **buf, size_t *len)
  * files of a pair.  The buffers live as long as the thread. */
 static __thread unsigned char *t_zbuf[2];
 static __thread size_t t_zcap[2];
+/* (given back when the thread ends: a key whose destructor frees them, armed by the thread's first read) */
+static pthread_key_t t_zkey;
+static pthread_once_t t_zkey_once = PTHREAD_ONCE_INIT;
+static void t_zfree(void *unused)
+{
+    (void)unused;
+    for (int i = 0; i < 2; i++) { free(t_zbuf[i]); t_zbuf[i] = NULL; t_zcap[i] = 0; }
+}
+static void t_zkey_make(void) { pthread_key_create(&t_zkey, t_zfree); }
 static int read_fd_whole(int fd, int slot, unsigned char **out, size_t *n_out)
 {
     struct stat zst;
@@ -808,6 +818,8 @@ static int read_fd_whole(int fd, int slot, unsigned char **out, size_t *n_out)
     for (;;) {
         const size_t want = zn + ((size_t)zst.st_size > zn ? (size_t)zst.st_size - zn : 0) + 4096;
         if (t_zcap[slot] < want) {
+            pthread_once(&t_zkey_once, t_zkey_make);
+            pthread_setspecific(t_zkey, (void *)1); /* (any non-NULL value: the destructor runs for threads that hold buffers) */
             const size_t nc = want + want / 4;
             unsigned char *q = realloc(t_zbuf[slot], nc);
             if (!q) return KSSD_HOST_ERR_NOMEM;

@@ -11,6 +11,7 @@
  * Own code throughout; what is reused are the published formats and the published folding constants of the CRC-32 polynomial. */
 #include "kssd_host.h"
 
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -616,6 +617,14 @@ static void z_fail(zstate *z, int rc)
 }
 
 static __thread inflate_tabs *t_tabs[2];
+static pthread_key_t t_tabs_key; /* (the tables go back when the thread ends) */
+static pthread_once_t t_tabs_once = PTHREAD_ONCE_INIT;
+static void t_tabs_free(void *unused)
+{
+    (void)unused;
+    for (int i = 0; i < 2; i++) { free(t_tabs[i]); t_tabs[i] = NULL; }
+}
+static void t_tabs_key_make(void) { pthread_key_create(&t_tabs_key, t_tabs_free); }
 static int z_init(zstate *z, int slot, const unsigned char *in, size_t in_len, unsigned char *out, size_t cap)
 {
     memset(z, 0, sizeof *z);
@@ -627,6 +636,8 @@ static int z_init(zstate *z, int slot, const unsigned char *in, size_t in_len, u
     z->rc = KSSD_HOST_OK;
     z->t = t_tabs[slot]; /* (the thread's own, kept from file to file: 0.2 MB that malloc() would map and unmap every time) */
     if (!z->t) {
+        pthread_once(&t_tabs_once, t_tabs_key_make);
+        pthread_setspecific(t_tabs_key, (void *)1);
         z->t = t_tabs[slot] = (inflate_tabs *)malloc(sizeof *z->t);
         if (!z->t) { z_fail(z, KSSD_HOST_ERR_NOMEM); return -1; }
         z->t->fixed_ready = 0;
