@@ -29,6 +29,10 @@ seeds.append(gzip.compress(T.dna(rng, 3000, alphabet=b"ACGTacgtNNNNRYKM"), 6) + 
 co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED); seeds.append(co.compress(T.dna(rng, 5000)) + co.flush())
 seeds.append(gzip.compress(rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(), 6))
 seeds.append(gzip.compress((b"AC" * 7 + b"GGT") * 900, 9))
+for lvl in (1, 6, 9):  # text + noise + text in ONE stream: stored blocks right behind Huffman blocks, no flush between
+    co = zlib.compressobj(lvl, zlib.DEFLATED, 31)
+    seeds.append(co.compress(T.dna(rng, 30_000) + rng.integers(0, 256, 40_000, dtype=np.uint8).tobytes() + T.dna(rng, 9_000)
+                             + rng.integers(0, 256, 700, dtype=np.uint8).tobytes() + T.dna(rng, 2_000)) + co.flush())
 accepted = refused = differ = 0
 prev = seeds[0]
 for case in range(n_cases):

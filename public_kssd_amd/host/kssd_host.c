@@ -837,6 +837,38 @@ static int read_fd_whole(int fd, int slot, unsigned char **out, size_t *n_out)
     return KSSD_HOST_OK;
 }
 
+/* a gzip'ed file through zlib's gzread (takes the descriptor over): the decoder of rounds 1 - 4, KSSD_ZLIB_GUNZIP=1, and the second
+ * opinion when host/kssd_inflate.c refuses a stream */
+static int slurp_gzread(int fd, unsigned char **buf, size_t *cap, size_t *len)
+{
+    gzFile g = gzdopen(fd, "rb");
+    if (!g) { close(fd); return KSSD_HOST_ERR_IO; }
+    gzbuffer(g, 1 << 20);
+    size_t n = 0;
+    *len = 0;
+    for (;;) {
+        if (*cap - n < (1u << 20)) {
+            size_t nc = *cap + *cap / 2 + (1u << 22);
+            unsigned char *q = realloc(*buf, nc);
+            if (!q) { gzclose(g); return KSSD_HOST_ERR_NOMEM; }
+            *buf = q;
+            *cap = nc;
+        }
+        size_t room = *cap - n;
+        int r = gzread(g, *buf + n, (unsigned)(room > (1u << 30) ? (1u << 30) : room));
+        if (r < 0) { gzclose(g); return KSSD_HOST_ERR_IO; }
+        if (r == 0) break;
+        n += (size_t)r;
+    }
+    /* (gzread returns what it has and reports a damaged or truncated stream only through gzerror / gzclose) */
+    int err = Z_OK;
+    (void)gzerror(g, &err);
+    const int eof_clean = err == Z_OK || err == Z_STREAM_END;
+    if (gzclose(g) != Z_OK || !eof_clean) return KSSD_HOST_ERR_IO;
+    *len = n;
+    return KSSD_HOST_OK;
+}
+
 /* the same into a buffer the caller keeps from file to file (grown when needed): no allocation, no page faults of fresh
  * memory per file.  Plain files are read straight with read(2); gzip'ed ones (magic 1f 8b) go through zlib. */
 int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t *len)
@@ -853,31 +885,10 @@ int kssd_slurp_reuse(const char *path, unsigned char **buf, size_t *cap, size_t 
         int rc = read_fd_whole(fd, 0, &z, &zn);
         close(fd);
         if (rc == KSSD_HOST_OK) rc = kssd_gunzip_mem(z, zn, buf, cap, len);
+        if (rc == KSSD_HOST_ERR_IO && (fd = open(path, O_RDONLY)) >= 0) rc = slurp_gzread(fd, buf, cap, len); /* zlib decides */
         return rc;
     }
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-        gzFile g = gzdopen(fd, "rb");
-        if (!g) { close(fd); return KSSD_HOST_ERR_IO; }
-        gzbuffer(g, 1 << 20);
-        size_t n = 0;
-        for (;;) {
-            if (*cap - n < (1u << 20)) {
-                size_t nc = *cap + *cap / 2 + (1u << 22);
-                unsigned char *q = realloc(*buf, nc);
-                if (!q) { gzclose(g); return KSSD_HOST_ERR_NOMEM; }
-                *buf = q;
-                *cap = nc;
-            }
-            size_t room = *cap - n;
-            int r = gzread(g, *buf + n, (unsigned)(room > (1u << 30) ? (1u << 30) : room));
-            if (r < 0) { gzclose(g); return KSSD_HOST_ERR_IO; }
-            if (r == 0) break;
-            n += (size_t)r;
-        }
-        gzclose(g);
-        *len = n;
-        return KSSD_HOST_OK;
-    }
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return slurp_gzread(fd, buf, cap, len);
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return KSSD_HOST_ERR_IO; }
     size_t want = (size_t)st.st_size, n = 0;
@@ -916,6 +927,10 @@ void kssd_slurp_reuse2(const char *const path[2], unsigned char **buf[2], size_t
     if (gz) {
         const unsigned char *const in[2] = {z[0], z[1]};
         kssd_gunzip_mem2(in, zn, buf, cap, len, rc);
+        for (int f = 0; f < 2; f++) {
+            int fd;
+            if (rc[f] == KSSD_HOST_ERR_IO && (fd = open(path[f], O_RDONLY)) >= 0) rc[f] = slurp_gzread(fd, buf[f], cap[f], len[f]); /* zlib decides */
+        }
     } else {
         for (int f = 0; f < 2; f++) rc[f] = kssd_slurp_reuse(path[f], buf[f], cap[f], len[f]);
     }

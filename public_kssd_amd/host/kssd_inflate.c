@@ -721,6 +721,9 @@ static void z_advance(zstate *z)
             if (type == 0) { /* stored: back to a byte boundary, LEN / NLEN, the bytes */
                 b->bb >>= b->bc & 7;
                 b->bc -= b->bc & 7;
+                /* the fast loop's refill leaves bits of *in above the count (harmless while `in` stands still: the next refill ORs
+                 * the same bits again) -- the copy below moves `in`, so nothing above the count may stay */
+                b->bb = b->bc ? b->bb & ((1ull << b->bc) - 1) : 0;
                 uint32_t len, nlen;
                 if (take_bits(b, 16, &len) || take_bits(b, 16, &nlen) || (len ^ nlen) != 0xFFFFu) { z_fail(z, KSSD_HOST_ERR_IO); return; }
                 if (out_room(o, len)) { z_fail(z, KSSD_HOST_ERR_NOMEM); return; }

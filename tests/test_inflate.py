@@ -132,6 +132,31 @@ def test_stored_fixed_and_repetitive_streams():
     assert rc == 0 and out == payload
 
 
+def test_stored_blocks_right_behind_huffman_blocks_in_one_stream():
+    """text + noise + text through ONE compressobj: a non-empty stored block follows a Huffman block that ended inside the fast
+    symbol loop, whose refill leaves bits of the next input byte above the bit count (they must not survive the
+    stored block's copy); alone and two in step, and through the file readers"""
+    rng = np.random.default_rng(11)
+    streams = []
+    for i in range(60):
+        co = zlib.compressobj((1, 6, 9)[i % 3], zlib.DEFLATED, 31)
+        parts = []
+        for _ in range(int(rng.integers(2, 5))):
+            parts.append(dna(rng, int(rng.integers(100, 120_000))))
+            parts.append(rng.integers(0, 256, int(rng.integers(1, 70_000)), dtype=np.uint8).tobytes())
+        if i % 2:
+            parts.append(dna(rng, 5_000))
+        raw = b"".join(parts)
+        z = co.compress(raw) + co.flush()
+        assert zlib.decompress(z, 31) == raw
+        streams.append((z, raw))
+        rc, out = gunzip(z)
+        assert rc == 0 and out == raw, i
+    for (z0, r0), (z1, r1) in zip(streams[::2], streams[1::2]):
+        (rc0, o0), (rc1, o1) = gunzip2(z0, z1)
+        assert rc0 == 0 and o0 == r0 and rc1 == 0 and o1 == r1
+
+
 def test_members_headers_and_trailing_zeros():
     rng = np.random.default_rng(3)
     a, b, c = dna(rng, 10_000), b"", dna(rng, 123_456)
