@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import public_kssd_amd as K  # noqa: E402
 from benchlib.launch import host_cores, log, self_launch  # noqa: E402
-from benchlib.workloads import READ_LEN, make_batch, make_long_records, make_reads_batch  # noqa: E402
+from benchlib.workloads import READ_LEN, make_batch, make_long_records, make_reads_batch, mask_summary, summary_clear_lanes  # noqa: E402
 from benchlib.multi import EmulatedGather, run_exchange_c  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -369,6 +369,7 @@ def run_fastq(a, shuf, dev):
     torch.cuda.synchronize()
     index_ms = e0.elapsed_time(e1)
     qcap = int(n_pos / 4096 * 1.5) + 4096
+    rsumm = None if a.no_mask_summary else mask_summary(ctx, rm, int(rco[-1]), dev)
     res_m = {}
     for M in (1, 2):
         qoff = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -379,7 +380,7 @@ def run_fastq(a, shuf, dev):
         flags = K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY
 
         def step(timed=None):
-            ctx.sketch_plan(rp, rm, rco, qoff, qids, qcap, flags, M)
+            ctx.sketch_plan(rp, rm, rco, qoff, qids, qcap, flags, M, d_summary=rsumm)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed is not None else None
             for i, ph in enumerate((K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH)):
                 if ev:
@@ -543,9 +544,10 @@ def run_mammal(a, dev, world, rank):
     off_d = torch.zeros(G + 1, dtype=torch.int64, device=dev)
     ids_d = torch.zeros(cap, dtype=torch.int32, device=dev)
     flags = K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY
+    summ = None if a.no_mask_summary else mask_summary(ctx, mask, int(chunk_off[-1]), dev)
 
     def step():
-        ctx.sketch_plan(packed, mask, chunk_off, off_d, ids_d, cap, flags, 1)
+        ctx.sketch_plan(packed, mask, chunk_off, off_d, ids_d, cap, flags, 1, d_summary=summ)
         for ph in (K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
             ctx.sketch_phase(ph, None)
     for attempt in range(8):                                       # sizes the workspaces
@@ -570,7 +572,7 @@ def run_mammal(a, dev, world, rank):
     t0 = time.perf_counter()
     for n in range(a.steps):
         if n == a.steps - 1:                                       # phase split of the last step (events on the stream the phases run on)
-            ctx.sketch_plan(packed, mask, chunk_off, off_d, ids_d, cap, flags, 1)
+            ctx.sketch_plan(packed, mask, chunk_off, off_d, ids_d, cap, flags, 1, d_summary=summ)
             for i, ph in enumerate((K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH)):
                 ev[i].record()
                 ctx.sketch_phase(ph, None)
@@ -716,6 +718,9 @@ def main():
     ap.add_argument("--clades", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
+    ap.add_argument("--no-mask-summary", action="store_true",
+                    help="A/B: the scan streams the whole validity mask (rounds 1-5) instead of reading the batch's summary words "
+                         "(one 64-bit word per chunk, written once when the batch is made resident) and the mask words of the lanes they name")
     ap.add_argument("--spinup", type=int, default=40, help="untimed steps before the warmup steps (GPU clock ramp; 0 = none)")
     ap.add_argument("--workload", choices=["allpairs", "fastq", "mammal"], default="allpairs",
                     help="allpairs = BASELINE configs[1] (the metric's config; configs[2] with --genomes 10000 --clades 500); "
@@ -882,6 +887,7 @@ def main():
         tstream = torch.cuda.current_stream()
         stream = tstream.cuda_stream
         st = {"unit": emu_unit if emu else cap, "idx_bound": cap, "search": None}
+        summ = None if a.no_mask_summary else mask_summary(ctx, mask, int(chunk_off[-1]), dev)   # part of the resident batch, like the mask itself
 
         def new_search():
             gather = EmulatedGather(W, R_, G, st["unit"], dev, ctx, emu_units) if emu else None
@@ -889,7 +895,7 @@ def main():
         new_search()
 
         def sketch():
-            ctx.sketch_plan(packed, mask, chunk_off, off_l, ids_l, cap, K.SKETCH_FASTA, 1)
+            ctx.sketch_plan(packed, mask, chunk_off, off_l, ids_l, cap, K.SKETCH_FASTA, 1, d_summary=summ)
             for ph in (K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
                 ctx.sketch_phase(ph, stream)
 
@@ -1072,6 +1078,7 @@ def main():
                    dist_only_t=dist_only_t, scan_ms=scan_ms, dist_ms=dist_ms, scan_t=scan_t, dist_t=dist_t, total=int(total), n_stage1=n_stage1,
                    n_bloom=n_bloom, exchange_us=exchange_us, unit=unit, checksum=checksum, index_ms=index_ms, rows_ms=rows_ms,
                    every=every, off=off_l.cpu().numpy(), ids=ids_l.cpu().numpy().view(np.uint32),
+                   mask_lanes=None if summ is None else summary_clear_lanes(summ, int(chunk_off[-1])),
                    block=shared.cpu().numpy().view(np.uint32).reshape(G, R) if emu else None,
                    planes=[p.cpu().numpy().view(np.int64) for p in planes] if (emu and not a.no_planes and G * R <= 16_000_000) else None)
         ctx.close()
@@ -1104,6 +1111,11 @@ def main():
         n_bases = G * L
         scan_bytes = 0.375 * n_bases + 4.0 * total        # 2-bit base + 1-bit mask, 4 B per id
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        # what the scan really asks the memory for (beside `traffic`, the counters' figure): with the batch's summary words the mask
+        # stream shrinks to 8 B per chunk + the two words of every lane that holds a run-breaking position; `achieved` and `frac`
+        # stay on SURVEY 8d's 0.375 B/base either way (they are a rate in the survey's unit, not a count of requests)
+        n_chunks_b = int(chunk_off[-1])
+        moved = (0.375 * n_chunks_b * 4096 if m["mask_lanes"] is None else 0.25 * n_chunks_b * 4096 + 8.0 * n_chunks_b + 8.0 * m["mask_lanes"]) + 4.0 * total
         pairs = G * R
         dist_bytes = (4 if a.no_planes else 36) * pairs + 4.0 * (total + R / G * total)
         spread = lambda t: {"min_ms": float(t.min()), "max_ms": float(t.max())} if len(t) else {}
@@ -1125,8 +1137,11 @@ def main():
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
-                                   "L3K10 sketch + all-pairs" % (G, L / 1e6, a.clades),
+            "config": {"workload": "BASELINE %s: %d synthetic %.1f Mb bacterial genomes per GPU (%d clades), "
+                                   "L3K10 sketch + all-pairs" % (
+                                       "configs[1]" if (G, L) == (1000, 5_000_000) else
+                                       "configs[2] (the 500-clade generator stands in for GTDB r207: no data set on the box)" if G * world == 10000 else
+                                       "configs[1]'s generator at another size", G, L / 1e6, a.clades),
                        "k": 10, "subk": 6, "drlevel": 3, "genomes_per_gpu": G, "genome_len": L,
                        "pairs_per_step": world * pairs,
                        "parallelism": par},
@@ -1147,6 +1162,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
+                         "bytes_moved": moved, "bytes_moved_what": (
+                             "requested per launch: packed bases 0.25 B/position incl. padding + 8 B of summary per chunk + 8 B of mask for "
+                             "each of the %d lanes (of %d) whose 64 positions are not all bases + 4 B per id" % (m["mask_lanes"], n_chunks_b * 64)
+                             if m["mask_lanes"] is not None else "requested per launch: the whole packed and mask streams incl. padding + 4 B per id (--no-mask-summary)"),
                          "algorithmic_bytes_per_launch": scan_bytes, "launches_timed": len(m["scan_t"]), **spread(m["scan_t"])},
             # the distance half as its own quantity (BASELINE's metric names two rates): `pairs_per_s_dist` above is its
             # whole-job rate (index build + rows, `steps` timed passes), this is its dominant kernel against the same roofline:

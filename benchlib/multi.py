@@ -9,7 +9,7 @@ import torch
 
 import public_kssd_amd as K
 from benchlib.launch import log
-from benchlib.workloads import make_batch
+from benchlib.workloads import make_batch, mask_summary
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -35,6 +35,7 @@ def run_exchange_c(a, shuf, n_dev, reason=None):
         v.dev = torch.device("cuda", d)
         v.packed, v.mask, v.chunk_off, _ = make_batch(G, L, a.clades, 20260101 + 7919 * d, v.dev)
         v.ctx = K.GpuCtx(shuf, d)
+        v.summ = None if getattr(a, "no_mask_summary", False) else mask_summary(v.ctx, v.mask, int(v.chunk_off[-1]), v.dev)
         v.off_l = torch.zeros(G + 1, dtype=torch.int64, device=v.dev)
         v.ids_l = torch.zeros(cap, dtype=torch.int32, device=v.dev)
         v.roff = torch.zeros(R + 1, dtype=torch.int64, device=v.dev)
@@ -57,13 +58,13 @@ def run_exchange_c(a, shuf, n_dev, reason=None):
     def steps(n):
         for _ in range(n):
             for v in dv:
-                v.ctx.sketch_plan(v.packed, v.mask, v.chunk_off, v.off_l, v.ids_l, cap, K.SKETCH_FASTA, 1)
+                v.ctx.sketch_plan(v.packed, v.mask, v.chunk_off, v.off_l, v.ids_l, cap, K.SKETCH_FASTA, 1, d_summary=v.summ)
                 for ph in (K.PHASE_PREP, K.PHASE_SCAN, K.PHASE_EXACT, K.PHASE_FINISH):
                     v.ctx.sketch_phase(ph, v.stream)
             K.GpuCtx.allgather_sketches([v.ctx for v in dv], [v.off_l for v in dv], [v.ids_l for v in dv], G, unit[0],
                                         [v.roff for v in dv], [v.rids for v in dv], streams=[v.stream for v in dv])
             for v in dv:
-                v.ctx.index_build_device(v.roff, v.rids, R, bound[0] * n_dev, v.stream)
+                v.ctx.index_build_device(v.roff, v.rids, R, bound[0] * n_dev, v.stream, check=False)  # (no status read-back inside the loop: the devices must not wait for one another on the host)
                 v.ctx.dist_device(v.off_l, v.ids_l, G, 0, G, v.shared, *v.planes, stream=v.stream)
 
     for attempt in range(6):          # sizing passes (workspaces, overflow retries), untimed

@@ -52,6 +52,21 @@ def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0, on_genome=N
     return packed, mask, chunk_off, kept
 
 
+def mask_summary(ctx, mask, n_chunks, dev):
+    """the batch's summary words (include/kssd_gpu.h: one 64-bit word per chunk, bit l = lane l's 64 positions are all bases), written
+    by the library's own kernel when the batch is made resident -- untimed setup like the packing itself; returns (tensor, lanes
+    whose bit is clear = whose 8 bytes of mask the scan still fetches)"""
+    summ = torch.zeros(max(n_chunks, 1), dtype=torch.int64, device=dev)
+    ctx.mask_summarise_device(mask, n_chunks, summ)
+    torch.cuda.synchronize()
+    return summ
+
+
+def summary_clear_lanes(summ, n_chunks):
+    h = summ[:n_chunks].cpu().numpy().view(np.uint8)
+    return int(n_chunks) * 64 - int(np.unpackbits(h).sum())
+
+
 def make_reads_batch(src_codes, n_reads, seed, dev, err=0.005, keep_reads=0, slice_reads=1 << 21):
     """packed / mask / chunk_off of n_reads x 150 bp drawn from the device code tensors `src_codes` (equally long),
     either strand, substitution errors at rate err; the codes of the first keep_reads reads come back as a host array"""

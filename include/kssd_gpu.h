@@ -129,6 +129,20 @@ int kssd_gpu_sketch_plan(kssd_gpu_ctx *ctx, const uint32_t *d_packed, const uint
 int kssd_gpu_sketch_phase(kssd_gpu_ctx *ctx, int phase, void *stream);
 
 /*
+ * The summary level above the validity mask (part of the packed batch layout since round 6; optional): one 64-bit word per
+ * chunk, bit l = "the 64 positions [64 l, 64 l + 64) of the chunk are all bases" -- i.e. the reference's run counter
+ * (`base`, iseq2comem.c:213-243) is never reset inside them.  With it the scan reads 8 bytes per chunk instead of the chunk's
+ * 512 bytes of mask and fetches the two mask words of the lanes whose bit is clear only (a lane with an N, a genome's last
+ * lanes, its padding).  Results are identical with and without.
+ *   kssd_gpu_mask_summarise_device  writes d_summary[n_chunks] (DEVICE) from d_mask on `stream`: what whoever makes a batch
+ *                                   resident calls once (the device tokeniser's callers get it with the mask);
+ *   kssd_gpu_sketch_set_mask_summary  names the summary of the d_mask of the NEXT kssd_gpu_sketch_plan / _sketch_device call
+ *                                   of this context (that one call only; NULL / nothing set: the scan streams the mask).
+ */
+int kssd_gpu_mask_summarise_device(kssd_gpu_ctx *ctx, const uint32_t *d_mask, uint64_t n_chunks, uint64_t *d_summary, void *stream);
+int kssd_gpu_sketch_set_mask_summary(kssd_gpu_ctx *ctx, const uint64_t *d_summary);
+
+/*
  * Synchronises `stream` and reports on the last kssd_gpu_sketch_device call:
  *   *total_ids  = ids the batch produced (valid even on KSSD_ERR_OVERFLOW: size to retry with)
  *   *bad_genome = first genome that raised KSSD_ERR_CAPACITY, else -1

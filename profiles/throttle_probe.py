@@ -39,7 +39,7 @@ try:
         return round(t1 - t0, 3), {k: c1[k] - c0[k] for k in c1 if k in ("usage_usec", "nr_throttled", "throttled_usec")}, {k: round(v, 3) for k, v in tm.items() if k in ("s_total", "s_context_create_max", "s_read_gunzip", "s_device_calls_summed")}
     run("fa", {})
     for src in ("fa", "gz"):
-        for env, p in (({}, 16), ({"KSSD_NO_REEXEC": "1"}, 16), ({"KSSD_DEV_SYNC_FLAGS": "4"}, 16), ({"KSSD_DEV_SYNC_FLAGS": "2"}, 16), ({}, 16), ({"KSSD_NO_REEXEC": "1"}, 16)):
+        for env, p in (({}, 16), ({"OMP_WAIT_POLICY": "active"}, 16), ({"KSSD_DEV_SYNC_FLAGS": "4"}, 16), ({"KSSD_DEV_SYNC_FLAGS": "2"}, 16), ({}, 16), ({"OMP_WAIT_POLICY": "active"}, 16)):
             for _ in range(4):
                 print(src, env, "-p", p, *run(src, env, p), flush=True)
 finally:

@@ -49,7 +49,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_resident_create", "kssd_gpu_resident_destroy", "kssd_gpu_resident_put", "kssd_gpu_resident_put_host",
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
     "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times", "kssd_gpu_dist_counts_device", "kssd_gpu_transpose_metrics_device",
-    "kssd_gpu_host_register", "kssd_gpu_host_unregister",
+    "kssd_gpu_host_register", "kssd_gpu_host_unregister", "kssd_gpu_mask_summarise_device", "kssd_gpu_sketch_set_mask_summary",
 ]
 
 
@@ -174,6 +174,8 @@ def gpu_lib():
         L.kssd_gpu_sketch_batch_pos.argtypes = [vp, vp, vp, vp, u32, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                 C.POINTER(C.c_int64)]
         L.kssd_gpu_sketch_set_pos_output.argtypes = [vp, vp]
+        L.kssd_gpu_mask_summarise_device.argtypes = [vp, vp, u64, vp, vp]
+        L.kssd_gpu_sketch_set_mask_summary.argtypes = [vp, vp]
         L.kssd_gpu_set_union.argtypes = [vp, vp, u64, C.c_int, C.POINTER(vp), C.POINTER(u64)]
         L.kssd_gpu_set_filter.argtypes = [vp, vp, vp, u32, vp, u64, C.c_int, C.POINTER(vp), C.POINTER(vp)]
         L.kssd_gpu_free.argtypes = [vp]
@@ -800,15 +802,24 @@ class GpuCtx:
 
     # device-level (torch tensors or raw addresses; nothing is synchronised) ------------------------------
     def sketch_device(self, d_packed, d_mask, chunk_off, d_out_off, d_out_ids, out_cap, flags=SKETCH_FASTA,
-                      min_occ=1, stream=None):
+                      min_occ=1, stream=None, d_summary=None):
         chunk_off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        if d_summary is not None:
+            _gck(gpu_lib().kssd_gpu_sketch_set_mask_summary(self.h, _ptr(d_summary)))
         _gck(gpu_lib().kssd_gpu_sketch_device(self.h, _ptr(d_packed), _ptr(d_mask), chunk_off.ctypes.data,
                                               len(chunk_off) - 1, flags, min_occ, _ptr(d_out_off), _ptr(d_out_ids),
                                               out_cap, stream))
 
-    def sketch_plan(self, d_packed, d_mask, chunk_off, d_out_off, d_out_ids, out_cap, flags=SKETCH_FASTA, min_occ=1):
-        """host part of sketch_device; the phases follow with sketch_phase (PHASE_PREP .. PHASE_FINISH, one stream)"""
+    def mask_summarise_device(self, d_mask, n_chunks, d_summary, stream=None):
+        """d_summary[n_chunks] (u64, device) from d_mask: bit l of word c = the 64 positions of lane l of chunk c are all bases"""
+        _gck(gpu_lib().kssd_gpu_mask_summarise_device(self.h, _ptr(d_mask), n_chunks, _ptr(d_summary), stream))
+
+    def sketch_plan(self, d_packed, d_mask, chunk_off, d_out_off, d_out_ids, out_cap, flags=SKETCH_FASTA, min_occ=1, d_summary=None):
+        """host part of sketch_device; the phases follow with sketch_phase (PHASE_PREP .. PHASE_FINISH, one stream).
+        d_summary: the mask's summary words (mask_summarise_device) -- the scan then does not stream the mask"""
         chunk_off = np.ascontiguousarray(chunk_off, dtype=np.uint64)
+        if d_summary is not None:
+            _gck(gpu_lib().kssd_gpu_sketch_set_mask_summary(self.h, _ptr(d_summary)))
         _gck(gpu_lib().kssd_gpu_sketch_plan(self.h, _ptr(d_packed), _ptr(d_mask), chunk_off.ctypes.data,
                                             len(chunk_off) - 1, flags, min_occ, _ptr(d_out_off), _ptr(d_out_ids), out_cap))
 

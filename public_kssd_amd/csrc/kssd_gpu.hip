@@ -101,6 +101,11 @@ struct kssd_gpu_ctx {
     uint32_t *d_regions;    // staging regions: u32 tuples, or u64 (tuple << 32 | position) in first-position mode
     size_t cap_regions;
     uint32_t *d_out_pos;    // first-position output of the next KSSD_SKETCH_FIRST_POS call (caller's buffer)
+    const uint64_t *d_next_summ = nullptr;  // the summary words of the NEXT planned batch's mask (kssd_gpu_sketch_set_mask_summary)
+    bool summ_auto = false;        // KSSD_MASK_SUMMARY=1: the host-level calls summarise their resident batch themselves (tests, fuzzers: the
+                                   // summary costs a pass over the mask, which a batch that is scanned once does not earn back)
+    uint64_t *d_in_summ = nullptr; // ... into this
+    size_t cap_in_summ = 0;
     uint64_t *d_cand;       // candidate list of the last scan (one slice per scan wave)
     size_t cap_cand;
     uint32_t *d_cand_count;
@@ -128,6 +133,7 @@ struct kssd_gpu_ctx {
     struct {
         bool valid;
         const uint32_t *d_packed, *d_mask;
+        const uint64_t *d_summ;  // the mask's summary words, or NULL (kssd_gpu_sketch_set_mask_summary)
         uint32_t n_genomes, flags, min_occ, big_min, n_slices;
         bool with_pos;
         uint64_t n_chunks, max_cap, max_big, cand_cap, out_cap;
@@ -270,6 +276,10 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
         return KSSD_ERR_NOMEM;
     }
     c->ev_every[0] = c->ev_every[1] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
+    {
+        const char *e = getenv("KSSD_MASK_SUMMARY");
+        c->summ_auto = e && *e && *e != '0';
+    }
     *out = c;
     return KSSD_OK;
 }
@@ -312,6 +322,10 @@ extern "C" int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int dev
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) { delete c; return KSSD_ERR_NOMEM; }
     c->ev_every[0] = c->ev_every[1] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
+    {
+        const char *e = getenv("KSSD_MASK_SUMMARY");
+        c->summ_auto = e && *e && *e != '0';
+    }
     *out = c;
     return KSSD_OK;
 }
@@ -322,7 +336,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     hipSetDevice(c->device);
     void *ptrs[] = {c->d_T1, c->d_G, c->d_chunk_gid, c->d_chunk_off, c->d_reg_off, c->d_cursor, c->d_kept,
                     c->d_regions, c->d_status, c->d_ref_sz, c->d_hkeys, c->d_post, c->d_cand, c->d_cand_count, c->d_blk_info, c->d_big_alt,
-                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag, c->d_lb};
+                    c->d_in_packed, c->d_in_mask, c->d_b_ids, c->d_b_pos, c->d_b_off, c->d_bkt, c->d_sel_cnt, c->d_sel_out, c->d_arrive, c->d_tok_tab, c->d_tok_pos, c->d_tok_sum, c->d_tok_state, c->d_text, c->d_filt, c->d_tok_sup, c->d_tok_q, c->d_x_off, c->d_x_ids, c->d_med, c->d_med_out, c->d_med_cnt, c->d_hdr_cnt, c->d_hdr_pre, c->d_hdr_out, c->d_idx_flag, c->d_lb, c->d_in_summ};
     for (void *p : ptrs)
         if (p) hipFree(p);
     free(c->tok_args_saved);
@@ -575,8 +589,13 @@ static bool kernel_timed(kssd_gpu_ctx *c, int which)
 template <int SUBK, int ABL = 0>
 static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
-    if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
-    else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
+    if (a.summ && ABL == 0) {  // the batch came with its summary words (kssd_gpu_sketch_set_mask_summary): the mask is not streamed
+        if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, 0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
+        else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, 0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
+    } else {
+        if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
+        else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
+    }
     HIPCK(hipGetLastError());
     return KSSD_OK;
 }
@@ -826,12 +845,33 @@ static int finish_sketch(kssd_gpu_ctx *c, uint32_t n_genomes, uint32_t flags, ui
 // kssd_gpu_sketch_device runs them back to back.  A caller that streams batches through several contexts puts its
 // own event waits between the phases, so that the LDS-free phases of one batch run underneath the scan of another
 // (bench.py); the results do not depend on how the phases are interleaved with other contexts' work.
+extern "C" int kssd_gpu_sketch_set_mask_summary(kssd_gpu_ctx *c, const uint64_t *d_summary)
+{
+    if (!c) return KSSD_ERR_PARAM;
+    c->d_next_summ = d_summary;
+    return KSSD_OK;
+}
+
+extern "C" int kssd_gpu_mask_summarise_device(kssd_gpu_ctx *c, const uint32_t *d_mask, uint64_t n_chunks, uint64_t *d_summary, void *stream)
+{
+    if (!c || !d_mask || !d_summary) return KSSD_ERR_PARAM;
+    if (n_chunks == 0) return KSSD_OK;
+    if (n_chunks > 0xFFFFFFFFull * 4) return KSSD_ERR_PARAM;
+    HIPCK(hipSetDevice(c->device));
+    hipLaunchKernelGGL(mask_summarise_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_mask,
+                       (unsigned long long)n_chunks, reinterpret_cast<unsigned long long *>(d_summary));
+    HIPCK(hipGetLastError());
+    return KSSD_OK;
+}
+
 extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask,
                                     const uint64_t *h_chunk_off, uint32_t n_genomes, uint32_t flags, uint32_t min_occ,
                                     uint64_t *d_out_off, uint32_t *d_out_ids, uint64_t out_cap)
 {
     if (!c) return KSSD_ERR_PARAM;
     c->plan.valid = false;
+    c->plan.d_summ = c->d_next_summ;  // (one plan's: a summary of another mask would be wrong bits, not a slower scan)
+    c->d_next_summ = nullptr;
     if (d_packed != c->d_in_packed) c->resident_valid = false;
     if (c->dist_only || !h_chunk_off || !d_out_off || (!d_out_ids && out_cap)) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
@@ -1034,6 +1074,7 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     int rc;
     ScanArgs a;
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
+    a.summ = reinterpret_cast<const uint32_t *>(pl.d_summ);
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.rec8 = (c->h_big.empty() && c->h_med.empty()) ? 1u : 0u;  // (= scanned.fused below: the FINISH phase evaluates the candidates itself)
     a.stage1_count = c->d_cand_count + pl.n_slices;
@@ -1290,7 +1331,12 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     uint64_t out_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * rate * 1.5) + 1024;
     uint64_t total = 0;
+    if (c->summ_auto && n_chunks) {
+        if ((rc = ensure(&c->d_in_summ, &c->cap_in_summ, (size_t)n_chunks)) != KSSD_OK) return rc;
+        if ((rc = kssd_gpu_mask_summarise_device(c, c->d_in_mask, n_chunks, c->d_in_summ, s)) != KSSD_OK) return rc;
+    }
     for (int attempt = 0; attempt < 12; attempt++) {
+        if (c->summ_auto && n_chunks) c->d_next_summ = c->d_in_summ;
         if ((rc = ensure(&c->d_b_ids, &c->cap_b_ids, (size_t)out_cap)) != KSSD_OK) break;
         if (out_pos) {
             if ((rc = ensure(&c->d_b_pos, &c->cap_b_pos, (size_t)out_cap)) != KSSD_OK) break;

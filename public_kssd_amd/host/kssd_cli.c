@@ -378,43 +378,20 @@ static int cmd_dist(int argc, char **argv)
     return 0;
 }
 
-/* A profiler's tool library may have started the GPU runtime before main(): such a process must not be replaced by another (the
- * rule of the GPU hosts this runs on), so it keeps the environment it came with.  Told by the profilers' own variables and by
- * their libraries' names in LD_PRELOAD (another preloaded library -- a sanitizer, a guard -- starts nothing). */
-extern char **environ;
-static int tooling_preloaded(void)
-{
-    for (char **e = environ; e && *e; e++) {
-        if (!strncmp(*e, "ROCP", 4) || !strncmp(*e, "HSA_TOOLS", 9)) return 1;
-        if (!strncmp(*e, "LD_PRELOAD=", 11) && (strstr(*e, "rocprof") || strstr(*e, "roctracer") || strstr(*e, "rocprofiler") || strstr(*e, "omnitrace") || strstr(*e, "rocsys")))
-            return 1;
-    }
-    return 0;
-}
-
 int main(int argc, char **argv)
 {
     setvbuf(stdout, NULL, _IOLBF, 0);
     struct timespec t_main;
     clock_gettime(CLOCK_REALTIME, &t_main);
     /* The host threads of this command wait for one another every few milliseconds (a wave of files, a job's genomes), and libgomp's
-     * threads wait by spinning unless told otherwise BEFORE the library initialises: 16 readers + the device workers' teams then count as
-     * 20-odd running CPUs whatever they do, and under a CPU quota (a container's cpu.max) the whole command is stopped for the rest of
-     * every accounting period -- measured on the GPU box (16-CPU quota): 0.4-0.9 thread-seconds throttled per run, 4.6 s of CPU for 1.7 s
-     * of work (profiles/r05v_throttle_probe.txt).  libkssd_env.so's constructor has set the passive policy in front of libgomp's own
-     * (host/kssd_env.c) -- the thread limit it set with it is the proof.  Where the loader ran the two the other way round, the command
-     * starts itself again with the policy in its environment: once, first thing, before anything has touched a device, and never under
-     * a profiler (KSSD_NO_REEXEC=1: not at all). */
-    if (omp_get_thread_limit() != 1000003 && !getenv("KSSD_NO_REEXEC") && !tooling_preloaded()) { /* (the mark is there: nothing to do) */
-        const char *mark = getenv("OMP_THREAD_LIMIT");
-        const int late = mark && !strcmp(mark, "1000003");                              /* the constructor ran, but behind libgomp's */
-        const int absent = !late && !getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT"); /* ... or not at all (otherwise: the caller's own choice) */
-        if (late || absent) {
-            setenv("OMP_WAIT_POLICY", "passive", 0);
-            setenv("KSSD_NO_REEXEC", "1", 1);
-            execv("/proc/self/exe", argv); /* (no /proc, no permission: go on as we are) */
-        }
-    }
+     * threads wait by spinning unless told otherwise BEFORE the library initialises: under a CPU quota (a container's cpu.max) spinning
+     * teams get the whole command stopped for the rest of every accounting period (profiles/r05v_throttle_probe.txt).  libkssd_env.so's
+     * constructor has set the passive policy in front of libgomp's own (host/kssd_env.c) -- the thread limit it set with it is the
+     * proof.  Where the loader ran the two the other way round the command goes on as it is: spinning costs time, and a process that
+     * links the GPU runtime is never replaced by another (rounds 5's restart is gone); KSSD_TIMING says so. */
+    const char *mark = getenv("OMP_THREAD_LIMIT"); /* (set by the constructor, yet without effect: it ran behind libgomp's) */
+    if (getenv("KSSD_TIMING") && omp_get_thread_limit() != 1000003 && ((mark && !strcmp(mark, "1000003")) || (!getenv("OMP_WAIT_POLICY") && !getenv("GOMP_SPINCOUNT"))))
+        fprintf(stderr, "{\"kssd_timing\": \"wait_policy\", \"note\": \"libkssd_env.so was initialised behind libgomp: host threads spin; set OMP_WAIT_POLICY=passive\"}\n");
     if (argc < 2 || !strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) {
         printf("%s\n\nUsage: kssd <subcommand> [OPTION...] [arguments ...]\nSupported subcommands are:\n\n"
                "  shuffle\tshuffle/sampling k-mer substring space.\n\n  dist   \tsequences sketching and distance estimation.\n\n"

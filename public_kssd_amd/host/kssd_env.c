@@ -5,8 +5,8 @@
  * Spinning teams are what a container's CPU quota throttles: on the GPU hosts (16 CPUs) the command lost two accounting periods per
  * run to it.  The loader initialises the libraries of a program in the reverse of the order it loaded them
  * (dependencies first): the command line links this library BEHIND libgomp, so this constructor runs in front of libgomp's.  Whether
- * it did is checked in main() through a second variable whose effect can be asked for (the thread limit); where it did not, the
- * command falls back to starting itself again with the policy set (host/kssd_cli.c). */
+ * it did can be asked through a second variable whose effect is visible (the thread limit); where it did not, the command runs on
+ * with spinning teams and says so under KSSD_TIMING (host/kssd_cli.c) -- it is never restarted. */
 #include <stdlib.h>
 
 #define KSSD_ENV_THREAD_LIMIT "1000003" /* (a limit nobody reaches: the mark main() looks for with omp_get_thread_limit()) */

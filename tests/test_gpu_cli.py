@@ -359,7 +359,7 @@ def test_waves_of_gzipped_files_give_the_files_of_the_plain_inputs(tmp_path):
     want = sets("o_fa")
     assert len(want) == 21 and all(len(v) > 0 for v in want.values())
     for tag, env in (("pairs", {}), ("single", {"KSSD_GZ_ONE_AT_A_TIME": "1"}), ("zlib", {"KSSD_ZLIB_GUNZIP": "1"}), ("ahead1", {"KSSD_GZ_AHEAD": "1"}),
-                     ("as_we_are", {"KSSD_NO_REEXEC": "1"})):
+                     ("spinning", {"OMP_WAIT_POLICY": "active"})):
         run(["dist", "-p", 4, "-L", "L3K10.shuf", "-o", "o_" + tag, "gz"], d, env=env)
         got = sets("o_" + tag)
         assert sorted(got) == sorted(want), tag

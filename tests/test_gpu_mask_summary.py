@@ -1,0 +1,105 @@
+"""-m gpu: the summary level above the validity mask (include/kssd_gpu.h: kssd_gpu_mask_summarise_device,
+kssd_gpu_sketch_set_mask_summary).  With it the scan reads one 64-bit word per chunk and fetches the mask words of the lanes that
+hold a run-breaking position only; the sketches must not know the difference (iseq2comem.c:213-243: the run counter's resets are
+the same bits either way)."""
+import numpy as np
+import pytest
+
+import public_kssd_amd as K
+import test_gpu_sketch as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_summary_words_are_the_masks_all_ones_lanes(gpu_ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    for n_chunks in (1, 3, 4, 5, 257, 4099):
+        m = np.full(n_chunks * K.CHUNK_MASKW, 0xFFFFFFFF, dtype=np.uint32)
+        # holes: single bits, whole words, whole lanes, a chunk of nothing
+        for w in rng.integers(0, len(m), max(1, len(m) // 50)):
+            m[w] &= ~np.uint32(1 << int(rng.integers(0, 32)))
+        m[rng.integers(0, len(m), max(1, len(m) // 200))] = 0
+        if n_chunks > 4:
+            m[2 * K.CHUNK_MASKW:3 * K.CHUNK_MASKW] = 0
+        d_m = torch.from_numpy(m.view(np.int32)).to(dev)
+        d_s = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        gpu_ctx.mask_summarise_device(d_m, n_chunks, d_s)
+        torch.cuda.synchronize()
+        got = d_s.cpu().numpy().view(np.uint64)
+        lanes = (m.reshape(-1, 2) == 0xFFFFFFFF).all(axis=1).reshape(n_chunks, 64)
+        want = (lanes.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+        assert np.array_equal(got, want), n_chunks
+
+
+def test_device_level_sketch_with_and_without_the_summary(shuf_l3k10):
+    """the bench's own batch layout (N at 1e-4, genomes that end inside a chunk), sketched through the plan / phase calls: with the
+    summary words the CSR is bit for bit the one without, and scanning with a summary is a per-plan choice (the next plan streams the
+    mask again)"""
+    import sys, os, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from benchlib.workloads import make_batch
+    dev = torch.device("cuda", 0)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        for G, L in ((24, 300_001), (3, 1_234_567), (40, 20_000)):
+            packed, mask, chunk_off, _ = make_batch(G, L, 4, 77 + G, dev)
+            n_chunks = int(chunk_off[-1])
+            summ = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+            ctx.mask_summarise_device(mask, n_chunks, summ)
+            cap = int(G * L / 4096 * 1.5) + 4096
+            res = []
+            for use in (None, summ, None, summ):
+                off = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+                ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+                for attempt in range(8):
+                    ctx.sketch_device(packed, mask, chunk_off, off, ids, cap, d_summary=use)
+                    rc, total, bad = ctx.sketch_status()
+                    if rc == 0:
+                        break
+                    assert rc == K.capi.ERR_OVERFLOW, rc
+                else:
+                    raise AssertionError("sketch kept overflowing")
+                res.append((off.cpu().numpy().copy(), ids.cpu().numpy()[:int(total)].copy()))
+            assert len(res[0][1]) > G * L / 4096 * 0.8
+            for r in res[1:]:
+                assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1])
+    finally:
+        ctx.close()
+
+
+@pytest.fixture
+def summarising_ctx(shuf_l3k10, monkeypatch):
+    """a context whose host-level calls summarise their resident batch themselves (KSSD_MASK_SUMMARY=1 at creation): every sketch
+    call of the tests below scans with the summary words"""
+    monkeypatch.setenv("KSSD_MASK_SUMMARY", "1")
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    yield ctx
+    ctx.close()
+
+
+def test_the_oracle_suite_of_the_sketch_path_with_summaries(summarising_ctx, shuf_l3k10, monkeypatch):
+    """tests of tests/test_gpu_sketch.py and tests/test_gpu_tokenise.py once more, scanning with summary words: edge-case texts (N
+    runs, IUPAC, CRLF, records shorter than a k-mer, nine records in one file), clade genomes, FASTQ -n, tiny genomes that share
+    chunks' waves, chunks denser than the candidate buffer -- all against the oracle"""
+    c = summarising_ctx
+    S.test_clade_genomes_l3k10(c, shuf_l3k10)
+    S.test_edge_cases_l3k10(c, shuf_l3k10)
+    S.test_uniq_mode(c, shuf_l3k10)
+    S.test_fastq_min_occ(c, shuf_l3k10)
+    S.test_many_tiny_genomes_share_waves_and_chunks(c, shuf_l3k10)
+    S.test_chunks_with_more_stage_one_candidates_than_the_buffer_holds(c, shuf_l3k10)
+    S.test_empty_batch_and_empty_genome(c, shuf_l3k10)
+
+
+@pytest.mark.parametrize("params", [(10, 6, 3), (11, 6, 3), (10, 7, 5), (8, 4, 1)])
+def test_lengths_around_chunk_and_block_borders_with_summaries(params, monkeypatch):
+    monkeypatch.setenv("KSSD_MASK_SUMMARY", "1")   # (the test makes its own contexts)
+    S.test_lengths_around_chunk_and_block_borders(params)
+
+
+def test_large_genome_paths_with_summaries(shuf_l3k10, monkeypatch):
+    monkeypatch.setenv("KSSD_MASK_SUMMARY", "1")
+    S.test_genomes_sorted_in_lds_in_parts(shuf_l3k10)
+    S.test_a_wave_that_owns_more_than_2048_chunks(shuf_l3k10)
