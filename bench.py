@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import public_kssd_amd as K  # noqa: E402
 from benchlib.launch import host_cores, log, self_launch  # noqa: E402
-from benchlib.workloads import READ_LEN, make_batch, make_long_records, make_reads_batch, mask_summary, summary_clear_lanes  # noqa: E402
+from benchlib.workloads import READ_LEN, FastaTextSink, make_batch, make_long_records, make_reads_batch, mask_summary, summary_clear_lanes  # noqa: E402
 from benchlib.multi import EmulatedGather, run_exchange_c  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -63,7 +63,7 @@ def _run_ours(args, cwd, env_extra=None, timeout=900):
     return dt, (None if not timing else timing[0] if len(timing) == 1 else {t["kssd_timing"]: t for t in timing})
 
 
-def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_search=1024, e2e_search4k=4096):
+def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_search=1024, e2e_search4k=4096, e2e_sketch_large=8192):
     """The CPU comparators and the end-to-end leg, on the same inputs in the same run:
       port       oracle/kssd_oracle.c (our restatement) sketching the sample texts, OpenMP over genomes
       reference  oracle/_ref/kssd (the real reference, when the snapshot carries it): stage I on FASTA files in tmpfs,
@@ -148,6 +148,41 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
                            "buffers on the host threads, raw text H2D, tokenised on the device, sketch kernels, D2H, slot order, "
                            "combco.* written -- wall time of the command, the better of two runs (HIP start-up varies by ~0.1 s from "
                            "process to process)", "sample": fa_desc, "stages": tm, "seconds_runs": runs}
+            # ---- the same command where start-up is amortised: stage I alone on 8 192 names hard-linked onto the distinct files ----
+            n_big = (e2e_sketch_large // n) * n if e2e_sketch_large >= 4 * nf else 0
+            if n_big:
+                os.mkdir(os.path.join(d, "fa_big"))
+                for r in range(n_big // n):
+                    for i in range(n):
+                        os.link(os.path.join(d, "fa", "r00_g%04d.fasta" % i), os.path.join(d, "fa_big", "h%03d_g%04d.fasta" % (r, i)))
+                dtb, tmb = _run_ours(["dist", "-p", cores, "-L", "L3K10.shuf", "-o", "our_sk_big", "fa_big"], d, {"KSSD_TIMING": "1"})
+                ob = ko.sketch_sets_by_name(os.path.join(d, "our_sk_big"))
+                for i in (0, n // 2, n - 1):
+                    for r in (0, n_big // n - 1):
+                        assert np.array_equal(ob["h%03d_g%04d.fasta" % (r, i)], gpu_sets[i]), "kssd CLI sketch (8 192-file leg) != device-level sketch"
+                shutil.rmtree(os.path.join(d, "our_sk_big"), ignore_errors=True)
+                shutil.rmtree(os.path.join(d, "fa_big"), ignore_errors=True)
+                st1 = tmb if (tmb and "s_total" in tmb) else None
+                big = {"value": n_big / dtb, "unit": "genomes/s", "mbase_per_s": nb / n * n_big / 1e6 / dtb, "seconds": dtb, "host_threads": cores, "stages": tmb,
+                       "what": "`kssd dist -L L3K10.shuf -o <dir> <fasta dir>`, stage I only, on %d names hard-linked onto the %d distinct files in tmpfs: "
+                               "the same command as `end_to_end` with process start, hipInit and the first context amortised; wall time of one run" % (n_big, n)}
+                if st1:
+                    jobs = max(1, int(st1["batches"]))
+                    startup = float(st1["s_context_create_max"]) + float(st1["s_before_workers"])
+                    steady = max(1e-9, float(st1["s_total"]) - startup - float(st1["s_assemble_write"]))
+                    per = {"wall_ms_per_job_steady": steady / jobs * 1e3,
+                           "h2d_floor_ms_per_job": float(st1["text_bytes"]) / jobs / 53e9 * 1e3,
+                           "reader_threads_ms_per_job": (float(st1["s_copy_threads_summed"]) + float(st1["s_unpack_threads_summed"])) / max(1, int(st1["host_threads"])) / jobs * 1e3,
+                           "device_calls_ms_per_job_per_worker": float(st1["s_device_calls_summed"]) / jobs / (2 * max(1, int(st1["gpus"]))) * 1e3}
+                    names = {"h2d_floor_ms_per_job": "PCIe (H2D of the raw text at ~53 GB/s)", "reader_threads_ms_per_job": "the readers (read(2) out of tmpfs into the jobs' texts, summed thread time / threads)",
+                             "device_calls_ms_per_job_per_worker": "the device calls (H2D + kernels + D2H as the two workers per device see them)"}
+                    top = max(names, key=lambda k_: per[k_])
+                    per["steady_genomes_per_s"] = n_big / steady
+                    per["bound"] = ("%s: %.2f ms of the %.2f ms a job takes in the steady state" % (names[top], per[top], per["wall_ms_per_job_steady"])
+                                    + ("" if per[top] > 0.7 * per["wall_ms_per_job_steady"] else
+                                       " -- none of the three parts fills the interval: the rest is hand-over between readers, workers and the device (waves of files per job)"))
+                    big["per_job"] = per
+                e2e["sketch_%d" % n_big] = big
             sk_s = "our_sk"
             dt_s = dt
             if sub:
@@ -524,6 +559,76 @@ def run_fastq(a, shuf, dev):
 # ------------------------------------------------------------------------------------------------------
 
 
+# ------------------------------------------------------------------------------------------------------
+# roofline_tok: what the product runs on the device in FRONT of the scan.  `kssd dist` uploads raw FASTA text and tokenises it on the
+# device (csrc/kssd_tok.inc: the byte rules of fasta2co, iseq2comem.c:213-242); the headline's batch is the packed form.  Here the
+# same genomes as resident FASTA text (header line, 70 columns, N's) go through kssd_gpu_tokenise_fasta_device, its two passes over
+# the text bracketed by their own HIP events like the scan, and the tokenised batch is sketched: the CSR must be the headline's.
+# Algorithmic bytes: 1.0 B per text byte in + 0.375 B per position out.
+# ------------------------------------------------------------------------------------------------------
+
+
+def tokeniser_leg(a, shuf, local, dev, sink, m):
+    G = len(sink.len)
+    ctx = K.GpuCtx(shuf, local)
+    tstream = torch.cuda.current_stream()
+    stream = tstream.cuda_stream
+    chunks = (sink.len + np.uint64(4095)) // np.uint64(4096)
+    tco = np.concatenate([[0], np.cumsum(chunks)]).astype(np.uint64)
+    n_chunks = int(tco[-1])
+    tp = torch.zeros(n_chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
+    tm = torch.zeros(n_chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
+    rc, bad, npos = ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream)      # (synchronises; also the warm-up)
+    if rc != 0:
+        raise SystemExit("tokeniser leg: rc=%d file %d" % (rc, bad))
+    text_bytes, positions = int(sink.len.sum()), int(npos.sum())
+    reps = max(3, min(10, a.steps))
+    ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, status=False)
+    torch.cuda.synchronize()
+    ctx.kernel_time(2, reset=True)
+    ctx.kernel_time(3, reset=True)
+    ctx.set_kernel_timing(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(tstream)
+    for _ in range(reps):
+        ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, status=False)
+    e1.record(tstream)
+    torch.cuda.synchronize()
+    call_ms = e0.elapsed_time(e1) / reps
+    t_sum, t_emit = ctx.kernel_times(2), ctx.kernel_times(3)
+    ctx.set_kernel_timing(0)
+    # the tokenised batch's sketches are the headline's (same genomes; the packed words differ where two N's meet: one invalid position)
+    cap = len(m["ids"])
+    off = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+    for attempt in range(6):
+        ctx.sketch_device(tp, tm, tco, off, ids, cap)
+        rc, total, _ = ctx.sketch_status()
+        if rc == 0:
+            break
+        assert rc == K.capi.ERR_OVERFLOW, rc
+    assert rc == 0 and int(total) == m["total"], (rc, total, m["total"])
+    assert np.array_equal(off.cpu().numpy().view(np.uint64), np.asarray(m["off"]).view(np.uint64)), "tokeniser leg: sketch sizes differ from the packed batch's"
+    assert np.array_equal(ids.cpu().numpy().view(np.uint32)[:int(total)], m["ids"][:int(total)]), "tokeniser leg: ids differ from the packed batch's"
+    ctx.close()
+    del tp, tm
+    torch.cuda.empty_cache()
+    kern_ms = float(t_sum.mean() + t_emit.mean())
+    alg = 1.0 * text_bytes + 0.375 * positions
+    ach = alg / (kern_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "tok_summarise_kernel<false> + tok_emit_kernel<false>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+            "bytes_moved": 2.0 * text_bytes + 0.375 * n_chunks * 4096 * 2,
+            "summarise_ms": float(t_sum.mean()), "emit_ms": float(t_emit.mean()), "launches_timed": [len(t_sum), len(t_emit)],
+            "call_ms": call_ms, "text_bytes": text_bytes, "positions": positions,
+            "text_GBs_whole_call": text_bytes / (call_ms * 1e-3) / 1e9,
+            "what": "the device ingests ASCII here (1.0 B per text byte + 0.375 B per position written), the headline's scan ingests the packed form "
+                    "(0.375 B/base); `kssd dist` runs this in front of every scan (a-3: iseq2comem.c:213-242).  achieved = algorithmic bytes / the two "
+                    "passes' summed launch durations (events of the dispatches themselves); call_ms = the whole call incl. the zeroing of the "
+                    "outputs and the three small composition kernels; bytes_moved: the text is read twice, the outputs zeroed and written.  "
+                    "The tokenised batch's sketches equal the packed batch's (checked)."}
+
+
 def run_mammal(a, dev, world, rank):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -718,6 +823,9 @@ def main():
     ap.add_argument("--clades", type=int, default=50)
     ap.add_argument("--cpu-sample", type=int, default=128, help="genomes of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-planes", action="store_true", help="shared counts only (4 B/pair instead of 36)")
+    ap.add_argument("--no-tok-leg", action="store_true",
+                    help="allpairs, one GPU: skip roofline_tok (the device tokeniser on the batch's genomes as resident FASTA text: what `kssd dist` "
+                         "runs on the device in front of the scan)")
     ap.add_argument("--no-mask-summary", action="store_true",
                     help="A/B: the scan streams the whole validity mask (rounds 1-5) instead of reading the batch's summary words "
                          "(one 64-bit word per chunk, written once when the batch is made resident) and the mask words of the lanes they name")
@@ -740,6 +848,7 @@ def main():
     ap.add_argument("--rank", type=int, default=0, help="--emulate-world: which rank this GPU plays")
     ap.add_argument("--e2e-files", type=int, default=1024, help="files of the end-to-end / reference leg (the CPU sample under several names)")
     ap.add_argument("--e2e-search", type=int, default=1024, help="sketches of the end-to-end search leg (all-pairs among the first N files)")
+    ap.add_argument("--e2e-sketch-large", type=int, default=8192, help="names of the stage-I leg where process start is amortised (hard links onto the sample's files; 0 = skip)")
     ap.add_argument("--e2e-search-large", type=int, default=4096, help="sketches of the second search leg, where start-up no longer dominates (0 = skip)")
     ap.add_argument("--reads", type=int, default=100_000_000, help="fastq workload: reads of 150 bp")
     ap.add_argument("--parity-reads", type=int, default=10_000_000, help="fastq workload: reads of the oracle slice (0 = skip)")
@@ -826,7 +935,9 @@ def main():
     W, R_ = (a.emulate_world, a.rank) if emu else (world, rank)
     t0 = time.time()
     n_keep = a.cpu_sample if (rank == 0 and W == 1) else 0
-    packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * R_, dev, keep_codes=min(n_keep, G))
+    tok_leg = rank == 0 and W == 1 and not a.no_tok_leg
+    sink = FastaTextSink(G, L, dev) if tok_leg else None
+    packed, mask, chunk_off, kept = make_batch(G, L, a.clades, 20260101 + 7919 * R_, dev, keep_codes=min(n_keep, G), on_genome=sink)
     torch.cuda.synchronize()
     if rank == 0:
         log("[bench] batch of %d x %.1f Mb packed on device in %.1f s" % (G, L / 1e6, time.time() - t0))
@@ -1106,6 +1217,7 @@ def main():
                 for x, y in zip(m["planes"], other["planes"]):
                     assert np.array_equal(x, y), "the two partitions compute different metric bits"
     dt, scan_ms, dist_ms, total = m["dt"], m["scan_ms"], m["dist_ms"], m["total"]
+    tok = tokeniser_leg(a, shuf, local, dev, sink, m) if tok_leg else None
 
     if rank == 0:
         n_bases = G * L
@@ -1178,6 +1290,8 @@ def main():
                               "algorithmic_bytes_per_launch": dist_bytes, "launch_ms": m["dist_only_ms"],
                               "launches_timed": m["dist_only_n"], **spread(m["dist_only_t"])},
         }
+        if tok is not None:
+            res["roofline_tok"] = tok
         if W > 1:
             res["backend"] = backend
             res["ranks_seen"] = world
@@ -1220,7 +1334,8 @@ def main():
             ol, il = m["off"], m["ids"]
             gpu_sets = [il[int(ol[g]):int(ol[g + 1])] for g in range(len(kept))]
             cores = host_cores()
-            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files, e2e_search=a.e2e_search, e2e_search4k=a.e2e_search_large)
+            cb = cpu_baseline(shuf, kept, cores, gpu_sets, a.e2e_files, e2e_search=a.e2e_search, e2e_search4k=a.e2e_search_large,
+                              e2e_sketch_large=a.e2e_sketch_large)
             res["cpu_baseline"] = cb.get("reference", cb["port"])
             res["cpu_baseline_port"] = cb["port"]
             res["cpu_baseline_dist"] = cb.get("dist_reference", cb["dist_port"])

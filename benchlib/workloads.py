@@ -52,6 +52,36 @@ def make_batch(n_genomes, length, n_clades, seed, dev, keep_codes=0, on_genome=N
     return packed, mask, chunk_off, kept
 
 
+class FastaTextSink:
+    """make_batch's genomes once more as FASTA TEXT on the device (a header line, 70 columns, 'N' where the generator put one): what
+    `kssd dist` uploads for the same genomes -- the input of the device tokeniser's leg.  File g sits at a multiple of 16 bytes."""
+
+    def __init__(self, n_genomes, length, dev, width=70):
+        self.width, self.dev = width, dev
+        rows = (length + width - 1) // width
+        self.per = ((32 + length + rows) + 15) // 16 * 16
+        self.text = torch.zeros(n_genomes * self.per + 64, dtype=torch.uint8, device=dev)
+        self.off = np.zeros(n_genomes, dtype=np.uint64)
+        self.len = np.zeros(n_genomes, dtype=np.uint64)
+        self.lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+
+    def __call__(self, gi, codes, nmask):
+        L, w = int(codes.numel()), self.width
+        ch = self.lut[codes.long()]
+        ch = torch.where(nmask, torch.full_like(ch, ord("N")), ch)
+        hdr = torch.tensor(list(b">g%d synthetic\n" % gi), dtype=torch.uint8, device=self.dev)
+        full = L // w
+        body = torch.cat([ch[:full * w].view(full, w), torch.full((full, 1), 10, dtype=torch.uint8, device=self.dev)], dim=1).reshape(-1)
+        parts = [hdr, body]
+        if L % w:
+            parts += [ch[full * w:], torch.tensor([10], dtype=torch.uint8, device=self.dev)]
+        t = torch.cat(parts)
+        at = gi * self.per
+        assert t.numel() <= self.per
+        self.text[at:at + t.numel()] = t
+        self.off[gi], self.len[gi] = at, t.numel()
+
+
 def mask_summary(ctx, mask, n_chunks, dev):
     """the batch's summary words (include/kssd_gpu.h: one 64-bit word per chunk, bit l = lane l's 64 positions are all bases), written
     by the library's own kernel when the batch is made resident -- untimed setup like the packing itself; returns (tensor, lanes

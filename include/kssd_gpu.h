@@ -513,7 +513,8 @@ int kssd_gpu_set_filter(kssd_gpu_ctx *ctx, const uint64_t *off, const uint32_t *
 
 /*
  * Timing hook for bench.py: every launch of the dominant kernel of a path is bracketed by HIP events on
- * the caller's stream (a ring of the last 128 launches).  which: 0 = sketch scan, 1 = distance rows.
+ * the caller's stream (a ring of the last 128 launches).  which: 0 = sketch scan, 1 = distance rows, 2 / 3 = the FASTA
+ * tokeniser's two passes over the text (tok_summarise, tok_emit).
  * Waits for the recorded events, returns their average in milliseconds and how many launches that covers;
  * reset != 0 empties the ring.
  */

@@ -745,14 +745,16 @@ class GpuCtx:
         res = (off, ids, pos) if with_pos else (off, ids)
         return res + (lines[:n],) if _fastq else res
 
-    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None, fastq=False):
+    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None, fastq=False, status=True):
         """device-level: raw FASTA (or FASTQ) bytes in HBM -> packed batch in HBM; returns (rc, bad_file, positions per
-        file[, lines per file])"""
+        file[, lines per file]); status=False: the kernels are enqueued and nothing is synchronised (returns None)"""
         to = np.ascontiguousarray(text_off, dtype=np.uint64)
         tl = np.ascontiguousarray(text_len, dtype=np.uint64)
         co = np.ascontiguousarray(chunk_off, dtype=np.uint64)
         fn = gpu_lib().kssd_gpu_tokenise_fastq_device if fastq else gpu_lib().kssd_gpu_tokenise_fasta_device
         _gck(fn(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed), _ptr(d_mask), co.ctypes.data, stream))
+        if not status:
+            return None
         bad = C.c_int64(-1)
         npos = np.zeros(max(len(tl), 1), dtype=np.uint64)
         if fastq:

@@ -64,6 +64,7 @@ extern "C" const char *kssd_gpu_strerror(int code)
 #define DEDUP_THREADS 512
 #define DEDUP_MAX_N 32768 // ids one workgroup can sort in LDS (128 KiB)
 #define EV_RING 128
+#define EV_KINDS 4  // 0 = sketch scan, 1 = distance rows, 2 = tok_summarise, 3 = tok_emit
 #define SCAN_TAB_BYTES (KSSD_T1_BYTES + KSSD_BLOOM_WORDS * 4)  // stage-1 table + stage-1.5 Bloom filter, contiguous
 #define SCAN_LDS_BYTES (SCAN_TAB_BYTES + SCAN_WAVES * CBUF * 4)
 
@@ -211,9 +212,9 @@ struct kssd_gpu_ctx {
     size_t cap_pairs;
     size_t cap_ref;
     // timing: ring of HIP event pairs around the dominant kernel of each path (0 = sketch scan, 1 = dist rows)
-    hipEvent_t ev_a[2][EV_RING], ev_b[2][EV_RING];
-    unsigned ev_n[2];
-    unsigned ev_every[2], ev_launch[2];  // every ev_every-th launch is bracketed (0: none), counted by ev_launch (kssd_gpu_set_kernel_timing)
+    hipEvent_t ev_a[EV_KINDS][EV_RING], ev_b[EV_KINDS][EV_RING];
+    unsigned ev_n[EV_KINDS];
+    unsigned ev_every[EV_KINDS], ev_launch[EV_KINDS];  // every ev_every-th launch is bracketed (0: none), counted by ev_launch (kssd_gpu_set_kernel_timing)
 };
 
 static int ctx_upload_tables(kssd_gpu_ctx *c, const std::vector<uint32_t> &accepted)
@@ -275,7 +276,7 @@ static int ctx_new(kssd_gpu_ctx **out, const kssd_shuf_hdr *hdr, std::vector<uin
         delete c;
         return KSSD_ERR_NOMEM;
     }
-    c->ev_every[0] = c->ev_every[1] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
+    for (int w = 0; w < EV_KINDS; w++) c->ev_every[w] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
     {
         const char *e = getenv("KSSD_MASK_SUMMARY");
         c->summ_auto = e && *e && *e != '0';
@@ -321,7 +322,7 @@ extern "C" int kssd_gpu_create_for_dist(kssd_gpu_ctx **out, int kmerlen, int dev
     c->dist_only = true;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return KSSD_ERR_HIP; }
     if (hipMalloc(&c->d_status, sizeof(SketchStatus)) != hipSuccess) { delete c; return KSSD_ERR_NOMEM; }
-    c->ev_every[0] = c->ev_every[1] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
+    for (int w = 0; w < EV_KINDS; w++) c->ev_every[w] = 1;  // (the events themselves are made by the first launch that needs one: kernel_timed)
     {
         const char *e = getenv("KSSD_MASK_SUMMARY");
         c->summ_auto = e && *e && *e != '0';
@@ -343,7 +344,7 @@ extern "C" void kssd_gpu_destroy(kssd_gpu_ctx *c)
     for (hipEvent_t e : c->text_ev)
         if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < EV_KINDS; w++)
         for (int i = 0; i < EV_RING; i++) {
             if (c->ev_a[w][i]) hipEventDestroy(c->ev_a[w][i]);
             if (c->ev_b[w][i]) hipEventDestroy(c->ev_b[w][i]);
@@ -1470,14 +1471,13 @@ extern "C" int kssd_gpu_sketch_batch_pos(kssd_gpu_ctx *c, const uint32_t *packed
 extern "C" int kssd_gpu_set_kernel_timing(kssd_gpu_ctx *c, uint32_t every)
 {
     if (!c) return KSSD_ERR_PARAM;
-    c->ev_every[0] = c->ev_every[1] = every;
-    c->ev_launch[0] = c->ev_launch[1] = 0;
+    for (int w = 0; w < EV_KINDS; w++) { c->ev_every[w] = every; c->ev_launch[w] = 0; }
     return KSSD_OK;
 }
 
 extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float *avg_ms, uint32_t *launches)
 {
-    if (!c || which < 0 || which > 1) return KSSD_ERR_PARAM;
+    if (!c || which < 0 || which >= EV_KINDS) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     const unsigned n = c->ev_n[which] < EV_RING ? c->ev_n[which] : EV_RING;
     double sum = 0;
@@ -1497,7 +1497,7 @@ extern "C" int kssd_gpu_kernel_time(kssd_gpu_ctx *c, int which, int reset, float
 // prints beside the mean
 extern "C" int kssd_gpu_kernel_times(kssd_gpu_ctx *c, int which, float *ms, uint32_t cap, uint32_t *launches)
 {
-    if (!c || which < 0 || which > 1 || (!ms && cap)) return KSSD_ERR_PARAM;
+    if (!c || which < 0 || which >= EV_KINDS || (!ms && cap)) return KSSD_ERR_PARAM;
     HIPCK(hipSetDevice(c->device));
     const unsigned n = c->ev_n[which] < EV_RING ? c->ev_n[which] : EV_RING;
     for (unsigned i = 0; i < n && i < cap; i++) {
