@@ -162,7 +162,7 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
                         assert np.array_equal(ob["h%03d_g%04d.fasta" % (r, i)], gpu_sets[i]), "kssd CLI sketch (8 192-file leg) != device-level sketch"
                 shutil.rmtree(os.path.join(d, "our_sk_big"), ignore_errors=True)
                 shutil.rmtree(os.path.join(d, "fa_big"), ignore_errors=True)
-                st1 = tmb if (tmb and "s_total" in tmb) else None
+                st1 = (tmb if "s_total" in tmb else tmb.get("stage1")) if tmb else None   # (one timing line, or several keyed by their names)
                 big = {"value": n_big / dtb, "unit": "genomes/s", "mbase_per_s": nb / n * n_big / 1e6 / dtb, "seconds": dtb, "host_threads": cores, "stages": tmb,
                        "what": "`kssd dist -L L3K10.shuf -o <dir> <fasta dir>`, stage I only, on %d names hard-linked onto the %d distinct files in tmpfs: "
                                "the same command as `end_to_end` with process start, hipInit and the first context amortised; wall time of one run" % (n_big, n)}

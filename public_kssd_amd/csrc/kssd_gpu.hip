@@ -1147,6 +1147,7 @@ static int phase_exact(kssd_gpu_ctx *c, hipStream_t s)
     if (c->h_big.empty() && c->h_med.empty()) return KSSD_OK;  // the FINISH phase evaluates the candidates itself (sketch_dedup_kernel<K, DEDUP_FUSED>)
     ExactArgs x;
     x.packed = pl.d_packed; x.mask = pl.d_mask; x.chunk_gid = c->d_chunk_gid;
+    x.summ = reinterpret_cast<const unsigned long long *>(pl.d_summ);
     x.chunk_off = (const unsigned long long *)c->d_chunk_off; x.G = c->d_G; x.gfilt = c->d_gfilt;
     x.cand = reinterpret_cast<const ulonglong2 *>(c->d_cand); x.cand_cap = pl.cand_cap; x.cand_count = c->d_cand_count;
     x.carry = kssd_carry_ok(c->P) ? 1u : 0u;

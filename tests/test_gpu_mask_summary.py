@@ -69,6 +69,45 @@ def test_device_level_sketch_with_and_without_the_summary(shuf_l3k10):
         ctx.close()
 
 
+def test_read_set_with_and_without_the_summary(shuf_l3k10):
+    """a read set is ONE genome of 150-base runs: no lane's neighbourhood is all bases, so the exact-evaluation kernel
+    (sketch_exact_kernel: batches with a large genome) settles every candidate's validity itself -- by the summary words where they
+    answer, by the mask where they do not; -n 1 and -n 2, ids bit for bit the ones without summary words (which
+    tests/test_gpu_configs.py holds against the oracle)"""
+    import sys, os, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from benchlib.workloads import make_batch, make_reads_batch
+    dev = torch.device("cuda", 0)
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        _, _, _, kept = make_batch(6, 400_000, 3, 5, dev, keep_codes=6, keep_on_device=True)
+        rp, rm, rco, _ = make_reads_batch([c for c, _ in kept], 300_000, 99, dev)
+        n_chunks = int(rco[-1])
+        summ = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        ctx.mask_summarise_device(rm, n_chunks, summ)
+        torch.cuda.synchronize()
+        lanes_all_valid = int(np.unpackbits(summ.cpu().numpy().view(np.uint8)).sum())
+        assert 0.4 < lanes_all_valid / (n_chunks * 64) < 0.7        # (a run of 150 bases, then a break: 64 / 151 of the lanes hold one)
+        cap = int(300_000 * 151 / 4096 * 1.5) + 4096
+        for min_occ in (1, 2):
+            res = []
+            for use in (None, summ):
+                off = torch.zeros(2, dtype=torch.int64, device=dev)
+                ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+                for attempt in range(8):
+                    ctx.sketch_device(rp, rm, rco, off, ids, cap, K.SKETCH_KEEP_ZERO | K.SKETCH_NO_CAPACITY, min_occ, d_summary=use)
+                    rc, total, bad = ctx.sketch_status()
+                    if rc == 0:
+                        break
+                    assert rc == K.capi.ERR_OVERFLOW, rc
+                else:
+                    raise AssertionError("sketch kept overflowing")
+                res.append(ids.cpu().numpy()[:int(total)].copy())
+            assert len(res[0]) > 1000 and np.array_equal(res[0], res[1]), min_occ
+    finally:
+        ctx.close()
+
+
 @pytest.fixture
 def summarising_ctx(shuf_l3k10, monkeypatch):
     """a context whose host-level calls summarise their resident batch themselves (KSSD_MASK_SUMMARY=1 at creation): every sketch
@@ -103,3 +142,4 @@ def test_large_genome_paths_with_summaries(shuf_l3k10, monkeypatch):
     monkeypatch.setenv("KSSD_MASK_SUMMARY", "1")
     S.test_genomes_sorted_in_lds_in_parts(shuf_l3k10)
     S.test_a_wave_that_owns_more_than_2048_chunks(shuf_l3k10)
+    S.test_large_genomes_sorted_by_ranges_of_their_keys()
