@@ -138,6 +138,8 @@ int kssd_gpu_sketch_phase(kssd_gpu_ctx *ctx, int phase, void *stream);
  *                                   resident calls once (the device tokeniser's callers get it with the mask);
  *   kssd_gpu_sketch_set_mask_summary  names the summary of the d_mask of the NEXT kssd_gpu_sketch_plan / _sketch_device call
  *                                   of this context (that one call only; NULL / nothing set: the scan streams the mask).
+ * A batch sketched with fastq2co semantics (KSSD_SKETCH_KEEP_ZERO: read sets, where four lanes in ten hold a read's end) is still
+ * scanned with the streamed mask; its exact-evaluation stage settles a candidate's validity by the summary words where they answer.
  */
 int kssd_gpu_mask_summarise_device(kssd_gpu_ctx *ctx, const uint32_t *d_mask, uint64_t n_chunks, uint64_t *d_summary, void *stream);
 int kssd_gpu_sketch_set_mask_summary(kssd_gpu_ctx *ctx, const uint64_t *d_summary);

@@ -1075,7 +1075,10 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     int rc;
     ScanArgs a;
     a.packed = pl.d_packed; a.mask = pl.d_mask; a.n_chunks = pl.n_chunks; a.tab = c->d_T1;
-    a.summ = reinterpret_cast<const uint32_t *>(pl.d_summ);
+    // (fastq2co semantics = a read set: four lanes in ten hold a read's end, their mask loads are issued in every chunk all the same and
+    // cost the scan more than the stream they replace -- 1.52 against 1.47 ms at configs[3], profiles/r06c_*; the exact-evaluation kernel
+    // asks the summary words either way)
+    a.summ = (pl.flags & KSSD_SKETCH_KEEP_ZERO) ? nullptr : reinterpret_cast<const uint32_t *>(pl.d_summ);
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.rec8 = (c->h_big.empty() && c->h_med.empty()) ? 1u : 0u;  // (= scanned.fused below: the FINISH phase evaluates the candidates itself)
     a.stage1_count = c->d_cand_count + pl.n_slices;

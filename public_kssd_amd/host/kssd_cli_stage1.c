@@ -727,7 +727,11 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     const int xwarming = o->allpairs && !o->fake_ranks && (n_dev > 1 || getenv("KSSD_EXCHANGE_ONE_RANK")) && pthread_create(&xwarm, NULL, warm_exchange, &xa) == 0;
     /* sketch workers per device (each with its own context and stream) and text buffers beyond one per worker: tuning knobs of the
      * pipeline, measured in profiles/r04I_e2e_workers_buffers.txt */
-    int wpd = 2, extra_bufs = 1;
+    /* (round 6, profiles/r06c_e2e_steady_probe.txt: once start-up is amortised -- 8 192 inputs, 512 jobs -- two workers leave the
+     * device's copy engine idle a third of the time: a worker's job is copy -> kernels -> results -> slot order on the host, and
+     * four of them keep a copy in flight: 5 150 -> 7 200 genomes/s in the steady state; a command of a thousand inputs is start-up
+     * for half of its time and keeps two) */
+    int wpd = fl->n >= 2048 ? 4 : 2, extra_bufs = 1;
     if (getenv("KSSD_WORKERS_PER_DEVICE")) wpd = atoi(getenv("KSSD_WORKERS_PER_DEVICE"));
     if (getenv("KSSD_TEXT_BUFFERS_EXTRA")) extra_bufs = atoi(getenv("KSSD_TEXT_BUFFERS_EXTRA"));
     if (wpd < 1) wpd = 1;
