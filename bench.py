@@ -613,19 +613,23 @@ def tokeniser_leg(a, shuf, local, dev, sink, m):
     ctx.close()
     del tp, tm
     torch.cuda.empty_cache()
-    kern_ms = float(t_sum.mean() + t_emit.mean())
+    one_pass = len(t_emit) == 0      # (round 6: FASTA goes through tok_onepass_kernel; KSSD_TOK_TWO_PASS=1 keeps the two passes of rounds 2 - 5)
+    kern_ms = float(t_sum.mean()) if one_pass else float(t_sum.mean() + t_emit.mean())
     alg = 1.0 * text_bytes + 0.375 * positions
     ach = alg / (kern_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "tok_summarise_kernel<false> + tok_emit_kernel<false>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": "tok_onepass_kernel" if one_pass else "tok_summarise_kernel<false> + tok_emit_kernel<false>", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
-            "bytes_moved": 2.0 * text_bytes + 0.375 * n_chunks * 4096 * 2,
-            "summarise_ms": float(t_sum.mean()), "emit_ms": float(t_emit.mean()), "launches_timed": [len(t_sum), len(t_emit)],
+            "bytes_moved": (1.0 if one_pass else 2.0) * text_bytes + 0.375 * n_chunks * 4096 * 2,
+            "kernel_ms": kern_ms, "min_ms": float(t_sum.min()) if one_pass else None, "max_ms": float(t_sum.max()) if one_pass else None,
+            "summarise_ms": None if one_pass else float(t_sum.mean()), "emit_ms": None if one_pass else float(t_emit.mean()),
+            "launches_timed": [len(t_sum), len(t_emit)],
             "call_ms": call_ms, "text_bytes": text_bytes, "positions": positions,
             "text_GBs_whole_call": text_bytes / (call_ms * 1e-3) / 1e9,
             "what": "the device ingests ASCII here (1.0 B per text byte + 0.375 B per position written), the headline's scan ingests the packed form "
-                    "(0.375 B/base); `kssd dist` runs this in front of every scan (a-3: iseq2comem.c:213-242).  achieved = algorithmic bytes / the two "
-                    "passes' summed launch durations (events of the dispatches themselves); call_ms = the whole call incl. the zeroing of the "
-                    "outputs and the three small composition kernels; bytes_moved: the text is read twice, the outputs zeroed and written.  "
+                    "(0.375 B/base); `kssd dist` runs this in front of every scan (a-3: iseq2comem.c:213-242).  achieved = algorithmic bytes / the "
+                    "tokenising kernel's launch duration (events of the dispatch itself; two passes: their sum); call_ms = the whole call incl. the "
+                    "zeroing of the outputs; bytes_moved: the text read (twice in two passes), the outputs zeroed and written.  "
                     "The tokenised batch's sketches equal the packed batch's (checked)."}
 
 

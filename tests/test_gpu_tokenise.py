@@ -35,6 +35,11 @@ def _cases():
         b"N" * 70 + b"\n" + rnd(100) + b"\n",                          # breaks BEFORE the first base: no leading invalid position
         b">" + b"A" * 5000 + b"\n" + rnd(20_000) + b"\n",              # bases inside a header are not bases
         bytes(rng.integers(0, 256, 60_000, dtype=np.uint8)).replace(b">", b"#") + b"\n",   # arbitrary bytes incl. >= 128
+        # files of many 16 KiB groups (the one-pass tokeniser's look-back walks more than its 64-group window): a header of 1.3 MB in
+        # the middle (eighty groups that emit nothing), a run of breaks of 1.1 MB, bases without a single line end
+        rnd(200_000) + b"\n>" + b"h" * 1_300_000 + b"\n" + rnd(150_000) + b"\n" + b"N" * 1_100_000 + rnd(40_000) + b"\n>last\n" + rnd(70_001),
+        rnd(2_500_000),
+        b">x\n" + (rnd(59) + b"\n") * 30_000 + b">y" + b" " * 16_383 + b"\n" + rnd(16_384) + b"n" + rnd(16_383) + b"\n",
     ]
 
 
