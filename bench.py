@@ -1140,10 +1140,12 @@ def main():
         dt_dist = float(tmax.item())
         n_stage1, n_bloom = ctx.scan_stats(stream)
 
+        dt_local = dt
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        ex_local = None
 
         if W > 1:
             # the exchange alone, untimed beside the steps: the two all-gathers (emulation: the copies of their bytes) + the
@@ -1158,10 +1160,21 @@ def main():
                 g(off_l, ids_l[:unit], stream=stream)
             e1.record(tstream)
             sync()
-            ex = torch.tensor([e0.elapsed_time(e1) * 1e3 / 20], dtype=torch.float64, device=dev)
+            ex_local = e0.elapsed_time(e1) * 1e3 / 20
+            ex = torch.tensor([ex_local], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(ex, op=dist.ReduceOp.MAX)
             exchange_us = float(ex.item())
+        per_rank = None
+        if world > 1:
+            # every rank's own figures side by side (the line's headline numbers are maxima over ranks): a measured scaling curve can be
+            # read term by term against the one-GPU emulation of the same rank (profiles/r05n_bench_emu*.json)
+            mine_v = torch.tensor([dt_local / a.steps * 1e3, scan_ms, index_ms, rows_ms, ex_local if ex_local is not None else 0.0, float(total)],
+                                  dtype=torch.float64, device=dev)
+            allv = torch.zeros(world * mine_v.numel(), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allv, mine_v)
+            per_rank = [{"rank": r, "step_ms": v[0], "sketch_scan_ms": v[1], "index_ms": v[2], "rows_ms": v[3], "exchange_us": v[4], "ids": int(v[5])}
+                        for r, v in enumerate(allv.view(world, -1).cpu().tolist())]
 
         szs = (off_l[1:] - off_l[:-1]).to(torch.int32)
         sh = shared.view(G, R)   # [this rank's genomes (its rows of the matrix)] x [all genomes], in either partition
@@ -1193,7 +1206,7 @@ def main():
                    dist_only_t=dist_only_t, scan_ms=scan_ms, dist_ms=dist_ms, scan_t=scan_t, dist_t=dist_t, total=int(total), n_stage1=n_stage1,
                    n_bloom=n_bloom, exchange_us=exchange_us, unit=unit, checksum=checksum, index_ms=index_ms, rows_ms=rows_ms,
                    every=every, off=off_l.cpu().numpy(), ids=ids_l.cpu().numpy().view(np.uint32),
-                   mask_lanes=None if summ is None else summary_clear_lanes(summ, int(chunk_off[-1])),
+                   mask_lanes=None if summ is None else summary_clear_lanes(summ, int(chunk_off[-1])), per_rank=per_rank,
                    block=shared.cpu().numpy().view(np.uint32).reshape(G, R) if emu else None,
                    planes=[p.cpu().numpy().view(np.int64) for p in planes] if (emu and not a.no_planes and G * R <= 16_000_000) else None)
         ctx.close()
@@ -1304,6 +1317,8 @@ def main():
                                         "two all_gather_into_tensor (offsets, padded id units) + the unpacking kernel") +
                                        ", alone on the step's stream, mean of 20, max over ranks"}
             res["matrix_checksum"] = m["checksum"]
+            if m["per_rank"] is not None:
+                res["per_rank"] = m["per_rank"]     # step / scan / exchange+unpack+index / rows / exchange alone, rank by rank (ms; exchange in us)
             if not emu:
                 res["runtime"] = {"hip": K.gpu_lib().kssd_gpu_runtime_path(0).decode(), "mapped": K.capi.runtime_paths(),
                                   "what": "the HIP runtime libkssd_gpu.so is bound to and every HIP / RCCL / HSA file mapped into rank 0 (one of each: "

@@ -68,8 +68,17 @@ def run_exchange_c(a, shuf, n_dev, reason=None):
                 v.ctx.dist_device(v.off_l, v.ids_l, G, 0, G, v.shared, *v.planes, stream=v.stream)
 
     for attempt in range(6):          # sizing passes (workspaces, overflow retries), untimed
-        steps(1)
-        sync_all()
+        try:
+            steps(1)
+            sync_all()
+        except K.KssdError as e:
+            # the first collective of the run: librccl.so, ncclCommInitAll over the device list, peer access, the grouped all-gathers.
+            # ONE line with the reason, a non-zero exit, nothing retried inside this process (a communicator that failed to come up
+            # is not torn down and built again under a timed run)
+            print(json.dumps({"error": "exchange failed", "where": "kssd_gpu_allgather_sketches (RCCL inside libkssd_gpu.so) on %d devices" % n_dev,
+                              "code": e.code, "reason": str(e)[:600], "hip": K.gpu_lib().kssd_gpu_last_hip_error().decode(errors="replace")[:300]}),
+                  file=__import__("sys").stderr, flush=True)
+            raise SystemExit(3)
         rcs = [v.ctx.sketch_status(v.stream) for v in dv]
         ircs = [v.ctx.index_status(v.stream) for v in dv]
         if all(r[0] == 0 for r in rcs) and all(i == 0 for i in ircs):
@@ -136,6 +145,7 @@ def run_exchange_c(a, shuf, n_dev, reason=None):
                                    "packed sketches; full index on every device, own query block as rows" % n_dev}},
         "spinup": a.spinup, "pairs_per_s": n_dev * G * R * a.steps / dt, "ids_per_batch": total,
         "kernels": {"sketch_scan_ms": scan_ms, "dist_rows_ms": rows_ms},
+        "per_rank": [{"rank": d, "device": d, "sketch_scan_ms": scan[d][0], "rows_ms": rows[d][0], "ids": int(dv[d].off_l[-1].item())} for d in range(n_dev)],
         "roofline": {"bound": "hbm", "kernel": "sketch_scan_kernel<6>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": scan_bytes},
         "exchange": {"kind": "c", "us": exchange_us, "unit_ids_per_rank": unit[0],

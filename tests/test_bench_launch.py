@@ -66,6 +66,12 @@ def test_two_ranks_share_one_device_over_gloo():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["parallelism"]["ranks"] == 2 and j["config"]["parallelism"]["backend"] == "gloo"
     assert j["kernels"]["launches_timed"][0] >= 1
+    # every rank's own terms side by side: what a measured scaling curve is read against (the one-GPU emulation prints the same terms)
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1]
+    for r in pr:
+        assert r["step_ms"] > 0 and r["sketch_scan_ms"] > 0 and r["index_ms"] > 0 and r["rows_ms"] > 0 and r["exchange_us"] > 0 and r["ids"] > 0
+    assert max(r["step_ms"] for r in pr) <= j["ms_per_step"] * 1.0001      # (the headline is the maximum over ranks)
 
 
 def test_bench_modules_name_nothing_undefined():
