@@ -79,7 +79,8 @@ def test_bench_modules_name_nothing_undefined():
     module (an import, a definition, an assignment) -- what a split of the file can break without any CPU test noticing"""
     import ast
     import builtins
-    for f in ("bench.py", os.path.join("benchlib", "workloads.py"), os.path.join("benchlib", "launch.py"), os.path.join("benchlib", "multi.py")):
+    for f in ("bench.py", os.path.join("benchlib", "workloads.py"), os.path.join("benchlib", "launch.py"), os.path.join("benchlib", "multi.py"),
+              os.path.join("benchlib", "legs.py")):
         tree = ast.parse(open(os.path.join(ROOT, f)).read())
         defined = set(dir(builtins)) | {"__file__", "__name__"}
         for n in ast.walk(tree):
