@@ -601,6 +601,9 @@ def main():
                     res["roofline"]["traffic_source"] = src
                     res["roofline_dist"]["traffic"] = pj.get("dist_rows_bytes_per_launch")
                     res["roofline_dist"]["traffic_source"] = src
+                    if "roofline_tok" in res:
+                        res["roofline_tok"]["traffic"] = pj.get("tok_bytes_per_launch")
+                        res["roofline_tok"]["traffic_source"] = src
                 else:
                     res["roofline"]["traffic_source"] = res["roofline_dist"]["traffic_source"] = (
                         "none: profiles/pmc_traffic.json was recorded on other kernel sources (%s, now %s): run profiles/pmc_refresh.py"

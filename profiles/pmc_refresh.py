@@ -23,7 +23,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-RX = "sketch_scan_kernel|sketch_dedup_kernel|sketch_gather_kernel|idx_|dist_rows_kernel|dist_metrics"
+RX = "sketch_scan_kernel|sketch_dedup_kernel|sketch_gather_kernel|idx_|dist_rows_kernel|dist_metrics|tok_onepass_kernel|tok_summarise_kernel|tok_emit_kernel|mask_summarise_kernel"
 
 
 def one_pass(tag, counter, out_dir):
@@ -80,10 +80,12 @@ def main():
            "sketch_scan_bytes_per_launch": total("sketch_scan_kernel"),
            # roofline_dist.traffic: what the rows kernel moves, reads AND writes (36 B per pair are writes)
            "dist_rows_bytes_per_launch": total("dist_rows_kernel"),
+           # roofline_tok.traffic: the device tokeniser on the batch's genomes as FASTA text (reads of the text + the packed batch written)
+           "tok_bytes_per_launch": total("tok_onepass_kernel"),
            "kernels": kernels}
     path = os.path.join(out_dir, "pmc_traffic.json")
     json.dump(res, open(path, "w"), indent=1)
-    print(json.dumps({k: res[k] for k in ("tag", "source_sha", "sketch_scan_bytes_per_launch", "dist_rows_bytes_per_launch")}))
+    print(json.dumps({k: res[k] for k in ("tag", "source_sha", "sketch_scan_bytes_per_launch", "dist_rows_bytes_per_launch", "tok_bytes_per_launch")}))
     for k, v in kernels.items():
         print("%-60s fetch x2 %10.0f KB   write %10.0f KB   (%d / %d dispatches)" % (k[:60], v["fetch_x2_bytes"] / 1024, v["write_bytes"] / 1024,
                                                                                     v["dispatches"][0], v["dispatches"][1]))
