@@ -78,6 +78,7 @@ struct SketchStatus {
     unsigned long long n_stage1, n_bloom;
     unsigned int cand_overflow;    // a shard of the candidate list was too small
     unsigned int cand_need;        // entries the fullest shard wanted
+    unsigned int lb_timeout;       // a workgroup of the per-genome kernel gave up waiting for the kept counts in front of it (kssd_dedup.inc: dedup_direct_out)
     unsigned int ranges_skew;      // a large genome's keys do not spread over its id ranges (one id tens of thousands of times, crafted
                                    // ids): the call is repeated with the global-memory sort for large genomes
 };
@@ -1275,6 +1276,12 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
                 st.cand_need, (unsigned long long)c->last_cand_cap, st.region_overflow, st.max_need_q8 / 256.0, c->region_factor,
                 st.out_overflow, st.capacity_genome_p1);
 #endif
+    if (st.lb_timeout) {
+        // the per-genome kernel's look-back relies on workgroups being dispatched in the order of their numbers; a workgroup that waited
+        // ~a second for a genome in front of it says so instead of hanging the launch
+        snprintf(g_hip_err, sizeof g_hip_err, "sketch_dedup_kernel: a workgroup's look-back timed out (workgroups not dispatched in order?)");
+        return KSSD_ERR_HIP;
+    }
     if (st.cand_overflow) {
         c->cand_floor = (uint64_t)st.cand_need + st.cand_need / 4 + 64;
         return KSSD_ERR_OVERFLOW;
