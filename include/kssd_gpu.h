@@ -321,9 +321,7 @@ int kssd_gpu_host_unregister(void *p);
  * accepted).  max_ref_ids is only an upper bound of d_roff[n_ref] -- the TOTAL number of reference ids; it sizes the
  * index's arrays -- so no host synchronisation is needed between sketching and indexing.  A bound that turns out too
  * small is not followed behind those arrays: the index then holds the first max_ref_ids entries and
- * kssd_gpu_index_status returns KSSD_ERR_PARAM.  d_rids must be READABLE for max_ref_ids entries (the bound of the array the ids
- * were sketched into: the build asks for its first ids while d_roff[n_ref] is still on its way, and drops what lies behind the real
- * total).  The index lives in ctx until the next call.
+ * kssd_gpu_index_status returns KSSD_ERR_PARAM.  The index lives in ctx until the next call.
  */
 int kssd_gpu_index_build_device(kssd_gpu_ctx *ctx, const uint64_t *d_roff, const uint32_t *d_rids,
                                 uint32_t n_ref, uint64_t max_ref_ids, void *stream);
