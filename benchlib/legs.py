@@ -378,6 +378,9 @@ def run_fastq(a, shuf, dev):
     # the reference index (untimed setup; `kssd dist -r` finds it prebuilt as mco.* too)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    # (the query is ONE row of a read set's ids, most of which are sequencing errors and miss the index: the negative filter in front of
+    # the table, as the host-level searches switch it on for such query sets -- csrc/kssd_dist.inc: dist_queries_miss_heavy)
+    ctx.index_set_filter(True, 0, 0)
     ctx.index_build_device(roff, rids, G, int(rtotal))
     e1.record()
     torch.cuda.synchronize()
