@@ -369,3 +369,33 @@ def test_waves_of_gzipped_files_give_the_files_of_the_plain_inputs(tmp_path):
     open(os.path.join(d, "gz", "s03.fasta.gz"), "wb").write(bytes(bad))
     r = subprocess.run([BIN, "dist", "-p", "4", "-L", "L3K10.shuf", "-o", "o_bad", "gz"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode != 0 and b"s03.fasta.gz" in r.stdout, r.stdout.decode()[-500:]
+
+
+def test_many_inputs_take_four_workers_per_device_and_leave_the_same_files(tmp_path):
+    """from 2 048 inputs on `kssd dist` runs four sketch workers per device (host/kssd_cli_stage1.c: the copy engine idles a third of
+    the time with two once start-up is amortised): 2 100 names hard-linked onto a dozen small files, the default against
+    KSSD_WORKERS_PER_DEVICE=1 -- combco.0, combco.index.0 and cofiles.stat byte for byte, and every name's sketch the oracle's"""
+    from synth import fasta_text
+    d = str(tmp_path)
+    rng = np.random.default_rng(2100)
+    shuf = K.Shuf.generate(10, 6, 3, seed=20260101)
+    shuf.write(os.path.join(d, "L3K10.shuf"))
+    os.mkdir(os.path.join(d, "src"))
+    os.mkdir(os.path.join(d, "fa"))
+    sk = ko.Sketcher(shuf.table, 10, 6, 3)
+    want = []
+    for i in range(12):
+        t = fasta_text(rng.integers(0, 4, int(rng.integers(20_000, 120_000)), dtype=np.uint8), b"g%d" % i)
+        open(os.path.join(d, "src", "g%02d.fasta" % i), "wb").write(t)
+        want.append(np.sort(sk.fasta(t)))
+    for r in range(175):
+        for i in range(12):
+            os.link(os.path.join(d, "src", "g%02d.fasta" % i), os.path.join(d, "fa", "h%03d_g%02d.fasta" % (r, i)))
+    run(["dist", "-p", 8, "-L", "L3K10.shuf", "-o", "o4", "fa"], d)
+    run(["dist", "-p", 8, "-L", "L3K10.shuf", "-o", "o1", "fa"], d, env={"KSSD_WORKERS_PER_DEVICE": "1"})
+    for fn in ("combco.0", "combco.index.0", "cofiles.stat"):
+        assert open(os.path.join(d, "o4", fn), "rb").read() == open(os.path.join(d, "o1", fn), "rb").read(), fn
+    sets = ko.sketch_sets_by_name(os.path.join(d, "o4"))
+    assert len(sets) == 2100
+    for nm, ids in sets.items():
+        assert np.array_equal(ids, want[int(nm[-8:-6])]), nm
