@@ -152,9 +152,10 @@ def cpu_baseline(shuf, kept, cores, gpu_sets, e2e_files, gz_distinct=128, e2e_se
                     per = {"wall_ms_per_job_steady": steady / jobs * 1e3,
                            "h2d_floor_ms_per_job": float(st1["text_bytes"]) / jobs / 53e9 * 1e3,
                            "reader_threads_ms_per_job": (float(st1["s_copy_threads_summed"]) + float(st1["s_unpack_threads_summed"])) / max(1, int(st1["host_threads"])) / jobs * 1e3,
-                           "device_calls_ms_per_job_per_worker": float(st1["s_device_calls_summed"]) / jobs / (2 * max(1, int(st1["gpus"]))) * 1e3}
+                           "device_calls_ms_per_job_per_worker": float(st1["s_device_calls_summed"]) / jobs / max(1, int(st1.get("workers", 2 * max(1, int(st1["gpus"]))))) * 1e3,
+                           "workers": int(st1.get("workers", 0))}
                     names = {"h2d_floor_ms_per_job": "PCIe (H2D of the raw text at ~53 GB/s)", "reader_threads_ms_per_job": "the readers (read(2) out of tmpfs into the jobs' texts, summed thread time / threads)",
-                             "device_calls_ms_per_job_per_worker": "the device calls (H2D + kernels + D2H as the two workers per device see them)"}
+                             "device_calls_ms_per_job_per_worker": "the device calls (H2D + kernels + D2H as the workers see them, summed / workers)"}
                     top = max(names, key=lambda k_: per[k_])
                     per["steady_genomes_per_s"] = n_big / steady
                     per["bound"] = ("%s: %.2f ms of the %.2f ms a job takes in the steady state" % (names[top], per[top], per["wall_ms_per_job_steady"])

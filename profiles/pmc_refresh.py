@@ -77,7 +77,10 @@ def main():
                                "lane: 2^30 bytes read, 524 300 KB reported).  The x 2 is applied to narrow gathers too: an upper bound there. "
                                "WRITE_SIZE needs none (dist_rows_kernel: 36.0 MB written algorithmically, 35 210 KB reported).",
            # what bench.py prints as roofline.traffic: reads x 2 + writes of the scan (its writes are the candidate records: ~2 %)
-           "sketch_scan_bytes_per_launch": total("sketch_scan_kernel"),
+           # (the headline's scan is the instantiation that reads the summary words, <SUBK, 0, 1>; the tokeniser's leg sketches once
+           # without them: <SUBK, 0, 0> -- summed together before round 6's closing pass noticed)
+           "sketch_scan_bytes_per_launch": total("sketch_scan_kernel<6, 0, 1>") if any("sketch_scan_kernel<6, 0, 1>" in k for k in kernels) else total("sketch_scan_kernel"),
+           "sketch_scan_streamed_mask_bytes_per_launch": total("sketch_scan_kernel<6, 0, 0>"),
            # roofline_dist.traffic: what the rows kernel moves, reads AND writes (36 B per pair are writes)
            "dist_rows_bytes_per_launch": total("dist_rows_kernel"),
            # roofline_tok.traffic: the device tokeniser on the batch's genomes as FASTA text (reads of the text + the packed batch written)

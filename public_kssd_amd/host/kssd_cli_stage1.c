@@ -1134,9 +1134,9 @@ void sketch_files(const dist_opt *o, filelist *fl, const char *outdir)
     free(s.sub);
     if (getenv("KSSD_TIMING")) /* machine-readable stage split (metrics / logging) */
         fprintf(stderr, "{\"kssd_timing\": \"stage1\", \"files\": %d, \"text_bytes\": %llu, \"ids\": %llu, \"batches\": %d, \"gpus\": %d, "
-                        "\"host_threads\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_unpack_threads_summed\": %.6f, \"s_copy_threads_summed\": %.6f, \"s_wait_text_buffer\": %.6f, \"s_tokenise\": %.6f, "
+                        "\"host_threads\": %d, \"workers\": %d, \"s_total\": %.6f, \"s_context_create_max\": %.6f, \"s_context_destroy_max\": %.6f, \"s_before_workers\": %.6f, \"s_shuf\": %.6f, \"shuf_core_cached\": %d, \"s_read_gunzip\": %.6f, \"s_unpack_threads_summed\": %.6f, \"s_copy_threads_summed\": %.6f, \"s_wait_text_buffer\": %.6f, \"s_tokenise\": %.6f, "
                         "\"s_workers_summed\": %.6f, \"s_device_calls_summed\": %.6f, \"s_assemble_write\": %.6f}\n",
-                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_shuf, sc.from_cache, t_read, t_unpack_thr, t_copy_thr, t_wait_text, t_tok,
+                fl->n, (unsigned long long)n_bytes, (unsigned long long)total, n_jobs, n_dev, threads, n_workers, now_s() - t_start, pl.t_ctx, pl.t_ctx_destroy, t_workers_started - t_start, t_shuf, sc.from_cache, t_read, t_unpack_thr, t_copy_thr, t_wait_text, t_tok,
                 pl.t_gpu, pl.t_call, t_written - t_sketched);
 }
 
