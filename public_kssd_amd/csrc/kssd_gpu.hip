@@ -594,9 +594,6 @@ static int launch_scan(kssd_gpu_ctx *c, const ScanArgs &a, int grid, hipStream_t
     if (a.summ && ABL == 0) {  // the batch came with its summary words (kssd_gpu_sketch_set_mask_summary): the mask is not streamed
         if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, 0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
         else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, 0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
-    } else if (a.vex_nb && ABL == 0) {  // a read set: every candidate's validity settled in the scan (kssd_scan.inc: VEX)
-        if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, 0, 0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
-        else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, 0, 0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
     } else {
         if (ev_start) hipExtLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, ev_start, ev_stop, 0, a);
         else hipLaunchKernelGGL((sketch_scan_kernel<SUBK, ABL>), dim3(grid), dim3(SCAN_THREADS), 0, s, a);
@@ -1083,14 +1080,6 @@ static int phase_scan(kssd_gpu_ctx *c, hipStream_t s)
     // cost the scan more than the stream they replace -- 1.52 against 1.47 ms at configs[3], profiles/r06c_*; the exact-evaluation kernel
     // asks the summary words either way)
     a.summ = (pl.flags & KSSD_SKETCH_KEEP_ZERO) ? nullptr : reinterpret_cast<const uint32_t *>(pl.d_summ);
-    {
-        // fastq2co semantics = reads: the scan settles the candidates' validity itself (VEX) where the k-mer is at least 16 and at most
-        // 32 bases and begins at most 31 bases in front of its sub-context (every parameter set the tables admit); KSSD_SCAN_NO_VEX=1: A/B
-        static const bool no_vex = getenv("KSSD_SCAN_NO_VEX") != nullptr;
-        const bool vex = (pl.flags & KSSD_SKETCH_KEEP_ZERO) && !no_vex && c->P.nb >= 16 && c->P.nb <= 32 && c->P.out >= 0 && c->P.out < 32;
-        a.vex_nb = vex ? (uint32_t)c->P.nb : 0u;
-        a.vex_out = vex ? (uint32_t)c->P.out : 0u;
-    }
     a.cand = reinterpret_cast<ulonglong2 *>(c->d_cand); a.cand_cap = pl.cand_cap; a.cand_count = c->d_cand_count;
     a.rec8 = (c->h_big.empty() && c->h_med.empty()) ? 1u : 0u;  // (= scanned.fused below: the FINISH phase evaluates the candidates itself)
     a.stage1_count = c->d_cand_count + pl.n_slices;
