@@ -16,7 +16,7 @@ import torch
 
 import public_kssd_amd as K
 from benchlib.launch import host_cores, log
-from benchlib.workloads import READ_LEN, make_batch, make_long_records, make_reads_batch, mask_summary
+from benchlib.workloads import READ_LEN, make_batch, make_long_records, make_reads_batch, mask_summary, summary_clear_lanes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -561,12 +561,13 @@ def tokeniser_leg(a, shuf, local, dev, sink, m):
     n_chunks = int(tco[-1])
     tp = torch.zeros(n_chunks * K.CHUNK_WORDS + 64, dtype=torch.int32, device=dev)
     tm = torch.zeros(n_chunks * K.CHUNK_MASKW + 64, dtype=torch.int32, device=dev)
-    rc, bad, npos = ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream)      # (synchronises; also the warm-up)
+    tsumm = torch.zeros(max(n_chunks, 1), dtype=torch.int64, device=dev)   # the mask's summary words, written by the tokeniser with the mask
+    rc, bad, npos = ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, d_summary=tsumm)      # (synchronises; also the warm-up)
     if rc != 0:
         raise SystemExit("tokeniser leg: rc=%d file %d" % (rc, bad))
     text_bytes, positions = int(sink.len.sum()), int(npos.sum())
     reps = max(3, min(10, a.steps))
-    ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, status=False)
+    ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, status=False, d_summary=tsumm)
     torch.cuda.synchronize()
     ctx.kernel_time(2, reset=True)
     ctx.kernel_time(3, reset=True)
@@ -574,7 +575,7 @@ def tokeniser_leg(a, shuf, local, dev, sink, m):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(tstream)
     for _ in range(reps):
-        ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, status=False)
+        ctx.tokenise_fasta_device(sink.text, sink.off, sink.len, tp, tm, tco, stream, status=False, d_summary=tsumm)
     e1.record(tstream)
     torch.cuda.synchronize()
     call_ms = e0.elapsed_time(e1) / reps
@@ -585,7 +586,7 @@ def tokeniser_leg(a, shuf, local, dev, sink, m):
     off = torch.zeros(G + 1, dtype=torch.int64, device=dev)
     ids = torch.zeros(cap, dtype=torch.int32, device=dev)
     for attempt in range(6):
-        ctx.sketch_device(tp, tm, tco, off, ids, cap)
+        ctx.sketch_device(tp, tm, tco, off, ids, cap, d_summary=tsumm)     # (scanned with the tokeniser's own summary words: the product's path)
         rc, total, _ = ctx.sketch_status()
         if rc == 0:
             break
@@ -593,6 +594,12 @@ def tokeniser_leg(a, shuf, local, dev, sink, m):
     assert rc == 0 and int(total) == m["total"], (rc, total, m["total"])
     assert np.array_equal(off.cpu().numpy().view(np.uint64), np.asarray(m["off"]).view(np.uint64)), "tokeniser leg: sketch sizes differ from the packed batch's"
     assert np.array_equal(ids.cpu().numpy().view(np.uint32)[:int(total)], m["ids"][:int(total)]), "tokeniser leg: ids differ from the packed batch's"
+    # how much of the mask the tokeniser's summary words spare the scan: the lanes it leaves clear against the exact count
+    exact = torch.zeros(max(n_chunks, 1), dtype=torch.int64, device=dev)
+    ctx.mask_summarise_device(tm, n_chunks, exact)
+    torch.cuda.synchronize()
+    assert bool(((tsumm & ~exact) == 0).all()), "tokeniser leg: a summary bit is set where the mask holds a run-breaking position"
+    lanes_tok, lanes_exact = summary_clear_lanes(tsumm, n_chunks), summary_clear_lanes(exact, n_chunks)
     ctx.close()
     del tp, tm
     torch.cuda.empty_cache()
@@ -608,6 +615,9 @@ def tokeniser_leg(a, shuf, local, dev, sink, m):
             "summarise_ms": None if one_pass else float(t_sum.mean()), "emit_ms": None if one_pass else float(t_emit.mean()),
             "launches_timed": [len(t_sum), len(t_emit)],
             "call_ms": call_ms, "text_bytes": text_bytes, "positions": positions,
+            "summary_lanes_clear": {"tokeniser": lanes_tok, "exact": lanes_exact, "lanes": n_chunks * 64,
+                                    "what": "lanes of 64 positions whose summary bit the tokeniser leaves clear (the scan fetches their mask words) "
+                                            "against the lanes that really hold a run-breaking position or padding"},
             "text_GBs_whole_call": text_bytes / (call_ms * 1e-3) / 1e9,
             "what": "the device ingests ASCII here (1.0 B per text byte + 0.375 B per position written), the headline's scan ingests the packed form "
                     "(0.375 B/base); `kssd dist` runs this in front of every scan (a-3: iseq2comem.c:213-242).  achieved = algorithmic bytes / the "

@@ -130,8 +130,10 @@ int kssd_gpu_sketch_phase(kssd_gpu_ctx *ctx, int phase, void *stream);
 
 /*
  * The summary level above the validity mask (part of the packed batch layout since round 6; optional): one 64-bit word per
- * chunk, bit l = "the 64 positions [64 l, 64 l + 64) of the chunk are all bases" -- i.e. the reference's run counter
- * (`base`, iseq2comem.c:213-243) is never reset inside them.  With it the scan reads 8 bytes per chunk instead of the chunk's
+ * chunk; a SET bit l says "the 64 positions [64 l, 64 l + 64) of the chunk are all bases" -- i.e. the reference's run counter
+ * (`base`, iseq2comem.c:213-243) is never reset inside them --, a clear bit promises nothing (the scan then looks at the lane's
+ * mask words: kssd_gpu_mask_summarise_device sets every bit that can be set, the device tokeniser leaves the few runs of 64
+ * positions clear that two of its 16 KiB groups share).  With it the scan reads 8 bytes per chunk instead of the chunk's
  * 512 bytes of mask and fetches the two mask words of the lanes whose bit is clear only (a lane with an N, a genome's last
  * lanes, its padding).  Results are identical with and without.
  *   kssd_gpu_mask_summarise_device  writes d_summary[n_chunks] (DEVICE) from d_mask on `stream`: what whoever makes a batch
@@ -239,6 +241,11 @@ void kssd_gpu_free(void *p);
 int kssd_gpu_tokenise_fasta_device(kssd_gpu_ctx *ctx, const uint8_t *d_text, const uint64_t *h_text_off, const uint64_t *h_text_len,
                                    uint32_t n_files, uint32_t *d_packed, uint32_t *d_mask, const uint64_t *h_chunk_off, void *stream);
 int kssd_gpu_tokenise_status(kssd_gpu_ctx *ctx, int64_t *bad_file, uint64_t *h_positions, void *stream);
+/* the same, and the mask's summary words (kssd_gpu_sketch_set_mask_summary) written beside the mask: d_summary = DEVICE
+ * u64[h_chunk_off[n_files]].  kssd_gpu_sketch_fasta_text does this by itself and scans with them. */
+int kssd_gpu_tokenise_fasta_device_summary(kssd_gpu_ctx *ctx, const uint8_t *d_text, const uint64_t *h_text_off, const uint64_t *h_text_len,
+                                           uint32_t n_files, uint32_t *d_packed, uint32_t *d_mask, uint64_t *d_summary,
+                                           const uint64_t *h_chunk_off, void *stream);
 /*
  * host-level: FASTA texts in HOST memory (page-locked for full PCIe speed) -> sketches, tokenised on the device.  One
  * genome per file, layout as above; out_pos may be NULL (then no first positions / counts / stream positions are

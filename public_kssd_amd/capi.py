@@ -50,6 +50,7 @@ GPU_SYMBOLS = [
     "kssd_gpu_resident_sizes", "kssd_gpu_resident_allpairs", "kssd_gpu_runtime_path", "kssd_gpu_exchange_warm_up",
     "kssd_gpu_dist_device_transposed", "kssd_gpu_kernel_times", "kssd_gpu_dist_counts_device", "kssd_gpu_transpose_metrics_device",
     "kssd_gpu_host_register", "kssd_gpu_host_unregister", "kssd_gpu_mask_summarise_device", "kssd_gpu_sketch_set_mask_summary",
+    "kssd_gpu_tokenise_fasta_device_summary",
 ]
 
 
@@ -745,14 +746,21 @@ class GpuCtx:
         res = (off, ids, pos) if with_pos else (off, ids)
         return res + (lines[:n],) if _fastq else res
 
-    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None, fastq=False, status=True):
+    def tokenise_fasta_device(self, d_text, text_off, text_len, d_packed, d_mask, chunk_off, stream=None, fastq=False, status=True, d_summary=None):
         """device-level: raw FASTA (or FASTQ) bytes in HBM -> packed batch in HBM; returns (rc, bad_file, positions per
         file[, lines per file]); status=False: the kernels are enqueued and nothing is synchronised (returns None)"""
         to = np.ascontiguousarray(text_off, dtype=np.uint64)
         tl = np.ascontiguousarray(text_len, dtype=np.uint64)
         co = np.ascontiguousarray(chunk_off, dtype=np.uint64)
-        fn = gpu_lib().kssd_gpu_tokenise_fastq_device if fastq else gpu_lib().kssd_gpu_tokenise_fasta_device
-        _gck(fn(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed), _ptr(d_mask), co.ctypes.data, stream))
+        if d_summary is not None and not fastq:   # (the mask's summary words written beside the mask: u64 per chunk, device)
+            L = gpu_lib()
+            L.kssd_gpu_tokenise_fasta_device_summary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+            _gck(L.kssd_gpu_tokenise_fasta_device_summary(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed), _ptr(d_mask),
+                                                          _ptr(d_summary), co.ctypes.data, stream))
+        else:
+            fn = gpu_lib().kssd_gpu_tokenise_fastq_device if fastq else gpu_lib().kssd_gpu_tokenise_fasta_device
+            _gck(fn(self.h, _ptr(d_text), to.ctypes.data, tl.ctypes.data, len(tl), _ptr(d_packed), _ptr(d_mask), co.ctypes.data, stream))
         if not status:
             return None
         bad = C.c_int64(-1)

@@ -108,6 +108,7 @@ struct kssd_gpu_ctx {
                                    // summary costs a pass over the mask, which a batch that is scanned once does not earn back)
     uint64_t *d_in_summ = nullptr; // ... into this
     size_t cap_in_summ = 0;
+    bool in_summ_valid = false;    // d_in_summ holds the summary words of the resident batch already (the one-pass tokeniser wrote them)
     uint64_t *d_cand;       // candidate list of the last scan (one slice per scan wave)
     size_t cap_cand;
     uint32_t *d_cand_count;
@@ -1343,12 +1344,13 @@ static int sketch_resident_impl(kssd_gpu_ctx *c, const uint64_t *chunk_off, uint
     const double rate = (double)c->P.dim_end / (double)(1ull << (4 * c->P.subk));
     uint64_t out_cap = (uint64_t)((double)n_chunks * KSSD_CHUNK * rate * 1.5) + 1024;
     uint64_t total = 0;
-    if (c->summ_auto && n_chunks) {
+    const bool have_summ = n_chunks && (c->in_summ_valid || c->summ_auto);
+    if (have_summ && !c->in_summ_valid) {
         if ((rc = ensure(&c->d_in_summ, &c->cap_in_summ, (size_t)n_chunks)) != KSSD_OK) return rc;
         if ((rc = kssd_gpu_mask_summarise_device(c, c->d_in_mask, n_chunks, c->d_in_summ, s)) != KSSD_OK) return rc;
     }
     for (int attempt = 0; attempt < 12; attempt++) {
-        if (c->summ_auto && n_chunks) c->d_next_summ = c->d_in_summ;
+        if (have_summ) c->d_next_summ = c->d_in_summ;
         if ((rc = ensure(&c->d_b_ids, &c->cap_b_ids, (size_t)out_cap)) != KSSD_OK) break;
         if (out_pos) {
             if ((rc = ensure(&c->d_b_pos, &c->cap_b_pos, (size_t)out_cap)) != KSSD_OK) break;
@@ -1431,6 +1433,7 @@ static int sketch_batch_impl(kssd_gpu_ctx *c, const uint32_t *packed, const uint
     }
     HIPCK(hipMemsetAsync(c->d_in_packed + pw, 0, KSSD_PACK_SLACK_WORDS * 4, s));  // the slack behind the last chunk: no bases
     HIPCK(hipMemsetAsync(c->d_in_mask + mw, 0, KSSD_PACK_SLACK_WORDS * 4, s));
+    c->in_summ_valid = false;  // (a batch packed on the host comes without summary words)
     return sketch_resident_impl(c, chunk_off, n_genomes, flags, min_occ, out_off, out_ids, out_pos, bad_genome);
 }
 
@@ -1552,8 +1555,18 @@ static int sketch_text_impl(kssd_gpu_ctx *c, const uint8_t *text, const uint64_t
     if ((rc = ensure(&c->d_in_packed, &c->cap_in_packed, (size_t)n_chunks * KSSD_CHUNK_WORDS + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
     if ((rc = ensure(&c->d_in_mask, &c->cap_in_mask, (size_t)n_chunks * KSSD_CHUNK_MASKW + KSSD_PACK_SLACK_WORDS)) != KSSD_OK) return rc;
     if (text_end && text) HIPCK(hipMemcpyAsync(c->d_text, text, (size_t)text_end, hipMemcpyHostToDevice, s));
-    rc = tokenise_device_impl(c, c->d_text, text_off, text_len, n_files, c->d_in_packed, c->d_in_mask, chunk_off.data(), s, fq);
+    // FASTA: the one-pass tokeniser writes the mask's summary words with the mask, and the scan of this batch reads them instead of
+    // streaming the mask (KSSD_TOK_NO_SUMMARY=1: without, A/B)
+    static const bool tok_summ = !getenv("KSSD_TOK_NO_SUMMARY") && !getenv("KSSD_TOK_TWO_PASS");
+    c->in_summ_valid = false;
+    uint64_t *d_summ = nullptr;
+    if (!fq && tok_summ && n_chunks) {
+        if ((rc = ensure(&c->d_in_summ, &c->cap_in_summ, (size_t)n_chunks)) != KSSD_OK) return rc;
+        d_summ = c->d_in_summ;
+    }
+    rc = tokenise_device_impl(c, c->d_text, text_off, text_len, n_files, c->d_in_packed, c->d_in_mask, chunk_off.data(), s, fq, d_summ);
     if (rc != KSSD_OK) return rc;
+    c->in_summ_valid = d_summ != nullptr;
     rc = tokenise_status_impl(c, bad_genome, nullptr, fq ? h_lines : nullptr, s);
     if (rc != KSSD_OK) return rc;
     return sketch_resident_impl(c, chunk_off.data(), n_files, flags, min_occ, out_off, out_ids, out_pos, bad_genome);

@@ -143,3 +143,52 @@ def test_large_genome_paths_with_summaries(shuf_l3k10, monkeypatch):
     S.test_genomes_sorted_in_lds_in_parts(shuf_l3k10)
     S.test_a_wave_that_owns_more_than_2048_chunks(shuf_l3k10)
     S.test_large_genomes_sorted_by_ranges_of_their_keys()
+
+
+def test_the_tokeniser_writes_summary_words_with_the_mask(shuf_l3k10):
+    """kssd_gpu_tokenise_fasta_device_summary: every set bit is a lane whose 64 positions are all bases (never a wrong one, whatever
+    the text: headers, N runs, tiny files, files of hundreds of 16 KiB groups), nearly every such lane is found (the runs of 64
+    positions two groups share stay clear), and the batch sketched with these words gives the sketches it gives without"""
+    import torch
+    import test_gpu_tokenise as T
+    dev = torch.device("cuda", 0)
+    texts = T._cases()
+    ctx = K.GpuCtx(shuf_l3k10, 0)
+    try:
+        buf, offs, lens = ctx._text_layout(texts)
+        co = np.concatenate([[0], np.cumsum([(len(t) + 4095) // 4096 for t in texts])]).astype(np.uint64)
+        n_chunks = int(co[-1])
+        d_text = torch.from_numpy(buf).to(dev)
+        d_packed = torch.zeros(n_chunks * K.CHUNK_WORDS + K.SLACK_WORDS, dtype=torch.int32, device=dev)
+        d_mask = torch.zeros(n_chunks * K.CHUNK_MASKW + K.SLACK_WORDS, dtype=torch.int32, device=dev)
+        d_summ = torch.full((n_chunks,), -1, dtype=torch.int64, device=dev)           # (zeroed by the call)
+        rc, bad, npos = ctx.tokenise_fasta_device(d_text, offs, lens, d_packed, d_mask, co, d_summary=d_summ)
+        assert rc == 0 and bad == -1
+        exact = torch.zeros(n_chunks, dtype=torch.int64, device=dev)
+        ctx.mask_summarise_device(d_mask, n_chunks, exact)
+        torch.cuda.synchronize()
+        got, want = d_summ.cpu().numpy().view(np.uint64), exact.cpu().numpy().view(np.uint64)
+        assert not np.any(got & ~want), "a summary bit is set where the mask holds a run-breaking position"
+        n_got, n_want = int(np.unpackbits(got.view(np.uint8)).sum()), int(np.unpackbits(want.view(np.uint8)).sum())
+        assert n_want > 50_000 and n_got >= 0.98 * n_want, (n_got, n_want)
+        # the same mask without the words: the tokeniser's plain entry point
+        m2 = torch.zeros_like(d_mask)
+        p2 = torch.zeros_like(d_packed)
+        rc, bad, _ = ctx.tokenise_fasta_device(d_text, offs, lens, p2, m2, co)
+        assert rc == 0 and torch.equal(m2, d_mask) and torch.equal(p2, d_packed)
+        # sketched with the tokeniser's words = sketched without
+        cap = int(sum(len(t) for t in texts) / 4096 * 2) + 4096
+        res = []
+        for use in (None, d_summ):
+            off = torch.zeros(len(texts) + 1, dtype=torch.int64, device=dev)
+            ids = torch.zeros(cap, dtype=torch.int32, device=dev)
+            for attempt in range(8):
+                ctx.sketch_device(d_packed, d_mask, co, off, ids, cap, d_summary=use)
+                rc, total, _ = ctx.sketch_status()
+                if rc == 0:
+                    break
+                assert rc == K.capi.ERR_OVERFLOW, rc
+            res.append((off.cpu().numpy().copy(), ids.cpu().numpy()[:int(total)].copy()))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and len(res[0][1]) > 1000
+    finally:
+        ctx.close()
