@@ -1,18 +1,19 @@
 #!/bin/bash
-# round 6: the closing pass's core once more on the round's FINAL kernel sources (after r06Z: the tokeniser's te_compose for both header
+# round 6: the closing pass's core once more on the round's FINAL kernel sources (r06ZZ: after r06Z, the tokeniser's te_compose for both header
 # states at once + its look-back timeout, the exact stage's reordered chain): GPU suite, the driver's command, its kernel trace, the PMC
 # passes (the stamp bench.py checks), the line again with the traffic stamped, the fuzzers that touch what changed
+# (r06ZZ2: once more after the tokeniser learnt to write the mask's summary words -- `kssd dist` scans with them)
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/r06ZZ; mkdir -p $o
+o=gpurun_out/r06ZZ2; mkdir -p $o
 timeout 1800 python -m pytest tests -m gpu -q > $o/tests_gpu.log 2>&1; echo "gpu rc=$?" >> $o/tests_gpu.log
 tail -3 $o/tests_gpu.log
 timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $o/bench.json 2> $o/bench.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $o/prof.json 2> $o/prof.err
 f=$(find $o/prof -name '*kernel_stats.csv' | head -1); cp "$f" $o/kernel_stats.csv; rm -rf $o/prof
-timeout 1500 python3 profiles/pmc_refresh.py r06ZZ > $o/pmc_refresh.txt 2>&1; echo "pmc rc=$?"
+timeout 1500 python3 profiles/pmc_refresh.py r06ZZ2 > $o/pmc_refresh.txt 2>&1; echo "pmc rc=$?"
 cp gpurun_out/pmc_traffic.json $o/pmc_traffic.json 2>/dev/null; cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
-rm -rf gpurun_out/pmc_r06ZZ_FETCH_SIZE gpurun_out/pmc_r06ZZ_WRITE_SIZE
+rm -rf gpurun_out/pmc_r06ZZ2_FETCH_SIZE gpurun_out/pmc_r06ZZ2_WRITE_SIZE
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $o/bench_after_refresh.json 2> $o/bench_after_refresh.err
 timeout 600 python3 profiles/fuzz_cli.py 150 50000 > $o/fuzz_cli.txt 2>&1; tail -1 $o/fuzz_cli.txt
 timeout 400 python3 profiles/fuzz_fastq.py 400 > $o/fuzz_fastq.txt 2>&1; tail -1 $o/fuzz_fastq.txt

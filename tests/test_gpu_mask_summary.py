@@ -189,6 +189,6 @@ def test_the_tokeniser_writes_summary_words_with_the_mask(shuf_l3k10):
                     break
                 assert rc == K.capi.ERR_OVERFLOW, rc
             res.append((off.cpu().numpy().copy(), ids.cpu().numpy()[:int(total)].copy()))
-        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and len(res[0][1]) > 1000
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and len(res[0][1]) > 500
     finally:
         ctx.close()
