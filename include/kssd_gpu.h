@@ -136,7 +136,7 @@ int kssd_gpu_sketch_phase(kssd_gpu_ctx *ctx, int phase, void *stream);
  * positions clear that two of its 16 KiB groups share).  With it the scan reads 8 bytes per chunk instead of the chunk's
  * 512 bytes of mask and fetches the two mask words of the lanes whose bit is clear only (a lane with an N, a genome's last
  * lanes, its padding).  Results are identical with and without.
- *   kssd_gpu_mask_summarise_device  writes d_summary[n_chunks] (DEVICE) from d_mask on `stream`: what whoever makes a batch
+ *   kssd_gpu_mask_summarise_device  writes d_summary[n_chunks] (DEVICE) from d_mask (aligned as for the sketch calls: 16 bytes) on `stream`: what whoever makes a batch
  *                                   resident calls once (the device tokeniser's callers get it with the mask);
  *   kssd_gpu_sketch_set_mask_summary  names the summary of the d_mask of the NEXT kssd_gpu_sketch_plan / _sketch_device call
  *                                   of this context (that one call only; NULL / nothing set: the scan streams the mask).
