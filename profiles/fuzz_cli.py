@@ -118,8 +118,19 @@ for case in range(n_cases):
             ca = {os.path.basename(nm): c1[int(o1[j]):int(o1[j + 1])] for j, nm in enumerate(n1)}
             cb = {os.path.basename(nm): c2[int(o2[j]):int(o2[j + 1])] for j, nm in enumerate(n2)}
             if any(not np.array_equal(ca[x], cb[x]) for x in ca):
-                ok = False
-                print(tag, "ABUNDANCES differ", flush=True)
+                # mt_shortreads2koc's threads test a slot and write it in two steps (iseq2comem.c:598-609): under -p > 1 two reads that
+                # bring the same new k-mer at once both store "1" and an occurrence is lost (profiles/r06long_fuzz_cli.txt, case 30: not
+                # reproducible in twelve repetitions).  The reference's own -p 1 run decides.
+                pa = args[:]; pa[pa.index("-p") + 1] = "1"
+                ko.run_ref(pa + ["-o", "o_ref1", "in"], cwd=d, check=False)
+                h3, n3, o3, i3 = ko.read_sketch_dir(os.path.join(d, "o_ref1"))
+                c3 = np.fromfile(os.path.join(d, "o_ref1", "combco.0.a"), np.uint16)
+                cc = {os.path.basename(nm): c3[int(o3[j]):int(o3[j + 1])] for j, nm in enumerate(n3)}
+                if sorted(cc) == sorted(cb) and all(np.array_equal(cc[x], cb[x]) for x in cc):
+                    print(tag, "abundances differ from the reference's -p", args[args.index("-p") + 1], "run, equal its -p 1 run (not counted)", flush=True)
+                else:
+                    ok = False
+                    print(tag, "ABUNDANCES differ", flush=True)
         if not ok:
             bad += 1
             diff = [x for x in a if x not in b or not np.array_equal(a[x], b[x])]

@@ -81,6 +81,9 @@ struct SketchStatus {
     unsigned int lb_timeout;       // a workgroup of the per-genome kernel gave up waiting for the kept counts in front of it (kssd_dedup.inc: dedup_direct_out)
     unsigned int ranges_skew;      // a large genome's keys do not spread over its id ranges (one id tens of thousands of times, crafted
                                    // ids): the call is repeated with the global-memory sort for large genomes
+    unsigned int parts_skew;       // a genome sorted in parts has more keys in ONE id range than the LDS sort takes although its region held
+                                   // them all (a tandem repeat: hundreds of occurrences of a handful of ids): the call is repeated with such
+                                   // genomes on the global-memory path -- larger regions would not spread them
 };
 
 struct kssd_gpu_ctx {
@@ -193,6 +196,8 @@ struct kssd_gpu_ctx {
     bool resident_valid = false;  // the last sketch call was a host-level one: its batch is in d_in_packed / d_in_mask (kssd_gpu_sketch_again)
     bool results_valid = false;   // ... and it succeeded: d_b_off / d_b_ids hold ITS sketches (kssd_gpu_resident_put copies them)
     uint32_t ranges_off_calls = 0;  // successful calls the switch below still lasts for
+    uint32_t parts_off_calls = 0;
+    bool parts_off = false;  // a batch of this context has shown a part that overflows inside a region that did not: no PARTS launches for a while
     bool ranges_off = false; // a batch of this context has shown keys that do not spread over id ranges: large genomes take the global-memory sort
     int fastq_min_qual = 0;  // kssd_gpu_set_fastq_quality
     bool fastq_reads = false;  // kssd_gpu_set_fastq_reads
@@ -923,7 +928,7 @@ extern "C" int kssd_gpu_sketch_plan(kssd_gpu_ctx *c, const uint32_t *d_packed, c
         // genome must not go back to a path whose room depends on how its ids SPREAD -- a tandem repeat of 190 kb at a dense
         // parameter set stages 38 000 occurrences of a handful of ids, all in one of sixteen parts of 16 384 keys, and every
         // repetition asked for "2.36 x" of a region that was at its limit (profiles/r05E_fuzz_tandem_repeat.txt)
-        const bool no_parts = all_positions && c->region_factor > 2.0;
+        const bool no_parts = (all_positions && c->region_factor > 2.0) || c->parts_off;
         if (cap > big_min) {
             // a genome expected to fit the LDS sort keeps that path -- unless an earlier attempt has shown that this
             // batch emits far more than the sampling rate predicts (low-complexity sequence): then the factor decides
@@ -1287,6 +1292,13 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
         c->cand_floor = (uint64_t)st.cand_need + st.cand_need / 4 + 64;
         return KSSD_ERR_OVERFLOW;
     }
+    if (st.parts_skew) {
+        // (without this switch the factor had to grow until the region left the parts' range: x 1.39 x 1.25 per attempt from 23 to 770 for
+        // a 16 kb repeat under a test's LDS limit of 256 keys -- more attempts than callers make, profiles/r06long_fuzz_sketch.txt)
+        c->parts_off = true;
+        c->parts_off_calls = 4;
+        if (!st.region_overflow && !st.ranges_skew) return KSSD_ERR_OVERFLOW;
+    }
     if (st.ranges_skew && !st.region_overflow) {
         c->ranges_off = true;
         c->ranges_off_calls = 4;  // the repeated call and the further passes callers make over the same batch (occurrences, abundances)
@@ -1309,6 +1321,7 @@ extern "C" int kssd_gpu_sketch_status(kssd_gpu_ctx *c, uint64_t *total_ids, int6
         c->region_factor = f > 2.0 ? f : 2.0;
     }
     if (c->ranges_off && c->ranges_off_calls && c->P.pass == 0 && --c->ranges_off_calls == 0) c->ranges_off = false;  // later batches try the ranges again
+    if (c->parts_off && c->parts_off_calls && c->P.pass == 0 && --c->parts_off_calls == 0) c->parts_off = false;
     if (st.capacity_genome_p1) {
         if (bad_genome) *bad_genome = (int64_t)(0xFFFFFFFFu - st.capacity_genome_p1);
         return KSSD_ERR_CAPACITY;

@@ -738,3 +738,50 @@ def test_tandem_repeat_whose_region_is_all_its_positions_converges():
         assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want), g
     b.close()
     ctx.close()
+
+
+def test_tandem_repeat_in_one_part_leaves_the_parts_path():
+    """Found by profiles/fuzz_sketch.py at its long setting in round 6 (profiles/r06long_fuzz_sketch.txt; parameter set 3 = -k 11 -s 6
+    -l 3, seed 450, the LDS sort limited to 256 keys): a 16 kb tandem repeat stages ~360 occurrences of a handful of ids.  Sorted in
+    parts, all of them meet in ONE id range of 256 keys inside a region that holds them easily; the host answered by growing the regions
+    (x 1.39 x 1.25 per attempt), which moves nothing until the region leaves the parts' range -- at factor 770, more attempts away than
+    a call makes: "output or staging buffer too small".  A part that overflows inside a region that did not now says `parts_skew`, and
+    the repeated call sorts such genomes in global memory.  The batch as the fuzzer made it, ids against the oracle."""
+    pi, (k, s, l) = 3, (11, 6, 3)
+    shuf = K.Shuf.generate(k, s, l, seed=100 + pi)
+    sk = ko.Sketcher(shuf.table, k, s, l)
+    rng = np.random.default_rng(100000 + 1000 * pi + 450)
+    texts = []
+    for g in range(int(rng.integers(1, 12))):
+        kind = int(rng.integers(0, 6))
+        n = int(rng.choice([0, 1, 15, 16, 17, 2 * k - 1, 2 * k, 4095, 4096, 4097, 16383, 16384, 16385, 65536, int(rng.integers(100, 400_000))]))
+        codes = rng.integers(0, 4, n, dtype=np.uint8)
+        if kind == 1 and n > 100:
+            codes = np.tile(codes[: int(rng.integers(1, 50))], n)[:n]
+        nm = np.zeros(n, dtype=bool)
+        if kind == 2 and n:
+            nm[rng.integers(0, n, max(1, n // 500))] = True
+        if kind == 3 and n > 50:
+            a0 = int(rng.integers(0, n - 10))
+            nm[a0:a0 + int(rng.integers(1, 9000))] = True
+        texts.append(fasta_text(codes, b"g%d" % g, n_mask=nm if nm.any() else None))
+    assert any(len(t) > 16_000 for t in texts)
+    ctx = K.GpuCtx(shuf, 0)
+    try:
+        for limit in (256, 64, 1024):
+            ctx.set_lds_sort_limit(limit)
+            b = K.Batch()
+            for t in texts:
+                b.add_fasta(t)
+            off, ids = ctx.sketch_batch(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+            for g, t in enumerate(texts):
+                want = np.zeros(0, np.uint32)
+                if len(t):
+                    wi, wc = sk.fasta(t, with_comps=True)
+                    want = np.sort((wi.astype(np.uint64) << np.uint64(sk.p.comp_bits) | wc.astype(np.uint64)).astype(np.uint32))
+                assert np.array_equal(ids[int(off[g]):int(off[g + 1])], want), (limit, g)
+            off2, ids2, pos2 = ctx.sketch_batch_pos(b, K.SKETCH_FASTA | K.SKETCH_NO_CAPACITY)
+            assert np.array_equal(off2, off) and np.array_equal(ids2, ids)
+            b.close()
+    finally:
+        ctx.close()
