@@ -157,11 +157,14 @@ def test_config1_tutorial_on_real_test_fna_genomes(tmp_path):
     F = os.path.join(G, "test_fna")
     want = np.load(os.path.join(G, "test_fna.npz"))
     os.mkdir(os.path.join(d, "qin"))
-    for fn in os.listdir(os.path.join(F, "seqs2")):
+    os.mkdir(os.path.join(d, "rin"))
+    for fn in ("25_AE016877.fasta.gz", "29_AE016877.fasta.gz"):   # (the directory holds all of test_fna since round 6: test_tutorial_in_full)
         os.symlink(os.path.join(F, "seqs2", fn), os.path.join(d, "qin", fn))
+    for fn in ("10_AE016877.fasta.gz", "AE016877.fasta.gz"):
+        os.symlink(os.path.join(F, "seqs1", fn), os.path.join(d, "rin", fn))
     os.symlink(os.path.join(G, "qry_fa", "edge.fa"), os.path.join(d, "qin", "edge.fa"))
     run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
-    run(["dist", "-L", "L3K10.shuf", "-r", os.path.join(F, "seqs1"), "-o", "refdb"], d)      # sketch + index files
+    run(["dist", "-L", "L3K10.shuf", "-r", "rin", "-o", "refdb"], d)      # sketch + index files
     run(["dist", "-L", "L3K10.shuf", "-o", "qry", "qin"], d)
     run(["dist", "-r", "refdb", "-o", "out", "--keepskf", "qry"], d)
     order = {}
@@ -175,10 +178,44 @@ def test_config1_tutorial_on_real_test_fna_genomes(tmp_path):
     qi = [order["qry"].index(str(n)) for n in want["qry_names"]]
     ri = [order["ref"].index(str(n)) for n in want["ref_names"]]
     assert np.array_equal(sh[np.ix_(qi, ri)], want["shared"])
-    got = open(os.path.join(d, "out", "distance.out")).read().replace(os.path.join(F, "seqs1"), "REF").replace("qin", "QRY")
+    got = open(os.path.join(d, "out", "distance.out")).read().replace("rin/", "REF/").replace("qin", "QRY")
     wt = bytes(want["distance_out"]).decode()
     assert got.splitlines()[0] == wt.splitlines()[0] and sorted(got.splitlines()[1:]) == sorted(wt.splitlines()[1:])
     assert os.path.getsize(os.path.join(d, "refdb", "mco.index.0")) == 8 << 28      # the reference's dense index file
+
+
+def test_tutorial_in_full(tmp_path):
+    """BASELINE configs[0] exactly as the reference's README runs it (README.md:33-45): ALL of test_fna -- seqs1's 20 genomes as
+    references, seqs2's 11 as queries -- through the tutorial's five commands with this build's command line, against what the
+    reference binary left for the same commands (make_golden_tutorial.py): every genome's ids in the reference's file order, both
+    shared matrices by name, both distance.out texts line for line (as sets: the reference orders its inputs by the clock)."""
+    d = str(tmp_path)
+    F = os.path.join(G, "test_fna")
+    want = np.load(os.path.join(G, "tutorial.npz"))
+    for sub in ("seqs1", "seqs2"):
+        os.symlink(os.path.join(F, sub), os.path.join(d, sub))
+    run(["shuffle", "-k", 10, "-s", 6, "-l", 3, "-o", "L3K10", "--seed", META["seed"]], d)
+    run(["dist", "-L", "L3K10.shuf", "-o", "reference", "seqs1"], d)
+    run(["dist", "-o", "reference", "reference"], d)
+    run(["dist", "-L", "L3K10.shuf", "-o", "query", "seqs2"], d)
+    run(["dist", "-r", "reference", "-o", "distout", "--keepskf", "query"], d)
+    run(["dist", "-r", "reference", "-o", "distout2", "--keepskf", "reference"], d)
+    order = {}
+    for sub, dd, n in (("ref", "reference", 20), ("qry", "query", 11)):
+        hdr, names, off, ids = ko.read_sketch_dir(os.path.join(d, dd))
+        order[sub] = [os.path.basename(x) for x in names]
+        assert len(names) == n
+        for i, nm in enumerate(order[sub]):
+            assert np.array_equal(ids[int(off[i]):int(off[i + 1])], want["%s/%s" % (sub, nm)]), (sub, nm)
+    ri = [order["ref"].index(str(x)) for x in want["ref_names"]]
+    sh = np.fromfile(os.path.join(d, "distout", "sharedk_ct.dat"), np.uint32).reshape(11, 20)
+    assert np.array_equal(sh[np.ix_([order["qry"].index(str(x)) for x in want["qry_names"]], ri)], want["shared"])
+    sh2 = np.fromfile(os.path.join(d, "distout2", "sharedk_ct.dat"), np.uint32).reshape(20, 20)
+    assert np.array_equal(sh2[np.ix_([order["ref"].index(str(x)) for x in want["refq_names"]], ri)], want["shared_refs"])
+    for out, key, lines in (("distout", "distance_out", 221), ("distout2", "distance_out_refs", 401)):
+        got = open(os.path.join(d, out, "distance.out")).read().splitlines()
+        wt = bytes(want[key]).decode().splitlines()
+        assert len(got) == lines and got[0] == wt[0] and sorted(got[1:]) == sorted(wt[1:]), out
 
 
 def test_file_order_of_uniq_and_min_occ_modes(tmp_path):
