@@ -259,6 +259,17 @@ def main():
             run_steps(1)
             rc, total, bad = ctx.sketch_status(stream)
             irc = ctx.index_status(stream)        # (a capped index build that overflowed: the next one counts first)
+            if world > 1:
+                # a step holds a collective: the ranks repeat it together or not at all (a rank whose staging regions were too small
+                # while its neighbours' were not would otherwise meet their barrier with its all-gather)
+                flags = torch.tensor([0 if (rc == 0 and irc == 0) else 1,
+                                      0 if (rc in (0, K.capi.ERR_OVERFLOW) and irc in (0, K.capi.ERR_OVERFLOW)) else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+                again, fatal = int(flags[0].item()), int(flags[1].item())
+                if fatal:
+                    raise SystemExit("sketch / index failed on some rank: this rank's rc=%d, %d" % (rc, irc))
+                if again and rc == 0 and irc == 0:
+                    continue
             if rc == 0 and irc == 0:
                 # the index's bound per rank: what the FULLEST rank holds (the full-index partition builds over all ranks' ids with
                 # W x this -- with this rank's own count a fuller neighbour made the bound too small; kssd_gpu_index_status says so
