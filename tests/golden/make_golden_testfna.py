@@ -31,12 +31,12 @@ EXTRA_QRY = os.path.join(HERE, "qry_fa", "edge.fa")
 
 def main():
     assert ko.have_ref(), "oracle/_ref/kssd missing: run `make -C oracle` in the dev container"
-    dst = os.path.join(HERE, "test_fna")
-    shutil.rmtree(dst, ignore_errors=True)
+    dst = os.path.join(HERE, "test_fna")                     # (holds ALL of test_fna since round 6: make_golden_tutorial.py)
     for sub, fns in PICK.items():
-        os.makedirs(os.path.join(dst, sub))
+        os.makedirs(os.path.join(dst, sub), exist_ok=True)
         for fn in fns:
-            shutil.copyfile(os.path.join(SRC, sub, fn), os.path.join(dst, sub, fn))
+            if not os.path.exists(os.path.join(dst, sub, fn)):
+                shutil.copyfile(os.path.join(SRC, sub, fn), os.path.join(dst, sub, fn))
     tmp = tempfile.mkdtemp(prefix="kssd_golden_fna_")
     try:
         shuf = K.Shuf.generate(10, 6, 3, seed=SEED)
@@ -48,11 +48,15 @@ def main():
             os.symlink(os.path.join(dst, "seqs2", fn), os.path.join(qdir, fn))
         os.symlink(EXTRA_QRY, os.path.join(qdir, "edge.fa"))
         # the tutorial (README.md:37-44): reference database from seqs1, query sketches from seqs2, search
-        ko.run_ref(["dist", "-p", 1, "-L", sp, "-r", os.path.join(dst, "seqs1"), "-o", "refdb"], cwd=tmp)
+        rdir = os.path.join(tmp, "rin")                      # the two picked references only
+        os.mkdir(rdir)
+        for fn in PICK["seqs1"]:
+            os.symlink(os.path.join(dst, "seqs1", fn), os.path.join(rdir, fn))
+        ko.run_ref(["dist", "-p", 1, "-L", sp, "-r", rdir, "-o", "refdb"], cwd=tmp)
         ko.run_ref(["dist", "-p", 1, "-L", sp, "-o", "qry", qdir], cwd=tmp)
         ko.run_ref(["dist", "-p", 1, "-r", "refdb", "-o", "out", "--keepskf", "qry"], cwd=tmp)
         text = open(os.path.join(tmp, "out", "distance.out"), "rb").read().decode()
-        text = text.replace(os.path.join(dst, "seqs1"), "REF").replace(qdir, "QRY")
+        text = text.replace(rdir, "REF").replace(qdir, "QRY")
         out = {}
         for sub, d in (("ref", "refdb"), ("qry", "qry")):
             hdr, names, off, ids = ko.read_sketch_dir(os.path.join(tmp, d))
